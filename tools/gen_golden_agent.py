@@ -1,0 +1,428 @@
+"""Agent-level golden fixtures (task layer, learner, full iteration) taken from the reference's
+ADDAgent running on tools/ref_harness.FakeEngine.  Build-container tooling only."""
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+import ref_harness as H
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.learn import PARAM_SHAPES, synth_params  # noqa: E402  (shared deterministic weights)
+
+
+def _save(name, **arrays):
+    from gen_golden import save
+
+    save(name, **arrays)
+
+
+def T(x, dtype=torch.float32):
+    return torch.tensor(np.asarray(x), dtype=dtype)
+
+
+class DrawLog:
+    """Records (and optionally replays) every torch RNG call the reference makes."""
+
+    def __init__(self):
+        self.calls = []
+
+    @contextlib.contextmanager
+    def recording(self):
+        names = ("normal", "bernoulli", "multinomial", "rand", "randperm")
+        orig = {n: getattr(torch, n) for n in names}
+
+        def wrap(n):
+            def f(*a, **k):
+                out = orig[n](*a, **k)
+                self.calls.append((n, out.clone()))
+                return out
+
+            return f
+
+        for n in names:
+            setattr(torch, n, wrap(n))
+        try:
+            yield self
+        finally:
+            for n in names:
+                setattr(torch, n, orig[n])
+
+    def take(self, name):
+        out = [c for n, c in self.calls if n == name]
+        return out
+
+
+def build_agent(num_envs, clip_frames=200, seed=3, two_clip=False, task_over=None, **agent_over):
+    from add_gym.learning.add.add_agent import ADDAgent
+
+    if two_clip:
+        from gen_golden import two_clip_yaml
+
+        mf = two_clip_yaml()[0]
+    else:
+        mf = H.scratch_clip("walk1_subject1_trimmed.motion", clip_frames)
+    cfg = H.load_ref_config(num_envs, mf, **agent_over)
+    if task_over:
+        cfg["task"].update(task_over)
+    torch.manual_seed(seed)
+    ag = ADDAgent(cfg)
+    return ag, cfg
+
+
+def load_synth(ag, seed):
+    sd = ag.state_dict()
+    for k, v in synth_params(seed).items():
+        assert tuple(sd[k].shape) == v.shape, k
+        sd[k] = T(v)
+    ag.load_state_dict(sd)
+
+
+def randomize_sim(ag, rng, lib_time_max, at_times=None):
+    """Plausible simulator state near the reference pose + noise; returns nothing (state lives
+    in the fake entity)."""
+    ent = ag._env.robot.entity
+    n = ent.n
+    obs = ag._add_obs
+    ids = obs._motion_ids
+    t = T(rng.rand(n).astype(np.float32) * lib_time_max)
+    if at_times is not None:
+        t = at_times
+    rp, rr, rv, ra, dp, dv = ag._add_motion.get_motion_step(ids, t)
+    noise = lambda s, shape: T(rng.standard_normal(shape).astype(np.float32) * s)
+    q = rr + noise(0.05, (n, 4))
+    q = q / q.norm(dim=-1, keepdim=True)
+    ent.pos[:] = rp + noise(0.05, (n, 3))
+    ent.quat[:] = q
+    ent.vel[:] = rv + noise(0.2, (n, 3))
+    ent.ang[:] = ra + noise(0.2, (n, 3))
+    ent.dofs_pos[:, 6:] = dp + noise(0.1, (n, 29))
+    ent.dofs_vel[:, 6:] = dv + noise(0.5, (n, 29))
+    ent.dofs_vel[:, 0:3] = ent.vel
+    ent.dofs_vel[:, 3:6] = ent.ang
+
+
+def sim_arrays(ag):
+    r = ag._env.robot
+    return dict(root_pos=r.base_pos.clone(), root_rot=r.base_quat.clone(), root_vel=r.base_lin_vel.clone(),
+                root_ang_vel=r.base_ang_vel.clone(), dof_pos=r.dof_pos.clone(), dof_vel=r.dof_vel.clone())
+
+
+def hist_arrays(obs):
+    names = ("root_pos", "root_rot", "root_vel", "root_ang_vel", "dof_pos", "dof_vel")
+    out = {"hist_" + n: getattr(obs, "_disc_hist_" + n)._buffer.clone() for n in names}
+    out["hist_head"] = obs._disc_hist_root_pos._head
+    return out
+
+
+# ------------------------------------------------------------------------------------
+def gen_obs_reward_done():
+    variants = {
+        "default": {},
+        "local": dict(global_obs=False),
+        "noheight": dict(root_height_obs=False),
+        "local_noheight": dict(global_obs=False, root_height_obs=False),
+        "vel_phase": dict(enable_vel_obs=True, enable_phase_obs=True),
+        "local_vel": dict(global_obs=False, enable_vel_obs=True),
+    }
+    out = {}
+    n = 32
+    for vname, over in variants.items():
+        ag, cfg = build_agent(n, task_over=over)
+        rng = np.random.RandomState(21)
+        ag._reset_envs()
+        obs = ag._add_obs
+        env = ag._env
+        ent = env.robot.entity
+        # a few warm-up steps so that the ring head is not 0 and histories differ per slot
+        for _ in range(2):
+            randomize_sim(ag, rng, 6.0)
+            ag._step_env(torch.zeros(n, 29))
+        # craft time/offset so that TIME, SUCC and FAIL all occur
+        env.time_buf[:] = T(rng.rand(n).astype(np.float32) * 5.0)
+        obs._motion_time_offsets[:] = T(np.floor(rng.rand(n) * 100).astype(np.float32) * 0.01 + 0.02)
+        env.time_buf[0:4] = 19.99  # -> >= 20 after += dt : TIME (or SUCC since past the clip end)
+        obs._motion_time_offsets[0:4] = 0.02
+        obs._motion_time_offsets[0:2] = -15.0  # motion time 5.0 < clip length: TIME survives (flag-logic case)
+        env.time_buf[4:8] = 6.5  # past the 6.633 s clip end -> SUCC
+        obs._motion_time_offsets[4:8] = 0.2
+        randomize_sim(ag, rng, 6.0, at_times=env.time_buf + obs._motion_time_offsets + 0.01)
+        ent.dofs_pos[8:10, 6:] += 3.0  # pose failure
+        ent.pos[10:12, 0] += 2.0  # root failure (only when tracking the global root)
+        ent.forced_contact_link[:] = -1
+        ent.forced_contact_link[12] = 5  # non-foot link (left_hip_roll? any non-contact body) -> FAIL
+        ent.forced_contact_link[13] = 19  # left_ankle_roll_link: allowed contact -> no FAIL
+        pre = dict(time=env.time_buf.clone(), time_off=obs._motion_time_offsets.clone(), motion_ids=obs._motion_ids.clone())
+        pre.update(hist_arrays(obs))
+        target = T(rng.standard_normal((n, 29)).astype(np.float32) * 0.3)
+        pre["sim_pre_dof_pos"] = env.robot.dof_pos.clone()
+        o, r, d, info = ag._step_env(target)
+        post = sim_arrays(ag)
+        contact = env.robot.get_ground_contact_forces_v2(env.plane, ag._add_done._noncontact_body_ids)
+        res = dict(action=target, obs=o.clone(), reward=r.clone(), done=d.clone(), disc_obs=info["disc_obs"].clone(),
+                   disc_obs_demo=info["disc_obs_demo"].clone(), contact=contact, time_post=env.time_buf.clone())
+        res.update({"ref_" + k: getattr(obs, "ref_" + k).clone() for k in ("root_pos", "root_rot", "root_vel", "root_ang_vel", "dof_pos", "dof_vel")})
+        for k, v in {**pre, **post, **res}.items():
+            out[f"{vname}.{k}"] = v
+        out[f"{vname}.noncontact_ids"] = ag._add_done._noncontact_body_ids
+    _save("obs_reward_done", **out)
+
+
+def gen_reset():
+    n = 48
+    out = {}
+    for tag, two in (("one", False), ("two", True)):
+        ag, cfg = build_agent(n, two_clip=two)
+        rng = np.random.RandomState(4)
+        ag._reset_envs()
+        for _ in range(2 if not two else 1):
+            randomize_sim(ag, rng, 1.0)
+            ag._step_env(torch.zeros(n, 29))
+        # non-trivial sampler errors
+        ag._add_motion.sampler.errors = T(rng.rand(*ag._add_motion.sampler.errors.shape).astype(np.float32) * 3 + 0.1)
+        env_ids = T(np.sort(rng.choice(n, 17, replace=False)), torch.long)
+        pre = hist_arrays(ag._add_obs)
+        pre.update(time=ag._env.time_buf.clone(), time_off=ag._add_obs._motion_time_offsets.clone(),
+                   motion_ids=ag._add_obs._motion_ids.clone(), sampler_errors=ag._add_motion.sampler.errors.clone())
+        pre.update({"sim_" + k: v for k, v in sim_arrays(ag).items()})
+        log = DrawLog()
+        with log.recording():
+            o, info = ag._reset_envs(env_ids)
+        mult = log.take("multinomial")
+        post = {"post_" + k: v for k, v in hist_arrays(ag._add_obs).items()}
+        post.update({"post_sim_" + k: v for k, v in sim_arrays(ag).items()})
+        res = dict(env_ids=env_ids, draw_ids=mult[0], draw_segments=mult[1].squeeze(-1), draw_jitter=log.take("rand")[0],
+                   post_time=ag._env.time_buf.clone(), post_time_off=ag._add_obs._motion_time_offsets.clone(),
+                   post_motion_ids=ag._add_obs._motion_ids.clone(), obs=o.clone(), disc_obs=info["disc_obs"].clone(),
+                   disc_obs_demo=info["disc_obs_demo"].clone(), probs=ag._add_motion.sampler.get_probs(mult[0]))
+        for k, v in {**pre, **post, **res}.items():
+            out[f"{tag}.{k}"] = v
+    _save("reset", **out)
+
+
+def gen_sampler():
+    from add_gym.learning.sampler import AdaptiveSegmentSampler
+
+    rng = np.random.RandomState(9)
+    lengths = T([6.6333, 2.0, 9.3])
+    s = AdaptiveSegmentSampler(lengths, 0.01, 20, None, 0.02)
+    m = 4000
+    ids = T(rng.randint(0, 3, m), torch.long)
+    ids[:50] = 1
+    times = T(rng.rand(m).astype(np.float32)) * lengths[ids] * 1.05
+    err = T(rng.rand(m).astype(np.float32) * 4)
+    s.update_errors(ids, times, err)
+    e1 = s.errors.clone()
+    ids2 = T(rng.randint(0, 2, 300), torch.long)  # clip 2 untouched this round
+    times2 = T(rng.rand(300).astype(np.float32)) * lengths[ids2]
+    err2 = T(rng.rand(300).astype(np.float32))
+    s.update_errors(ids2, times2, err2)
+    q = T([0, 2, 2, 1], torch.long)
+    # floor-divide quantisation on its own
+    tt = T(rng.rand(2000).astype(np.float32) * 10)
+    _save("sampler", lengths=lengths, ids=ids, times=times, err=err, errors1=e1, ids2=ids2, times2=times2, err2=err2,
+          errors2=s.errors, probs_ids=q, probs=s.get_probs(q), probs_all=s.get_probs(), segment_sizes=s.segment_sizes,
+          fd_in=tt, fd_out=(tt // 0.01) * 0.01)
+
+
+def gen_actor_step():
+    n = 96
+    ag, cfg = build_agent(n)
+    load_synth(ag, 101)
+    rng = np.random.RandomState(2)
+    ag._reset_envs()
+    randomize_sim(ag, rng, 6.0)
+    obs, _ = ag._reset_envs(T([], torch.long))
+    obs = ag._add_obs._compute_obs()
+    # non-trivial obs normaliser
+    ag._obs_norm.record(obs + T(rng.standard_normal(obs.shape).astype(np.float32)))
+    ag._obs_norm.update()
+    log = DrawLog()
+    with log.recording(), torch.no_grad():
+        a, a_info = ag._decide_action(obs, None)
+    _save("actor_step", seed=101, obs=obs, obs_mean=ag._obs_norm._mean, obs_std=ag._obs_norm._std,
+          a_mean=ag._a_norm._mean, a_std=ag._a_norm._std, noise=log.take("normal")[0], action=a, a_logp=a_info["a_logp"],
+          rand_action_mask=a_info["rand_action_mask"])
+
+
+def gen_td_lambda_adv():
+    import add_gym.learning.base_agent as ba
+
+    n, Tn = 16, 32
+    ag, cfg = build_agent(n)
+    rng = np.random.RandomState(13)
+    r = T(rng.rand(Tn, n).astype(np.float32) * 2)
+    done = T(rng.choice([0, 0, 0, 0, 0, 0, 1, 2, 3], size=(Tn, n)), torch.int32)
+    nv = T(rng.standard_normal((Tn, n)).astype(np.float32) * 3)
+    v = T(rng.standard_normal((Tn, n)).astype(np.float32) * 3)
+    ret = ba.compute_td_lambda_return(r, nv, done, 0.99, 0.95)
+    # run the reference's own advantage code: feed crafted critic outputs through _build_train_data
+    eb = ag._exp_buffer
+    eb._buffers["reward"][:] = r
+    eb._buffers["done"][:] = done
+    eb._buffers["rand_action_mask"][:] = 1.0
+    queue = [nv.unsqueeze(-1).clone(), v.unsqueeze(-1).clone()]
+    ag.model.eval_critic = lambda obs: queue.pop(0)
+    from add_gym.learning import ppo_agent
+
+    info = ppo_agent.PPOAgent._build_train_data(ag)
+    _save("td_lambda_adv", r=r, done=done, next_vals=nv, vals=v, ret_raw=ret, tar_val=eb.get_data("tar_val"),
+          adv=eb.get_data("adv"), adv_mean=info["adv_mean"], adv_std=info["adv_std"])
+
+
+def param_summary(named):
+    out = {}
+    for k, v in named.items():
+        f = v.detach().reshape(-1).double()
+        stride = max(1, f.numel() // 64)
+        out[k + ".sum"] = f.sum()
+        out[k + ".l2"] = f.square().sum().sqrt()
+        out[k + ".sample"] = v.detach().reshape(-1)[::stride][:64].clone()
+    return out
+
+
+def gen_losses():
+    n = 64
+    M = 256
+    ag, cfg = build_agent(n)
+    load_synth(ag, 202)
+    rng = np.random.RandomState(17)
+    # non-trivial normalisers
+    ag._obs_norm._mean[:] = T(rng.standard_normal(264).astype(np.float32) * 0.3)
+    ag._obs_norm._std[:] = T(rng.rand(264).astype(np.float32) + 0.5)
+    ag._disc_obs_norm._mean_abs[:] = T(rng.rand(114).astype(np.float32) * 0.5 + 0.05)
+    batch = dict(
+        obs=T(rng.standard_normal((M, 264)).astype(np.float32)),
+        action=ag._a_norm.unnormalize(T(rng.standard_normal((M, 29)).astype(np.float32) * 0.6)),
+        a_logp=T(rng.standard_normal(M).astype(np.float32) * 3 + 40),
+        adv=T(np.clip(rng.standard_normal(M), -4, 4).astype(np.float32)),
+        tar_val=T(rng.standard_normal(M).astype(np.float32) * 2),
+        rand_action_mask=T((rng.rand(M) < 0.9).astype(np.float32)),
+        disc_obs=T(rng.standard_normal((M, 114)).astype(np.float32)),
+        disc_obs_demo=T(rng.standard_normal((M, 114)).astype(np.float32)),
+    )
+    # make old log-probs consistent with the current policy so that ratios are O(1)
+    with torch.no_grad():
+        dist = ag.model.eval_actor(ag._obs_norm.normalize(batch["obs"]))
+        batch["a_logp"] = dist.log_prob(ag._a_norm.normalize(batch["action"])) + T(rng.standard_normal(M).astype(np.float32) * 0.3)
+    inp = {k: v.clone() for k, v in batch.items()}
+    out = {"in." + k: v for k, v in inp.items()}
+    out.update(obs_mean=ag._obs_norm._mean, obs_std=ag._obs_norm._std, disc_mean_abs=ag._disc_obs_norm._mean_abs,
+               a_mean=ag._a_norm._mean, a_std=ag._a_norm._std, seed=202)
+    names = [n_ for n_, _ in PARAM_SHAPES]
+    sd_params = dict(ag.named_parameters())
+    for step in range(3):
+        info = ag._compute_loss({k: v.clone() for k, v in inp.items()})
+        ag._optimizer.step(info["loss"])
+        if step == 0:
+            for k, v in info.items():
+                out["info." + k] = v.detach()
+            out.update({"grad." + k: v for k, v in param_summary({n_: sd_params[n_].grad for n_ in names}).items()})
+        if step in (0, 2):
+            out.update({f"param{step + 1}." + k: v for k, v in param_summary({n_: sd_params[n_] for n_ in names}).items()})
+    _save("losses", **out)
+
+
+def gen_normalizers():
+    from add_gym.learning.normalizer import Normalizer
+    from add_gym.learning.diff_normalizer import DiffNormalizer
+
+    rng = np.random.RandomState(31)
+    nm = Normalizer((7,), "cpu")
+    dn = DiffNormalizer((5,), "cpu")
+    out = {}
+    for it in range(3):
+        for s in range(4):
+            x = T(rng.standard_normal((33, 7)).astype(np.float32) * (1 + it) + it)
+            y = T(rng.standard_normal((33, 5)).astype(np.float32) * 0.01 * (1 + it))
+            y[:, 0] *= 1e-4
+            nm.record(x)
+            dn.record(y)
+            out[f"x{it}_{s}"], out[f"y{it}_{s}"] = x, y
+        nm.update()
+        dn.update()
+        out[f"mean{it}"], out[f"std{it}"], out[f"count{it}"] = nm._mean.clone(), nm._std.clone(), nm._count.clone()
+        out[f"mean_abs{it}"], out[f"dcount{it}"] = dn._mean_abs.clone(), dn._count.clone()
+    xq = T(rng.standard_normal((9, 7)).astype(np.float32))
+    yq = T(rng.standard_normal((9, 5)).astype(np.float32))
+    out.update(xq=xq, yq=yq, xq_norm=nm.normalize(xq), xq_unnorm=nm.unnormalize(xq), yq_norm=dn.normalize(yq))
+    _save("normalizers", **out)
+
+
+def gen_loop_1iter():
+    n = 32
+    ag, cfg = build_agent(n, seed=5)
+    load_synth(ag, 303)
+    log0 = DrawLog()
+    with log0.recording():
+        ag._curr_obs, ag._curr_info = ag._reset_envs()
+    ag._exp_buffer.clear()
+    perm0 = ag._exp_buffer._sample_buf.clone()
+    # force some early terminations through fake contacts at chosen steps
+    ent = ag._env.robot.entity
+    rng = np.random.RandomState(8)
+    Tn = cfg["agent"]["steps_per_iter"]
+    contact_plan = np.full((Tn, n), -1, np.int64)
+    for t in (3, 9, 10, 20, 27):
+        contact_plan[t, rng.choice(n, 3, replace=False)] = 5
+    step_counter = {"t": 0}
+    orig_step = ag._step_env
+
+    def step_env(action):
+        ent.forced_contact_link[:] = T(contact_plan[step_counter["t"]], torch.long)
+        step_counter["t"] += 1
+        return orig_step(action)
+
+    ag._step_env = step_env
+    log = DrawLog()
+    with log.recording():
+        info = ag._train_iter()
+    # split the draw log per step: each step = normal, bernoulli, [multinomial, multinomial, rand]
+    noise, resets = [], []
+    calls = log.calls
+    i = 0
+    for t in range(Tn):
+        assert calls[i][0] == "normal" and calls[i + 1][0] == "bernoulli"
+        noise.append(calls[i][1])
+        i += 2
+        if calls[i][0] == "multinomial":
+            resets.append((calls[i][1], calls[i + 1][1].squeeze(-1), calls[i + 2][1]))
+            i += 3
+        else:
+            resets.append((torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), torch.zeros(0)))
+    perms = [perm0] + [c for nme, c in calls[i:] if nme == "randperm"]
+    kmax = max(len(r[0]) for r in resets)
+    pad = lambda x, fill, dt: torch.cat([x.to(dt), torch.full((kmax - len(x),), fill, dtype=dt)])
+    eb = ag._exp_buffer
+    out = dict(
+        seed=303, contact_plan=contact_plan, noise=torch.stack(noise),
+        reset_count=np.asarray([len(r[0]) for r in resets]),
+        reset_ids=torch.stack([pad(r[0], 0, torch.long) for r in resets]),
+        reset_segments=torch.stack([pad(r[1], 0, torch.long) for r in resets]),
+        reset_jitter=torch.stack([pad(r[2], 0.0, torch.float32) for r in resets]),
+        init_ids=log0.take("multinomial")[0], init_segments=log0.take("multinomial")[1].squeeze(-1), init_jitter=log0.take("rand")[0],
+        perms=torch.stack(perms),
+        obs_mean=ag._obs_norm._mean, obs_std=ag._obs_norm._std, disc_mean_abs=ag._disc_obs_norm._mean_abs,
+        sampler_errors=ag._add_motion.sampler.errors,
+    )
+    for k in ("obs", "next_obs", "action", "reward", "done", "a_logp", "tar_val", "adv", "disc_obs", "disc_obs_demo", "motion_times"):
+        v = eb.get_data(k)
+        out["buf." + k + ".sum"] = v.double().sum()
+        out["buf." + k + ".abs"] = v.double().abs().sum()
+    out["buf.done"] = eb.get_data("done").clone()
+    out["buf.reward"] = eb.get_data("reward").clone()
+    out["buf.adv"] = eb.get_data("adv").clone()
+    out["buf.motion_times"] = eb.get_data("motion_times").clone()
+    out["buf.obs_last"] = eb.get_data("obs")[-1].clone()
+    for k, v in info.items():
+        out["info." + k] = float(v)
+    names = [n_ for n_, _ in PARAM_SHAPES]
+    sd_params = dict(ag.named_parameters())
+    out.update({"param." + k: v for k, v in param_summary({n_: sd_params[n_] for n_ in names}).items()})
+    _save("loop_1iter", **out)
+
+
+AGENT_GENS = dict(obs_reward_done=gen_obs_reward_done, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
+                  td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
