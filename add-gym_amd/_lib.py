@@ -1,0 +1,146 @@
+"""ctypes binding of libaddhip.so (include/addhip.h).  The product path has no CPU fallback:
+if the HIP library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaddhip.so")
+
+MAX_TAR = 8
+HIST = 3
+POSE_W = 36
+NUM_DOF = 29
+DISC_STEP_W = 9 + NUM_DOF  # pos3 + tan/norm 6 + dof 29
+
+
+class AddhipError(RuntimeError):
+    pass
+
+
+f32p = C.c_void_p  # all device pointers travel as integers (tensor.data_ptr())
+
+
+class MotionT(C.Structure):
+    _fields_ = [("pose", f32p), ("vel", f32p), ("clip_start", f32p), ("clip_steps", f32p), ("clip_len", f32p), ("clip_loop", f32p),
+                ("num_clips", C.c_int32), ("total_steps", C.c_int32), ("reference_compat", C.c_int32), ("dt_inv", C.c_float)]
+
+
+class TaskT(C.Structure):
+    _fields_ = [("dt", C.c_float), ("global_obs", C.c_int32), ("root_height_obs", C.c_int32), ("num_tar_steps", C.c_int32),
+                ("tar_dt", C.c_float * MAX_TAR), ("demo_dt", C.c_float * HIST), ("max_episode_length", C.c_float),
+                ("enable_early_termination", C.c_int32), ("pose_termination", C.c_int32), ("pose_termination_dist", C.c_float),
+                ("pose_w", C.c_float), ("vel_w", C.c_float), ("root_pose_w", C.c_float), ("root_vel_w", C.c_float),
+                ("pose_scale", C.c_float), ("vel_scale", C.c_float), ("root_pose_scale", C.c_float), ("root_vel_scale", C.c_float),
+                ("obs_dim", C.c_int32), ("obs_stride", C.c_int32), ("disc_dim", C.c_int32), ("disc_stride", C.c_int32)]
+
+
+class EnvT(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("sim_pose", f32p), ("sim_vel", f32p), ("time", f32p), ("time_off", f32p), ("motion_id", f32p),
+                ("hist", f32p), ("done", f32p), ("contact", f32p), ("ref_pose", f32p), ("ref_vel", f32p), ("ret_acc", f32p), ("len_acc", f32p)]
+
+
+class StepOutT(C.Structure):
+    _fields_ = [("obs", f32p), ("obs_next_in", f32p), ("disc_obs", f32p), ("disc_demo", f32p), ("reward", f32p), ("done", f32p),
+                ("motion_id_rec", f32p), ("motion_time_rec", f32p), ("ep_stats", f32p)]
+
+
+class SamplerT(C.Structure):
+    _fields_ = [("errors", f32p), ("seg_size", f32p), ("clip_cdf", f32p), ("num_segments", C.c_int32), ("temperature", C.c_float),
+                ("min_start_time", C.c_float), ("rand_reset", C.c_int32), ("temp_bits", f32p), ("err_sum", f32p), ("err_cnt", f32p)]
+
+
+class GemmT(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("A", f32p), ("lda", C.c_int32), ("a_kcontig", C.c_int32),
+                ("B", f32p), ("ldb", C.c_int32), ("b_kcontig", C.c_int32), ("C", f32p), ("ldc", C.c_int32), ("epilogue", C.c_int32),
+                ("bias", f32p), ("mask", f32p), ("ldmask", C.c_int32), ("a_mean", f32p), ("a_std", f32p), ("split_k", C.c_int32),
+                ("alpha", C.c_float)]
+
+
+class GatherT(C.Structure):
+    _fields_ = [("idx", f32p), ("count", C.c_int32), ("obs", f32p), ("obs_stride", C.c_int32), ("obs_dim", C.c_int32), ("obs_mean", f32p),
+                ("obs_std", f32p), ("action", f32p), ("a_mean", f32p), ("a_std", f32p), ("a_logp", f32p), ("adv", f32p), ("tar_val", f32p),
+                ("rand_mask", f32p), ("disc_obs", f32p), ("disc_demo", f32p), ("disc_stride", C.c_int32), ("disc_dim", C.c_int32),
+                ("mean_abs", f32p), ("min_diff", C.c_float), ("norm_obs", f32p), ("norm_action", f32p), ("o_logp", f32p), ("o_adv", f32p),
+                ("o_tar_val", f32p), ("o_mask", f32p), ("norm_diff", f32p)]
+
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
+
+i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+P = C.POINTER
+
+# name -> argtypes (all return int).  Must list every symbol include/addhip.h declares.
+SIGNATURES = {
+    "addhip_env_step": [P(MotionT), P(TaskT), P(EnvT), P(StepOutT), i32, vp],
+    "addhip_env_reset": [P(MotionT), P(TaskT), P(EnvT), P(SamplerT), vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "addhip_motion_lookup": [P(MotionT), vp, vp, i32, vp, vp, vp, vp],
+    "addhip_kin_engine_step": [vp, vp, vp, i32, i32, f32, f32, vp],
+    "addhip_gemm_f32": [P(GemmT), vp],
+    "addhip_slab_reduce": [vp, i32, i64, vp, i64, f32, i32, vp],
+    "addhip_col_sum": [vp, i32, i32, i32, vp, f32, i32, vp],
+    "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp],
+    "addhip_fill_normal": [vp, i64, u64, u64, vp],
+    "addhip_fill_uniform": [vp, i64, u64, u64, vp],
+    "addhip_disc_prep": [vp, vp, i32, i32, i64, vp, f32, vp, vp, vp, P(SamplerT), i32, vp, vp],
+    "addhip_sampler_update": [P(SamplerT), i32, vp],
+    "addhip_disc_reward": [vp, vp, i64, f32, f32, f32, vp, vp],
+    "addhip_head_gemv": [vp, i32, i32, i64, vp, vp, vp, vp],
+    "addhip_td_lambda_adv": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
+    "addhip_norm_accum": [vp, i64, i32, i32, vp, vp, vp],
+    "addhip_norm_merge": [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
+    "addhip_diffnorm_merge": [vp, vp, vp, i64, i32, vp],
+    "addhip_gather_minibatch": [P(GatherT), vp],
+    "addhip_actor_loss": [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
+    "addhip_count_mask": [vp, i32, vp, vp],
+    "addhip_critic_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
+    "addhip_disc_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
+    "addhip_outer_mask": [vp, vp, vp, i32, i32, i64, vp, vp],
+    "addhip_bcast_mask": [vp, vp, i32, i32, i64, vp, vp],
+    "addhip_grad_penalty": [vp, i32, i32, i32, f32, vp, vp, vp],
+    "addhip_weighted_col_sum": [vp, vp, i32, i32, i64, vp, f32, i32, vp],
+    "addhip_l2_grad": [vp, vp, i64, f32, vp, vp],
+    "addhip_adamw": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
+    "addhip_return_tracker_fold": [vp, i32, vp, vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load libaddhip.so (in-tree, built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AddhipError(f"{LIB_PATH} not found: build it with `make -C add-gym_amd/csrc` (or __graft_entry__.build()). "
+                          "There is no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.addhip_last_error.restype = C.c_char_p
+    lib.addhip_version.restype = C.c_int
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise AddhipError(f"{name} failed ({rc}): {lib.addhip_last_error().decode()}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor; None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "addhip buffers must be contiguous"
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

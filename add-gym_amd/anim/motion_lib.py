@@ -1,0 +1,146 @@
+"""Reference-motion library.  One-time host work (torch CPU, same arithmetic as the reference's
+anim/motion_lib.py:164-320 so the 100 Hz step tables are bit-identical to its CPU path), then the
+tables live in HBM packed as pose[S,36] | vel[S,36] and every per-step lookup is a HIP kernel
+(addhip_motion_lookup / fused into addhip_env_step)."""
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from .. import _lib as L
+from ..util import quat as Q
+from . import motion as motion_io
+
+
+def torch_cpu_arange(n, step, vec=8):
+    """fp32 values of torch.arange(0, end, step) on the CPU (what the reference's table clock is,
+    motion_lib.py:296-298), reproduced without depending on the host's vector width: blocks of 2*vec
+    lanes are fl32(fl32(step*block) + lane*step), the tail is fl32(step*i) evaluated in double."""
+    out = np.empty(n, np.float32)
+    nv = (n // (2 * vec)) * (2 * vec)
+    lane = np.arange(vec, dtype=np.float64) * step
+    for b in range(0, nv, vec):
+        out[b:b + vec] = (np.float64(np.float32(step * b)) + lane).astype(np.float32)
+    out[nv:] = (np.arange(nv, n, dtype=np.float64) * step).astype(np.float32)
+    return torch.from_numpy(out)
+
+
+class MotionLib:
+    def __init__(self, motion_file, motion_order, kin_char_model, dt, device, reference_compat=True, frames_list=None, weights=None):
+        self._device, self._kin, self._dt = device, kin_char_model, dt
+        self._dt_inv = round(1 / dt)  # motion_lib.py:23
+        self.reference_compat = bool(reference_compat)
+        if frames_list is None:
+            files, weights = self._fetch_motion_files(motion_file)
+            frames_list = [motion_io.load_motion(f).frames for f in files]
+        self._build(frames_list, weights, list(motion_order))
+
+    # motion_lib.py:337-358
+    @staticmethod
+    def _fetch_motion_files(motion_file):
+        if os.path.splitext(motion_file)[1] == ".yaml":
+            with open(motion_file) as f:
+                entries = yaml.safe_load(f)["motions"]
+            assert all(e["weight"] >= 0 for e in entries)
+            return [e["file"] for e in entries], [e["weight"] for e in entries]
+        return [motion_file], [1.0]
+
+    def _build(self, frames_list, weights, order):
+        kin = self._kin
+        col = torch.tensor([order.index(n) for n in kin.get_joint_order()[1:]], dtype=torch.long)  # motion_lib.py:102-111
+        fps = 30
+        per_clip, lengths, nframes = [], [], []
+        for frames in frames_list:
+            root_pos = torch.tensor(frames[:, 0:3], dtype=torch.float32)
+            root_rot = torch.tensor(frames[:, [6, 3, 4, 5]], dtype=torch.float32)  # xyzw -> wxyz
+            joint_rot = kin.dof_to_rot(torch.tensor(frames[:, 7:], dtype=torch.float32)[:, col])
+            root_vel = torch.zeros_like(root_pos)
+            root_vel[:-1] = fps * (root_pos[1:] - root_pos[:-1])
+            root_vel[-1] = root_vel[-2]
+            root_ang = torch.zeros_like(root_pos)
+            root_ang[:-1] = fps * Q.exp_map(Q.mul(root_rot[1:], Q.conj(root_rot[:-1])))
+            root_ang[-1] = root_ang[-2]
+            dof_vel = kin.compute_frame_dof_vel(joint_rot, 1.0 / fps)
+            per_clip.append((root_pos, root_rot, root_vel, root_ang, joint_rot, dof_vel))
+            nframes.append(frames.shape[0])
+            lengths.append(1.0 / fps * (frames.shape[0] - 1))
+        self._motion_num_frames = torch.tensor(nframes, dtype=torch.long)
+        self._motion_lengths = torch.tensor(lengths, dtype=torch.float32)
+        self._motion_loop_modes = torch.zeros(len(nframes), dtype=torch.int32)
+        w = torch.tensor(weights, dtype=torch.float32)
+        self._motion_weights = w / w.sum()
+        raw_start = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(self._motion_num_frames, 0)[:-1]])
+
+        pose_rows, vel_rows, step_counts = [], [], []
+        for m, (root_pos, root_rot, root_vel, root_ang, joint_rot, dof_vel) in enumerate(per_clip):
+            length = self._motion_lengths[m]
+            n = int(np.ceil(float(length) / self._dt))
+            t = torch_cpu_arange(n, self._dt)
+            phase = torch.clip(t / length, 0.0, 1.0)  # CLAMP clips (motion_lib.py:361-372)
+            nf1 = self._motion_num_frames[m] - 1
+            i0 = (phase * nf1).long()
+            i1 = torch.min(i0 + 1, nf1)
+            blend = phase * nf1 - i0
+            b = blend.unsqueeze(-1)
+            pos = (1.0 - b) * root_pos[i0] + b * root_pos[i1]
+            rot = Q.slerp(root_rot[i0], root_rot[i1], blend)
+            dof = kin.rot_to_dof(Q.slerp(joint_rot[i0], joint_rot[i1], b))
+            pose_rows.append(torch.cat([pos, rot, dof], dim=-1))
+            # velocities are not blended (motion_lib.py:70-76)
+            vel_rows.append(torch.cat([root_vel[i0], root_ang[i0], dof_vel[i0], torch.zeros(n, 1)], dim=-1))
+            step_counts.append(n)
+        self._step_counts = torch.tensor(step_counts, dtype=torch.long)
+        step_start = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(self._step_counts, 0)[:-1]])
+        self.host_pose = torch.cat(pose_rows, 0).contiguous()
+        self.host_vel = torch.cat(vel_rows, 0).contiguous()
+        self._raw_start, self._step_start = raw_start, step_start
+        self.total_steps = int(self._step_counts.sum())
+        self._upload()
+
+    def _upload(self):
+        dev = self._device
+        self.pose = self.host_pose.to(dev)
+        self.vel = self.host_vel.to(dev)
+        start = self._raw_start if self.reference_compat else self._step_start  # motion_lib.py:280-282 quirk
+        self._d_start = start.to(torch.int32).to(dev)
+        self._d_steps = self._step_counts.to(torch.int32).to(dev)
+        self._d_len = self._motion_lengths.to(dev)
+        self._d_loop = self._motion_loop_modes.to(dev)
+        self.c_struct = L.MotionT(L.ptr(self.pose), L.ptr(self.vel), L.ptr(self._d_start), L.ptr(self._d_steps), L.ptr(self._d_len),
+                                  L.ptr(self._d_loop), self.get_num_motions(), self.total_steps, int(self.reference_compat), float(self._dt_inv))
+
+    def get_num_motions(self):
+        return self._motion_lengths.shape[0]
+
+    def get_total_length(self):
+        return torch.sum(self._motion_lengths).item()
+
+    def get_motion_lengths(self):
+        return self._motion_lengths
+
+    def get_motion_weights(self):
+        return self._motion_weights
+
+    def get_motion_length(self, motion_ids):
+        return self._d_len[motion_ids.long()]
+
+    def get_motion_loop_mode(self, motion_ids):
+        return self._d_loop[motion_ids.long()]
+
+    def step_index(self, motion_ids, motion_times):
+        """Row indices only (int32, bit-exact vs motion_lib.py:322-326)."""
+        n = motion_ids.shape[0]
+        idx = torch.empty(n, dtype=torch.int32, device=self._device)
+        L.call("addhip_motion_lookup", self.c_struct, L.ptr(motion_ids.to(torch.int32).contiguous()),
+               L.ptr(motion_times.to(torch.float32).contiguous()), n, L.ptr(idx), None, None, L.current_stream())
+        return idx
+
+    def get_precomputed_motion_step(self, motion_ids, motion_times):
+        """(root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel) like motion_lib.py:322-335."""
+        n = motion_ids.shape[0]
+        pose = torch.empty(n, L.POSE_W, device=self._device)
+        vel = torch.empty(n, L.POSE_W, device=self._device)
+        L.call("addhip_motion_lookup", self.c_struct, L.ptr(motion_ids.to(torch.int32).contiguous()),
+               L.ptr(motion_times.to(torch.float32).contiguous()), n, None, L.ptr(pose), L.ptr(vel), L.current_stream())
+        return pose[:, 0:3], pose[:, 3:7], vel[:, 0:3], vel[:, 3:6], pose[:, 7:], vel[:, 6:35]

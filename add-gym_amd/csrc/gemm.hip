@@ -1,0 +1,287 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 64 FLOP/clk/SIMD)
+// for the dense layers of the actor / critic / discriminator MLPs, forward and backward:
+//   C[M,N] = alpha * sum_k A(m,k) * B(n,k)   with either operand k-contiguous or m/n-contiguous,
+// fused epilogues (bias, bias+ReLU, ReLU-mask of the producing layer), optional fused input
+// normalisation (x-mean)/std on A, and split-K partial slabs for the weight-gradient shapes.
+//
+// Tiling: 256 threads = 4 wavefronts; each wavefront owns a (BM/WM)x(BN/WN) sub-tile made of 32x32
+// MFMA accumulators (64-lane layout: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)).
+// K is walked in 16-deep LDS tiles, double buffered, with the next tile prefetched global->VGPR
+// while the current one feeds the MFMAs.  k-contiguous operands sit in LDS as [row][16+4] and are
+// read with one ds_read_b128 per 8 k (conflict-free: 20-dword stride spreads a 16-lane group over
+// all 64 banks); m/n-contiguous operands sit as [k][rows+4] and are read with ds_read_b32.
+// Workgroup ids are remapped so that the N-tiles sharing an A row-panel run on one XCD (one L2).
+//
+// Replaces: torch.nn.Linear forward/backward inside PPOModel.eval_actor/eval_critic
+// (ppo_model.py:13-21), ADDModel.eval_disc (add_model.py:12-15) and their autograd.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BK = 16;
+constexpr int LDK = BK + 4;
+
+template <int ROWS, bool KC>
+struct Tile {
+  static constexpr int LD = KC ? LDK : (ROWS + 4);
+  static constexpr int SIZE = KC ? ROWS * LDK : BK * (ROWS + 4);
+  static constexpr int F4 = ROWS * BK / 4;            // float4 per tile
+  static constexpr int PER_THREAD = (F4 + 255) / 256;  // float4 per thread
+};
+
+// global -> registers for one operand tile.  (r0: first row of the tile in the M/N extent, k0: first k)
+template <int ROWS, bool KC>
+__device__ __forceinline__ void load_tile(float4* reg, const float* __restrict__ P, int ld, int r0,
+                                          int k0, int R, int kend, const float* mean, const float* stdv) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < Tile<ROWS, KC>::PER_THREAD; ++i) {
+    int f = tid + 256 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < Tile<ROWS, KC>::F4) {
+      if (KC) {
+        int row = f >> 2, kq = (f & 3) * 4;
+        int r = r0 + row, k = k0 + kq;
+        if (r < R && k < kend) {
+          v = *reinterpret_cast<const float4*>(P + (size_t)r * ld + k);
+          if (mean) {  // Normalizer.normalize (normalizer.py:107-110)
+            float4 mu = *reinterpret_cast<const float4*>(mean + k);
+            float4 sd = *reinterpret_cast<const float4*>(stdv + k);
+            v.x = (v.x - mu.x) / sd.x; v.y = (v.y - mu.y) / sd.y; v.z = (v.z - mu.z) / sd.z; v.w = (v.w - mu.w) / sd.w;
+          }
+        }
+      } else {
+        constexpr int RQ = ROWS / 4;
+        int kk = f / RQ, rq = (f - kk * RQ) * 4;
+        int r = r0 + rq, k = k0 + kk;
+        if (r < R && k < kend) v = *reinterpret_cast<const float4*>(P + (size_t)k * ld + r);
+      }
+    }
+    reg[i] = v;
+  }
+}
+
+template <int ROWS, bool KC>
+__device__ __forceinline__ void store_tile(float* lds, const float4* reg) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < Tile<ROWS, KC>::PER_THREAD; ++i) {
+    int f = tid + 256 * i;
+    if (f < Tile<ROWS, KC>::F4) {
+      if (KC) {
+        int row = f >> 2, kq = (f & 3) * 4;
+        *reinterpret_cast<float4*>(lds + row * LDK + kq) = reg[i];
+      } else {
+        constexpr int RQ = ROWS / 4;
+        int kk = f / RQ, rq = (f - kk * RQ) * 4;
+        *reinterpret_cast<float4*>(lds + kk * (ROWS + 4) + rq) = reg[i];
+      }
+    }
+  }
+}
+
+// fragment of one 32-row block for the 8-deep k chunk starting at kk: element j feeds MFMA j
+// (lane half h supplies k = kk + 4h + j; both operands use the same map so the products pair up)
+template <int ROWS, bool KC>
+__device__ __forceinline__ float4 read_frag(const float* lds, int row, int kk, int h) {
+  if (KC) return *reinterpret_cast<const float4*>(lds + row * LDK + kk + 4 * h);
+  const float* p = lds + (kk + 4 * h) * (ROWS + 4) + row;
+  return make_float4(p[0], p[ROWS + 4], p[2 * (ROWS + 4)], p[3 * (ROWS + 4)]);
+}
+
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
+  static_assert(WM * WN == 4, "4 wavefronts");
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
+  static_assert(FM >= 1 && FN >= 1, "wave tile must hold a 32x32 accumulator");
+  using TA = Tile<BM, AKC>;
+  using TB = Tile<BN, BKC>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (TA::SIZE + TB::SIZE)];
+  constexpr int STAGE = TA::SIZE + TB::SIZE;
+
+  // XCD-aware remap (blocks b and b+8 share an XCD): give each XCD a contiguous run of tiles,
+  // N-tile fastest, so the N-tiles of one A row-panel hit the same L2.  Bijective for any count.
+  const int total = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q = total >> 3, r = total & 7, xcd = orig & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // split-K range of this z-slice
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  const int kchunk = ((g.K + split - 1) / split + BK - 1) / BK * BK;
+  const int kbeg = blockIdx.z * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm0 = (wave / WN) * TM, wn0 = (wave % WN) * TN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FN; ++b)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
+
+  float4 ra[TA::PER_THREAD], rb[TB::PER_THREAD];
+  if (nk > 0) {
+    load_tile<BM, AKC>(ra, g.A, g.lda, m0, kbeg, g.M, kend, g.a_mean, g.a_std);
+    load_tile<BN, BKC>(rb, g.B, g.ldb, n0, kbeg, g.N, kend, nullptr, nullptr);
+    store_tile<BM, AKC>(lds, ra);
+    store_tile<BN, BKC>(lds + TA::SIZE, rb);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const float* a_cur = lds + cur * STAGE;
+    const float* b_cur = a_cur + TA::SIZE;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      load_tile<BM, AKC>(ra, g.A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, g.a_mean, g.a_std);
+      load_tile<BN, BKC>(rb, g.B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, nullptr, nullptr);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 8) {
+      float4 fa[FM], fb[FN];
+#pragma unroll
+      for (int a = 0; a < FM; ++a) fa[a] = read_frag<BM, AKC>(a_cur, wm0 + a * 32 + li, kk, lh);
+#pragma unroll
+      for (int b = 0; b < FN; ++b) fb[b] = read_frag<BN, BKC>(b_cur, wn0 + b * 32 + li, kk, lh);
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+        }
+    }
+    if (more) {
+      store_tile<BM, AKC>(lds + (cur ^ 1) * STAGE, ra);
+      store_tile<BN, BKC>(lds + (cur ^ 1) * STAGE + TA::SIZE, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane owns column n0+wn0+b*32+li; register x is row (x&3)+8*(x>>2)+4*lh of the 32x32 tile
+  float* C = g.C + (size_t)blockIdx.z * (size_t)g.M * g.ldc;
+#pragma unroll
+  for (int b = 0; b < FN; ++b) {
+    const int col = n0 + wn0 + b * 32 + li;
+    if (col >= g.N) continue;
+    const float bias = (g.epilogue == ADDHIP_EPI_BIAS || g.epilogue == ADDHIP_EPI_BIAS_RELU) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int row = m0 + wm0 + a * 32 + (x & 3) + 8 * (x >> 2) + 4 * lh;
+        if (row >= g.M) continue;
+        float v = g.alpha * acc[a][b][x] + bias;
+        if (g.epilogue == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        if (g.epilogue == ADDHIP_EPI_MASK) v = g.mask[(size_t)row * g.ldmask + col] > 0.f ? v : 0.f;
+        C[(size_t)row * g.ldc + col] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const addhip_gemm_t& g, hipStream_t st) {
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  dim3 grid(tiles_m * tiles_n, 1, split), block(256);
+#define ADDHIP_LAUNCH(AK, BKc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AK, BKc>), grid, block, 0, st, g, tiles_m, tiles_n)
+  if (g.a_kcontig && g.b_kcontig) ADDHIP_LAUNCH(true, true);
+  else if (g.a_kcontig && !g.b_kcontig) ADDHIP_LAUNCH(true, false);
+  else if (!g.a_kcontig && g.b_kcontig) ADDHIP_LAUNCH(false, true);
+  else ADDHIP_LAUNCH(false, false);
+#undef ADDHIP_LAUNCH
+  return addhip::check_launch("gemm_kernel");
+}
+
+// ------------------------------------------------------------------ small reductions
+__global__ void slab_reduce_kernel(const float* in, int slabs, long long stride, float* out, long long count, float scale, int accumulate) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long step = (long long)gridDim.x * blockDim.x;
+  for (; i < count; i += step) {
+    float s = 0.f;
+    for (int k = 0; k < slabs; ++k) s += in[k * stride + i];
+    s *= scale;
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// column sums of a row-major [M,N] matrix: each block reduces a 64-column strip over a slice of rows
+// into an LDS tile, then one atomicAdd per column per block (out must be pre-scaled/zeroed by the caller
+// when accumulate==0: handled in the wrapper with a memset)
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* X, int M, int N, int ld, float* out, float scale, int rows_per_block) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < N)
+    for (int r = r0 + w; r < r1; r += 4) s += X[(size_t)r * ld + c];
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < N) {
+    float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    atomicAdd(&out[c], t * scale);
+  }
+}
+
+}  // namespace
+
+extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
+  ADDHIP_REQUIRE(gp, "null gemm descriptor");
+  addhip_gemm_t g = *gp;
+  ADDHIP_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem %d x %d x %d", g.M, g.N, g.K);
+  ADDHIP_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
+  ADDHIP_REQUIRE(aligned16(g.A) && aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0), "gemm: operands must be 16-byte aligned with ld %% 4 == 0");
+  if (g.a_kcontig) ADDHIP_REQUIRE(g.K % 4 == 0, "gemm: K must be a multiple of 4 for a k-contiguous A");
+  else ADDHIP_REQUIRE(g.M % 4 == 0, "gemm: M must be a multiple of 4 for an m-contiguous A");
+  if (g.b_kcontig) ADDHIP_REQUIRE(g.K % 4 == 0, "gemm: K must be a multiple of 4 for a k-contiguous B");
+  else ADDHIP_REQUIRE(g.N % 4 == 0, "gemm: N must be a multiple of 4 for an n-contiguous B");
+  ADDHIP_REQUIRE(g.epilogue >= ADDHIP_EPI_NONE && g.epilogue <= ADDHIP_EPI_MASK, "gemm: bad epilogue");
+  if (g.epilogue == ADDHIP_EPI_BIAS || g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_REQUIRE(g.bias, "gemm: bias missing");
+  if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_REQUIRE(g.mask, "gemm: mask missing");
+  if (g.split_k > 1) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_NONE, "gemm: split-K slabs take no epilogue");
+  if (g.a_mean || g.a_std) ADDHIP_REQUIRE(g.a_kcontig && g.a_mean && g.a_std, "gemm: fused normalisation needs a k-contiguous A and both mean/std");
+  if (g.alpha == 0.0f) g.alpha = 1.0f;
+  hipStream_t st = (hipStream_t)stream;
+  if (g.N <= 32) return launch_cfg<128, 32, 4, 1>(g, st);
+  if (g.N <= 64) return launch_cfg<128, 64, 2, 2>(g, st);
+  // keep >= ~1 block per CU on the skinny rollout shapes
+  const long long tiles128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
+  if (tiles128 < 256) return launch_cfg<64, 128, 2, 2>(g, st);
+  return launch_cfg<128, 128, 2, 2>(g, st);
+}
+
+extern "C" int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count, float scale,
+                                  int32_t accumulate, void* stream) {
+  ADDHIP_REQUIRE(in && out && slabs > 0 && count > 0, "slab_reduce: bad arguments");
+  int blocks = (int)((count + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, slabs, (long long)slab_stride, out,
+                     (long long)count, scale, accumulate);
+  return addhip::check_launch("slab_reduce_kernel");
+}
+
+extern "C" int addhip_col_sum(const float* X, int32_t M, int32_t N, int32_t ld, float* out, float scale, int32_t accumulate, void* stream) {
+  ADDHIP_REQUIRE(X && out && M > 0 && N > 0 && ld >= N, "col_sum: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) ADDHIP_HIP(hipMemsetAsync(out, 0, sizeof(float) * N, st));
+  int strips = (N + 63) / 64;
+  int ysplit = 1;
+  while (strips * ysplit < 512 && M / (ysplit * 2) >= 64) ysplit *= 2;
+  int rows_per_block = (M + ysplit - 1) / ysplit;
+  hipLaunchKernelGGL(col_sum_kernel, dim3(strips, ysplit), dim3(256), 0, st, X, M, N, ld, out, scale, rows_per_block);
+  return addhip::check_launch("col_sum_kernel");
+}

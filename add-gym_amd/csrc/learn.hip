@@ -1,0 +1,728 @@
+// Learner-side kernels of the hot path that are not GEMMs: actor sampling, Philox fills, discriminator
+// reward / sampler statistics, TD(lambda) + advantage normalisation, running normalisers, minibatch gather,
+// loss heads (PPO clip, critic MSE, ADD discriminator BCE + gradient penalty), AdamW.  All HBM-bound:
+// one wavefront per row with 64-lane shuffle reductions, or one thread per element, coalesced.
+// Reference functions restated: see include/addhip.h at each entry point.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// sum over a 256-thread block (result valid on thread 0)
+__device__ __forceinline__ float block_sum(float v, float* sh /*[4]*/) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+inline int row_grid(long long rows) {  // 4 waves (rows) per 256-thread block, grid-stride
+  long long g = (rows + 3) / 4;
+  return (int)(g < 2048 ? g : 2048);
+}
+inline int elem_grid(long long n) {
+  long long g = (n + 255) / 256;
+  return (int)(g < 4096 ? g : 4096);
+}
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox(uint64_t ctr, uint64_t stream_id, uint64_t seed) {
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = (uint32_t)stream_id, c3 = (uint32_t)(stream_id >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0,1)
+
+__global__ void fill_uniform_kernel(float* out, long long n, uint64_t seed, uint64_t sid) {
+  long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+  for (; q * 4 < n; q += step) {
+    U4 r = philox((uint64_t)q, sid, seed);
+    float v[4] = {u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
+    for (int k = 0; k < 4; ++k)
+      if (q * 4 + k < n) out[q * 4 + k] = v[k];
+  }
+}
+__global__ void fill_normal_kernel(float* out, long long n, uint64_t seed, uint64_t sid) {
+  long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+  for (; q * 4 < n; q += step) {
+    U4 r = philox((uint64_t)q, sid, seed);
+    float u1 = 1.0f - u01(r.x), u2 = u01(r.y), u3 = 1.0f - u01(r.z), u4 = u01(r.w);  // (0,1]
+    float ra = sqrtf(-2.0f * logf(u1)), rb = sqrtf(-2.0f * logf(u3));
+    float v[4] = {ra * cosf(6.2831853071795865f * u2), ra * sinf(6.2831853071795865f * u2),
+                  rb * cosf(6.2831853071795865f * u4), rb * sinf(6.2831853071795865f * u4)};
+    for (int k = 0; k < 4; ++k)
+      if (q * 4 + k < n) out[q * 4 + k] = v[k];
+  }
+}
+
+// ------------------------------------------------------------------ rollout actor head
+__global__ __launch_bounds__(256) void actor_sample_kernel(const float* mean, int ldm, const float* noise, float stdv, float logp_const,
+                                                           const float* a_mean, const float* a_std, int n, int deterministic,
+                                                           float* action, float* a_logp, float* rand_mask) {
+  const int lane = threadIdx.x & 63;
+  for (int env = blockIdx.x * 4 + (threadIdx.x >> 6); env < n; env += gridDim.x * 4) {
+    float sq = 0.f, act = 0.f;
+    if (lane < ADDHIP_NUM_DOF) {
+      float mu = mean[(size_t)env * ldm + lane];
+      float na = deterministic ? mu : __fadd_rn(mu, __fmul_rn(stdv, noise[(size_t)env * ADDHIP_NUM_DOF + lane]));
+      float d = __fdiv_rn(__fsub_rn(na, mu), stdv);
+      sq = __fmul_rn(d, d);
+      act = __fadd_rn(__fmul_rn(na, a_std[lane]), a_mean[lane]);  // Normalizer.unnormalize
+    }
+    sq = wave_sum(sq);
+    if (lane < 32) action[(size_t)env * 32 + lane] = act;
+    if (lane == 0) {
+      a_logp[env] = __fadd_rn(__fmul_rn(-0.5f, sq), logp_const);
+      rand_mask[env] = deterministic ? 0.f : 1.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ build-train-data
+__global__ __launch_bounds__(256) void disc_prep_kernel(const float* dobs, const float* ddemo, int stride, int dim, long long rows,
+                                                        const float* mean_abs, float min_diff, float* norm_diff, const int* motion_id,
+                                                        const float* motion_time, addhip_sampler_t s, int cells, float* abs_sum) {
+  extern __shared__ float sh[];  // [cells] err sums | [cells] counts | [4][stride] abs partials
+  float* sh_sum = sh;
+  float* sh_cnt = sh + cells;
+  float* sh_abs = sh + 2 * cells;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 2 * cells; i += 256) sh[i] = 0.f;
+  float a0 = 0.f, a1 = 0.f;  // |diff| partials for columns lane, lane+64
+  __syncthreads();
+  for (long long row = (long long)blockIdx.x * 4 + w; row < rows; row += (long long)gridDim.x * 4) {
+    float err = 0.f;
+    for (int c = lane, k = 0; c < stride; c += 64, ++k) {
+      float v = 0.f;
+      if (c < dim) {
+        float ag = dobs[row * stride + c], de = ddemo[row * stride + c];
+        float d = de - ag;
+        float e = ag - de;
+        err += e * e;
+        v = d / fmaxf(mean_abs[c], min_diff);
+        if (k == 0) a0 += fabsf(d); else a1 += fabsf(d);
+      }
+      if (norm_diff) norm_diff[row * stride + c] = v;
+    }
+    err = wave_sum(err);
+    if (lane == 0 && motion_id) {  // AdaptiveSegmentSampler.update_errors index math (sampler.py:27-35)
+      int id = motion_id[row];
+      float seg = fmaxf(s.seg_size[id], 1e-6f);
+      long long si = (long long)(motion_time[row] / seg);
+      si = si < 0 ? 0 : (si > s.num_segments - 1 ? s.num_segments - 1 : si);
+      atomicAdd(&sh_sum[id * s.num_segments + (int)si], err);
+      atomicAdd(&sh_cnt[id * s.num_segments + (int)si], 1.0f);
+    }
+  }
+  if (abs_sum) {
+    sh_abs[w * stride + lane] = a0;
+    if (lane + 64 < stride) sh_abs[w * stride + lane + 64] = a1;
+  }
+  __syncthreads();
+  if (abs_sum)
+    for (int c = threadIdx.x; c < dim; c += 256)
+      atomicAdd(&abs_sum[c], sh_abs[c] + sh_abs[stride + c] + sh_abs[2 * stride + c] + sh_abs[3 * stride + c]);
+  if (motion_id)
+    for (int i = threadIdx.x; i < cells; i += 256)
+      if (sh_cnt[i] > 0.f) {
+        atomicAdd(&s.err_sum[i], sh_sum[i]);
+        atomicAdd(&s.err_cnt[i], sh_cnt[i]);
+      }
+}
+
+__global__ void sampler_update_kernel(addhip_sampler_t s, int cells) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cells) return;
+  float c = s.err_cnt[i];
+  if (c > 0.f) s.errors[i] = 0.9f * s.errors[i] + 0.1f * (s.err_sum[i] / c);  // sampler.py:52-55
+  s.err_sum[i] = 0.f;
+  s.err_cnt[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void disc_reward_kernel(const float* logits, float* reward, long long n, float scale, float task_w,
+                                                          float disc_w, float* stats) {
+  __shared__ float sh[4];
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float prob = 1.0f / (1.0f + expf(-logits[i]));
+    float dr = -logf(fmaxf(1.0f - prob, 0.0001f)) * scale;  // amp_agent.py:200-205
+    reward[i] = task_w * reward[i] + disc_w * dr;           // add_agent.py:124
+    s1 += dr;
+    s2 += dr * dr;
+  }
+  float t1 = block_sum(s1, sh);
+  float t2 = block_sum(s2, sh);
+  if (threadIdx.x == 0 && stats) {
+    atomicAdd(&stats[0], t1);
+    atomicAdd(&stats[1], t2);
+  }
+}
+
+__global__ __launch_bounds__(256) void head_gemv_kernel(const float* H, int ld, int K, long long rows, const float* w, const float* b, float* out) {
+  const int lane = threadIdx.x & 63;
+  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    float acc = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      float4 h = *reinterpret_cast<const float4*>(H + row * ld + k);
+      float4 ww = *reinterpret_cast<const float4*>(w + k);
+      acc += h.x * ww.x + h.y * ww.y + h.z * ww.z + h.w * ww.w;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[row] = acc + b[0];
+  }
+}
+
+// ------------------------------------------------------------------ TD(lambda) + advantage
+__global__ __launch_bounds__(256) void td_lambda_kernel(const float* reward, float* next_vals, const float* vals, const int* done,
+                                                        const float* rand_mask, int T, int N, float discount, float lam, float succ_val,
+                                                        float fail_val, float* tar_val, float* adv, double* partial) {
+  __shared__ double shd[3][4];
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+  if (n < N) {
+    float next_ret = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+      const size_t i = (size_t)t * N + n;
+      const int d = done[i];
+      float nv = next_vals[i];
+      if (d == ADDHIP_DONE_SUCC) nv = succ_val;  // ppo_agent.py:127-133
+      if (d == ADDHIP_DONE_FAIL) nv = fail_val;
+      next_vals[i] = nv;
+      float ret;
+      if (t == T - 1) {
+        ret = __fadd_rn(reward[i], __fmul_rn(discount, nv));  // base_agent.py:632-633
+      } else {
+        float reset = d != ADDHIP_DONE_NULL ? 1.f : 0.f;
+        float cl = __fmul_rn(lam, __fsub_rn(1.f, reset));
+        float mix = __fadd_rn(__fmul_rn(__fsub_rn(1.f, cl), nv), __fmul_rn(cl, next_ret));
+        ret = __fadd_rn(reward[i], __fmul_rn(discount, mix));  // base_agent.py:641-644
+      }
+      next_ret = ret;
+      tar_val[i] = ret;
+      float a = __fsub_rn(ret, vals[i]);
+      adv[i] = a;
+      if (rand_mask[i] == 1.0f) { s1 += a; s2 += (double)a * a; cnt += 1.0; }
+    }
+  }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); cnt = wave_sum_d(cnt);
+  if ((threadIdx.x & 63) == 0) { shd[0][threadIdx.x >> 6] = s1; shd[1][threadIdx.x >> 6] = s2; shd[2][threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[3 * blockIdx.x + 0] = shd[0][0] + shd[0][1] + shd[0][2] + shd[0][3];
+    partial[3 * blockIdx.x + 1] = shd[1][0] + shd[1][1] + shd[1][2] + shd[1][3];
+    partial[3 * blockIdx.x + 2] = shd[2][0] + shd[2][1] + shd[2][2] + shd[2][3];
+  }
+}
+__global__ void adv_stats_kernel(const double* partial, int blocks, float* stats_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s1 = 0, s2 = 0, c = 0;
+  for (int b = 0; b < blocks; ++b) { s1 += partial[3 * b]; s2 += partial[3 * b + 1]; c += partial[3 * b + 2]; }
+  double mean = c > 0 ? s1 / c : 0.0;
+  double var = c > 1 ? (s2 - c * mean * mean) / (c - 1.0) : 0.0;  // unbiased (torch.std_mean, ppo_agent.py:147)
+  stats_out[0] = (float)mean;
+  stats_out[1] = (float)sqrt(var > 0 ? var : 0.0);
+}
+__global__ void adv_norm_kernel(float* adv, long long n, const float* stats, float clip) {
+  const float mean = stats[0], sd = fmaxf(stats[1], 1e-5f);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = __fdiv_rn(__fsub_rn(adv[i], mean), sd);
+    adv[i] = fminf(fmaxf(v, -clip), clip);  // ppo_agent.py:149-150
+  }
+}
+
+// ------------------------------------------------------------------ normalisers
+__global__ __launch_bounds__(256) void norm_accum_kernel(const float* X, long long rows, int dim, int ld, float* sum, float* sumsq, long long rows_per_block) {
+  __shared__ float p1[4][64], p2[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < dim)
+    for (long long r = r0 + w; r < r1; r += 4) { float x = X[r * ld + c]; s1 += x; s2 += x * x; }
+  p1[w][threadIdx.x & 63] = s1; p2[w][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (w == 0 && c < dim) {
+    atomicAdd(&sum[c], p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x]);
+    if (sumsq) atomicAdd(&sumsq[c], p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x]);
+  }
+}
+__global__ void norm_merge_kernel(float* mean, float* stdv, float* mean_sq, long long* count, float* sum, float* sumsq, long long new_count,
+                                  int dim, float min_var, int first) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long old = *count;
+  __syncthreads();
+  if (i < dim && new_count > 0) {
+    float msq = first ? stdv[i] * stdv[i] + mean[i] * mean[i] : mean_sq[i];  // normalizer.py:38-39,134-137
+    const long long total = old + new_count;
+    const float w_old = (float)old / (float)total, w_new = (float)new_count / (float)total;
+    float nm = sum[i] / (float)new_count, nsq = sumsq[i] / (float)new_count;
+    float m = w_old * mean[i] + w_new * nm;
+    msq = w_old * msq + w_new * nsq;
+    mean[i] = m;
+    mean_sq[i] = msq;
+    stdv[i] = sqrtf(fmaxf(msq - m * m, min_var));
+    sum[i] = 0.f;
+    sumsq[i] = 0.f;
+  }
+  __syncthreads();
+  if (i == 0 && new_count > 0) *count = old + new_count;
+}
+__global__ void diffnorm_merge_kernel(float* mean_abs, long long* count, float* abs_sum, long long new_count, int dim) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long old = *count;
+  __syncthreads();
+  if (i < dim) {
+    const long long total = old + new_count;
+    const float w_old = (float)old / (float)total, w_new = (float)new_count / (float)total;
+    mean_abs[i] = w_old * mean_abs[i] + w_new * (abs_sum[i] / (float)new_count);  // diff_normalizer.py:33-45
+    abs_sum[i] = 0.f;
+  }
+  __syncthreads();
+  if (i == 0) *count = old + new_count;
+}
+
+// ------------------------------------------------------------------ minibatch gather
+__global__ __launch_bounds__(256) void gather_kernel(addhip_gather_t g) {
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < g.count; r += gridDim.x * 4) {
+    const long long src = g.idx[r];
+    for (int c = lane; c < g.obs_stride; c += 64)
+      g.norm_obs[(size_t)r * g.obs_stride + c] = c < g.obs_dim ? (g.obs[src * g.obs_stride + c] - g.obs_mean[c]) / g.obs_std[c] : 0.f;
+    if (lane < 32)
+      g.norm_action[(size_t)r * 32 + lane] = lane < ADDHIP_NUM_DOF ? (g.action[src * 32 + lane] - g.a_mean[lane]) / g.a_std[lane] : 0.f;
+    for (int c = lane; c < g.disc_stride; c += 64) {
+      float v = 0.f;
+      if (c < g.disc_dim) v = (g.disc_demo[src * g.disc_stride + c] - g.disc_obs[src * g.disc_stride + c]) / fmaxf(g.mean_abs[c], g.min_diff);
+      g.norm_diff[(size_t)r * g.disc_stride + c] = v;
+    }
+    if (lane == 0) {
+      g.o_logp[r] = g.a_logp[src];
+      g.o_adv[r] = g.adv[src];
+      g.o_tar_val[r] = g.tar_val[src];
+      g.o_mask[r] = g.rand_mask[src];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ loss heads
+__global__ __launch_bounds__(256) void count_mask_kernel(const float* mask, int M, float* out) {
+  __shared__ float sh[4];
+  float c = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) c += mask[i] == 1.0f ? 1.f : 0.f;
+  float t = block_sum(c, sh);
+  if (threadIdx.x == 0) atomicAdd(out, t);
+}
+
+__global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, const float* na, const float* old_logp, const float* adv,
+                                                         const float* mask, int M, float stdv, float logp_const, float clip, float bound_w,
+                                                         float loss_scale, const float* n_valid, float* d_mean, float* stats) {
+  __shared__ float sh[4];
+  const int lane = threadIdx.x & 63;
+  const float nv = fmaxf(n_valid[0], 1.f);
+  float st_min = 0.f, st_clip = 0.f, st_ratio = 0.f, st_bound = 0.f;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
+    const bool valid = mask[r] == 1.0f;  // ppo_agent.py:229-233
+    float mu = 0.f, d = 0.f, viol = 0.f;
+    if (lane < ADDHIP_NUM_DOF) {
+      mu = mean[(size_t)r * 32 + lane];
+      d = (na[(size_t)r * 32 + lane] - mu) / stdv;
+      viol = fminf(mu + 1.f, 0.f) + fmaxf(mu - 1.f, 0.f);  // base_agent.py:536-541 (one of the two is 0)
+    }
+    float sq = wave_sum(d * d);
+    float vs = wave_sum(viol * viol);
+    float logp = -0.5f * sq + logp_const;
+    float ratio = expf(logp - old_logp[r]);
+    float a = adv[r];
+    float l0 = a * ratio;
+    float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+    float l1 = a * rc;
+    bool inrange = ratio >= 1.f - clip && ratio <= 1.f + clip;
+    float gsel = l0 < l1 ? 1.f : (l0 == l1 ? (inrange ? 1.f : 0.5f) : 0.f);  // torch.minimum / clamp subgradients
+    float g_logp = valid ? -(a * gsel * ratio) / nv : 0.f;
+    if (lane < 32) {
+      float g = 0.f;
+      if (valid && lane < ADDHIP_NUM_DOF) g = g_logp * (d / stdv) + bound_w * 2.f * viol / nv;
+      d_mean[(size_t)r * 32 + lane] = loss_scale * g;
+    }
+    if (valid && lane == 0) {
+      st_min += fminf(l0, l1);
+      st_clip += fabsf(ratio - 1.f) > clip ? 1.f : 0.f;
+      st_ratio += ratio;
+      st_bound += vs;
+    }
+  }
+  float t0 = block_sum(st_min, sh), t1 = block_sum(st_clip, sh), t2 = block_sum(st_ratio, sh), t3 = block_sum(st_bound, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[0], t0); atomicAdd(&stats[1], t1); atomicAdd(&stats[2], t2); atomicAdd(&stats[3], t3);
+  }
+}
+
+__global__ __launch_bounds__(256) void critic_head_kernel(const float* H, int ld, int K, int M, const float* w, const float* b, const float* tar,
+                                                          float loss_scale, float* dZ, float* dv_out, float* stats) {
+  __shared__ float sh[4];
+  const int lane = threadIdx.x & 63;
+  float se = 0.f;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
+    float acc = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      float4 h = *reinterpret_cast<const float4*>(H + (size_t)r * ld + k);
+      float4 ww = *reinterpret_cast<const float4*>(w + k);
+      acc += h.x * ww.x + h.y * ww.y + h.z * ww.z + h.w * ww.w;
+    }
+    float v = wave_sum(acc) + b[0];
+    float diff = tar[r] - v;  // ppo_agent.py:215-216
+    float dv = loss_scale * 2.f * (v - tar[r]) / (float)M;
+    for (int k = lane * 4; k < K; k += 256) {
+      float4 h = *reinterpret_cast<const float4*>(H + (size_t)r * ld + k);
+      float4 ww = *reinterpret_cast<const float4*>(w + k);
+      float4 o = make_float4(h.x > 0.f ? dv * ww.x : 0.f, h.y > 0.f ? dv * ww.y : 0.f, h.z > 0.f ? dv * ww.z : 0.f, h.w > 0.f ? dv * ww.w : 0.f);
+      *reinterpret_cast<float4*>(dZ + (size_t)r * ld + k) = o;
+    }
+    if (lane == 0) { dv_out[r] = dv; se += diff * diff; }
+  }
+  float t = block_sum(se, sh);
+  if (threadIdx.x == 0) atomicAdd(&stats[0], t);
+}
+
+__device__ __forceinline__ float bce_logits(float x, float y) { return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void disc_head_kernel(const float* H, int ld, int K, int M, const float* h_pos, const float* w, const float* b,
+                                                        float loss_scale, float* dlogit, float* dlogit_pos, float* stats) {
+  __shared__ float sh[4];
+  const int lane = threadIdx.x & 63;
+  float s_bce = 0.f, s_logit = 0.f, s_acc = 0.f;
+  // row M is the single zero-difference "positive" sample (add_agent.py:145-149)
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r <= M; r += gridDim.x * 4) {
+    const float* row = r < M ? H + (size_t)r * ld : h_pos;
+    float acc = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      float4 h = *reinterpret_cast<const float4*>(row + k);
+      float4 ww = *reinterpret_cast<const float4*>(w + k);
+      acc += h.x * ww.x + h.y * ww.y + h.z * ww.z + h.w * ww.w;
+    }
+    float x = wave_sum(acc) + b[0];
+    if (lane == 0) {
+      if (r < M) {
+        dlogit[r] = loss_scale * 0.5f * (sigmoidf(x) - 0.1f) / (float)M;  // amp_agent.py:177-180
+        s_bce += bce_logits(x, 0.1f); s_logit += x; s_acc += x < 0.f ? 1.f : 0.f;
+      } else {
+        dlogit_pos[0] = loss_scale * 0.5f * (sigmoidf(x) - 0.9f);          // amp_agent.py:182-185
+        atomicAdd(&stats[1], bce_logits(x, 0.9f));
+        atomicAdd(&stats[3], x);
+        atomicAdd(&stats[5], x > 0.f ? 1.f : 0.f);
+      }
+    }
+  }
+  float t0 = block_sum(s_bce, sh), t2 = block_sum(s_logit, sh), t4 = block_sum(s_acc, sh);
+  if (threadIdx.x == 0) { atomicAdd(&stats[0], t0); atomicAdd(&stats[2], t2); atomicAdd(&stats[4], t4); }
+}
+
+__global__ void outer_mask_kernel(const float* v, const float* w, const float* H, int ld, int K, long long rows, float* out) {
+  const long long n = rows * (K / 4);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    long long r = i / (K / 4);
+    int k = (int)(i - r * (K / 4)) * 4;
+    float4 h = *reinterpret_cast<const float4*>(H + r * ld + k);
+    float4 ww = *reinterpret_cast<const float4*>(w + k);
+    float s = v ? v[r] : 1.f;
+    float4 o = make_float4(h.x > 0.f ? s * ww.x : 0.f, h.y > 0.f ? s * ww.y : 0.f, h.z > 0.f ? s * ww.z : 0.f, h.w > 0.f ? s * ww.w : 0.f);
+    *reinterpret_cast<float4*>(out + r * ld + k) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void grad_penalty_kernel(const float* g, int ld, int dim, int M, float coef, float* G, float* stats) {
+  __shared__ float sh[4];
+  const int lane = threadIdx.x & 63;
+  float sp = 0.f;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
+    float sq = 0.f;
+    for (int c = lane; c < dim; c += 64) { float x = g[(size_t)r * ld + c]; sq += x * x; }
+    sq = wave_sum(sq);
+    float n = sqrtf(sq + 1e-8f);  // add_agent.py:176
+    float f = coef * 2.f * (n - 1.f) / n / (float)M;
+    for (int c = lane; c < ld; c += 64) G[(size_t)r * ld + c] = c < dim ? f * g[(size_t)r * ld + c] : 0.f;
+    if (lane == 0) sp += (n - 1.f) * (n - 1.f);
+  }
+  float t = block_sum(sp, sh);
+  if (threadIdx.x == 0) atomicAdd(&stats[0], t);
+}
+
+__global__ __launch_bounds__(256) void weighted_col_sum_kernel(const float* v, const float* X, int ld, int K, long long rows, float* out, float scale,
+                                                               long long rows_per_block) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float s = 0.f;
+  if (c < K)
+    for (long long r = r0 + w; r < r1; r += 4) s += v[r] * X[r * ld + c];
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < K) atomicAdd(&out[c], scale * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+__global__ __launch_bounds__(256) void l2_grad_kernel(const float* w, float* grad, long long n, float coef, float* sumsq) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float x = w[i];
+    grad[i] += coef * x;
+    s += x * x;
+  }
+  float t = block_sum(s, sh);
+  if (threadIdx.x == 0 && sumsq) atomicAdd(sumsq, t);
+}
+
+// torch.optim.AdamW single-tensor update order (weight decay, lerp, addcmul, sqrt/bias2 + eps, addcdiv)
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,
+                             float step_size, float bc2_sqrt) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    float pi = p[i] * (1.f - lr * wd);
+    float mi = m[i] + (1.f - b1) * (gi - m[i]);
+    float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+__global__ void return_tracker_fold_kernel(const float* ep, int T, float* state) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float episodes = state[0], mret = state[1], mlen = state[2];
+  for (int t = 0; t < T; ++t) {
+    float k = ep[3 * t + 2];
+    if (k > 0.f) {  // base_agent.py:606-617
+      float new_ret = ep[3 * t] / k, new_len = ep[3 * t + 1] / k;
+      float cnt = episodes + k;
+      float w_new = k / cnt, w_old = episodes / cnt;
+      mret = w_new * new_ret + w_old * mret;
+      mlen = w_new * new_len + w_old * mlen;
+      episodes = cnt;
+    }
+  }
+  state[0] = episodes; state[1] = mret; state[2] = mlen;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int addhip_fill_normal(float* out, int64_t count, uint64_t seed, uint64_t stream_id, void* stream) {
+  ADDHIP_REQUIRE(out && count > 0, "fill_normal: bad arguments");
+  hipLaunchKernelGGL(fill_normal_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id);
+  return addhip::check_launch("fill_normal_kernel");
+}
+extern "C" int addhip_fill_uniform(float* out, int64_t count, uint64_t seed, uint64_t stream_id, void* stream) {
+  ADDHIP_REQUIRE(out && count > 0, "fill_uniform: bad arguments");
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id);
+  return addhip::check_launch("fill_uniform_kernel");
+}
+
+extern "C" int addhip_actor_sample(const float* mean, int32_t ld_mean, const float* noise, float stdv, float logp_const, const float* a_mean,
+                                   const float* a_std, int32_t num_envs, int32_t deterministic, float* action, float* a_logp, float* rand_mask,
+                                   void* stream) {
+  ADDHIP_REQUIRE(mean && a_mean && a_std && action && a_logp && rand_mask && num_envs > 0, "actor_sample: bad arguments");
+  ADDHIP_REQUIRE(deterministic || noise, "actor_sample: noise missing");
+  hipLaunchKernelGGL(actor_sample_kernel, dim3(row_grid(num_envs)), dim3(256), 0, ST, mean, ld_mean, noise, stdv, logp_const, a_mean, a_std,
+                     num_envs, deterministic, action, a_logp, rand_mask);
+  return addhip::check_launch("actor_sample_kernel");
+}
+
+extern "C" int addhip_disc_prep(const float* disc_obs, const float* disc_demo, int32_t stride, int32_t dim, int64_t rows, const float* mean_abs,
+                                 float min_diff, float* norm_diff, const int32_t* motion_id, const float* motion_time, const addhip_sampler_t* s,
+                                 int32_t num_clips, float* abs_sum, void* stream) {
+  ADDHIP_REQUIRE(disc_obs && disc_demo && mean_abs && rows > 0 && dim <= stride && stride <= 128, "disc_prep: bad arguments");
+  addhip_sampler_t ss;
+  memset(&ss, 0, sizeof(ss));
+  int cells = 0;
+  if (motion_id) {
+    ADDHIP_REQUIRE(s && motion_time && s->err_sum && s->err_cnt && s->seg_size && num_clips > 0, "disc_prep: sampler state missing");
+    ss = *s;
+    cells = num_clips * s->num_segments;
+    ADDHIP_REQUIRE(cells <= 8192, "disc_prep: more than 8192 (clip,segment) cells");
+  }
+  size_t shmem = sizeof(float) * (2 * (size_t)cells + 4 * (size_t)stride);
+  hipLaunchKernelGGL(disc_prep_kernel, dim3(row_grid(rows) < 1024 ? row_grid(rows) : 1024), dim3(256), shmem, ST, disc_obs, disc_demo, stride, dim,
+                     (long long)rows, mean_abs, min_diff, norm_diff, motion_id, motion_time, ss, cells, abs_sum);
+  return addhip::check_launch("disc_prep_kernel");
+}
+
+extern "C" int addhip_sampler_update(const addhip_sampler_t* s, int32_t num_clips, void* stream) {
+  ADDHIP_REQUIRE(s && s->errors && s->err_sum && s->err_cnt && num_clips > 0, "sampler_update: bad arguments");
+  int cells = num_clips * s->num_segments;
+  hipLaunchKernelGGL(sampler_update_kernel, dim3((cells + 255) / 256), dim3(256), 0, ST, *s, cells);
+  return addhip::check_launch("sampler_update_kernel");
+}
+
+extern "C" int addhip_disc_reward(const float* logits, float* reward_inout, int64_t count, float scale, float task_w, float disc_w, float* stats,
+                                  void* stream) {
+  ADDHIP_REQUIRE(logits && reward_inout && count > 0, "disc_reward: bad arguments");
+  hipLaunchKernelGGL(disc_reward_kernel, dim3(elem_grid(count) < 1024 ? elem_grid(count) : 1024), dim3(256), 0, ST, logits, reward_inout,
+                     (long long)count, scale, task_w, disc_w, stats);
+  return addhip::check_launch("disc_reward_kernel");
+}
+
+extern "C" int addhip_head_gemv(const float* H, int32_t ld, int32_t K, int64_t rows, const float* w, const float* b, float* out, void* stream) {
+  ADDHIP_REQUIRE(H && w && b && out && rows > 0 && K % 4 == 0 && ld % 4 == 0, "head_gemv: bad arguments");
+  hipLaunchKernelGGL(head_gemv_kernel, dim3(row_grid(rows)), dim3(256), 0, ST, H, ld, K, (long long)rows, w, b, out);
+  return addhip::check_launch("head_gemv_kernel");
+}
+
+extern "C" int addhip_td_lambda_adv(const float* reward, float* next_vals, const float* vals, const int32_t* done, const float* rand_mask, int32_t T,
+                                    int32_t N, float discount, float td_lambda, float succ_val, float fail_val, float adv_clip, float* tar_val,
+                                    float* adv, float* scratch, float* stats_out, void* stream) {
+  ADDHIP_REQUIRE(reward && next_vals && vals && done && rand_mask && tar_val && adv && scratch && stats_out && T > 0 && N > 0,
+                 "td_lambda_adv: bad arguments");
+  ADDHIP_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7u) == 0, "td_lambda_adv: scratch must be 8-byte aligned");
+  int blocks = (N + 255) / 256;
+  ADDHIP_REQUIRE(blocks <= 1024, "td_lambda_adv: at most 262144 envs per rank");
+  double* partial = reinterpret_cast<double*>(scratch);
+  hipLaunchKernelGGL(td_lambda_kernel, dim3(blocks), dim3(256), 0, ST, reward, next_vals, vals, done, rand_mask, T, N, discount, td_lambda, succ_val,
+                     fail_val, tar_val, adv, partial);
+  if (int rc = addhip::check_launch("td_lambda_kernel")) return rc;
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(64), 0, ST, partial, blocks, stats_out);
+  if (int rc = addhip::check_launch("adv_stats_kernel")) return rc;
+  hipLaunchKernelGGL(adv_norm_kernel, dim3(elem_grid((long long)T * N)), dim3(256), 0, ST, adv, (long long)T * N, stats_out, adv_clip);
+  return addhip::check_launch("adv_norm_kernel");
+}
+
+extern "C" int addhip_norm_accum(const float* X, int64_t rows, int32_t dim, int32_t ld, float* sum, float* sumsq, void* stream) {
+  ADDHIP_REQUIRE(X && sum && rows > 0 && dim > 0 && ld >= dim, "norm_accum: bad arguments");
+  int strips = (dim + 63) / 64;
+  int ysplit = 1;
+  while (strips * ysplit < 512 && rows / (ysplit * 2) >= 64) ysplit *= 2;
+  long long rpb = (rows + ysplit - 1) / ysplit;
+  hipLaunchKernelGGL(norm_accum_kernel, dim3(strips, ysplit), dim3(256), 0, ST, X, (long long)rows, dim, ld, sum, sumsq, rpb);
+  return addhip::check_launch("norm_accum_kernel");
+}
+
+extern "C" int addhip_norm_merge(float* mean, float* stdv, float* mean_sq, int64_t* count, float* sum, float* sumsq, int64_t new_count, int32_t dim,
+                                 float min_var, int32_t first, void* stream) {
+  ADDHIP_REQUIRE(mean && stdv && mean_sq && count && sum && sumsq && dim > 0 && dim <= 1024, "norm_merge: bad arguments (dim <= 1024)");
+  hipLaunchKernelGGL(norm_merge_kernel, dim3(1), dim3(1024), 0, ST, mean, stdv, mean_sq, (long long*)count, sum, sumsq, (long long)new_count, dim,
+                     min_var, first);
+  return addhip::check_launch("norm_merge_kernel");
+}
+
+extern "C" int addhip_diffnorm_merge(float* mean_abs, int64_t* count, float* abs_sum, int64_t new_count, int32_t dim, void* stream) {
+  ADDHIP_REQUIRE(mean_abs && count && abs_sum && new_count > 0 && dim > 0 && dim <= 1024, "diffnorm_merge: bad arguments");
+  hipLaunchKernelGGL(diffnorm_merge_kernel, dim3(1), dim3(1024), 0, ST, mean_abs, (long long*)count, abs_sum, (long long)new_count, dim);
+  return addhip::check_launch("diffnorm_merge_kernel");
+}
+
+extern "C" int addhip_gather_minibatch(const addhip_gather_t* g, void* stream) {
+  ADDHIP_REQUIRE(g && g->idx && g->count > 0, "gather: bad arguments");
+  ADDHIP_REQUIRE(g->obs && g->obs_mean && g->obs_std && g->action && g->a_mean && g->a_std && g->a_logp && g->adv && g->tar_val && g->rand_mask &&
+                     g->disc_obs && g->disc_demo && g->mean_abs, "gather: source pointers missing");
+  ADDHIP_REQUIRE(g->norm_obs && g->norm_action && g->o_logp && g->o_adv && g->o_tar_val && g->o_mask && g->norm_diff, "gather: output pointers missing");
+  hipLaunchKernelGGL(gather_kernel, dim3(row_grid(g->count)), dim3(256), 0, ST, *g);
+  return addhip::check_launch("gather_kernel");
+}
+
+extern "C" int addhip_count_mask(const float* rand_mask, int32_t M, float* out, void* stream) {
+  ADDHIP_REQUIRE(rand_mask && out && M > 0, "count_mask: bad arguments");
+  ADDHIP_HIP(hipMemsetAsync(out, 0, sizeof(float), ST));
+  hipLaunchKernelGGL(count_mask_kernel, dim3(elem_grid(M) < 64 ? elem_grid(M) : 64), dim3(256), 0, ST, rand_mask, M, out);
+  return addhip::check_launch("count_mask_kernel");
+}
+
+extern "C" int addhip_actor_loss(const float* mean, const float* norm_action, const float* old_logp, const float* adv, const float* rand_mask, int32_t M,
+                                 float stdv, float logp_const, float clip_ratio, float bound_weight, float loss_scale, const float* n_valid,
+                                 float* d_mean, float* stats, void* stream) {
+  ADDHIP_REQUIRE(mean && norm_action && old_logp && adv && rand_mask && n_valid && d_mean && stats && M > 0, "actor_loss: bad arguments");
+  hipLaunchKernelGGL(actor_loss_kernel, dim3(row_grid(M) < 1024 ? row_grid(M) : 1024), dim3(256), 0, ST, mean, norm_action, old_logp, adv, rand_mask, M,
+                     stdv, logp_const, clip_ratio, bound_weight, loss_scale, n_valid, d_mean, stats);
+  return addhip::check_launch("actor_loss_kernel");
+}
+
+extern "C" int addhip_critic_head(const float* H, int32_t ld, int32_t K, int32_t M, const float* w, const float* b, const float* tar, float loss_scale,
+                                  float* dZ, float* dv_out, float* stats, void* stream) {
+  ADDHIP_REQUIRE(H && w && b && tar && dZ && dv_out && stats && M > 0 && K % 4 == 0 && ld % 4 == 0, "critic_head: bad arguments");
+  hipLaunchKernelGGL(critic_head_kernel, dim3(row_grid(M) < 1024 ? row_grid(M) : 1024), dim3(256), 0, ST, H, ld, K, M, w, b, tar, loss_scale, dZ,
+                     dv_out, stats);
+  return addhip::check_launch("critic_head_kernel");
+}
+
+extern "C" int addhip_disc_head(const float* H, int32_t ld, int32_t K, int32_t M, const float* h_pos, const float* w, const float* b, float loss_scale,
+                                float* dlogit, float* dlogit_pos, float* stats, void* stream) {
+  ADDHIP_REQUIRE(H && h_pos && w && b && dlogit && dlogit_pos && stats && M > 0 && K % 4 == 0 && ld % 4 == 0, "disc_head: bad arguments");
+  hipLaunchKernelGGL(disc_head_kernel, dim3(row_grid(M + 1) < 1024 ? row_grid(M + 1) : 1024), dim3(256), 0, ST, H, ld, K, M, h_pos, w, b, loss_scale,
+                     dlogit, dlogit_pos, stats);
+  return addhip::check_launch("disc_head_kernel");
+}
+
+extern "C" int addhip_outer_mask(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, void* stream) {
+  ADDHIP_REQUIRE(v && w && H && out && rows > 0 && K % 4 == 0 && ld % 4 == 0, "outer_mask: bad arguments");
+  hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, out);
+  return addhip::check_launch("outer_mask_kernel");
+}
+extern "C" int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, void* stream) {
+  ADDHIP_REQUIRE(w && H && out && rows > 0 && K % 4 == 0 && ld % 4 == 0, "bcast_mask: bad arguments");
+  hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, (const float*)nullptr, w, H, ld, K, (long long)rows, out);
+  return addhip::check_launch("outer_mask_kernel(bcast)");
+}
+
+extern "C" int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, float* stats, void* stream) {
+  ADDHIP_REQUIRE(g && G && stats && M > 0 && dim <= ld, "grad_penalty: bad arguments");
+  hipLaunchKernelGGL(grad_penalty_kernel, dim3(row_grid(M) < 1024 ? row_grid(M) : 1024), dim3(256), 0, ST, g, ld, dim, M, coef, G, stats);
+  return addhip::check_launch("grad_penalty_kernel");
+}
+
+extern "C" int addhip_weighted_col_sum(const float* v, const float* X, int32_t ld, int32_t K, int64_t rows, float* out, float scale, int32_t accumulate,
+                                       void* stream) {
+  ADDHIP_REQUIRE(v && X && out && rows > 0 && K > 0 && ld >= K, "weighted_col_sum: bad arguments");
+  if (!accumulate) ADDHIP_HIP(hipMemsetAsync(out, 0, sizeof(float) * K, ST));
+  int strips = (K + 63) / 64;
+  int ysplit = 1;
+  while (strips * ysplit < 512 && rows / (ysplit * 2) >= 64) ysplit *= 2;
+  long long rpb = (rows + ysplit - 1) / ysplit;
+  hipLaunchKernelGGL(weighted_col_sum_kernel, dim3(strips, ysplit), dim3(256), 0, ST, v, X, ld, K, (long long)rows, out, scale, rpb);
+  return addhip::check_launch("weighted_col_sum_kernel");
+}
+
+extern "C" int addhip_l2_grad(const float* w, float* grad, int64_t count, float coef, float* sumsq_out, void* stream) {
+  ADDHIP_REQUIRE(w && grad && count > 0, "l2_grad: bad arguments");
+  hipLaunchKernelGGL(l2_grad_kernel, dim3(elem_grid(count) < 512 ? elem_grid(count) : 512), dim3(256), 0, ST, w, grad, (long long)count, coef, sumsq_out);
+  return addhip::check_launch("l2_grad_kernel");
+}
+
+extern "C" int addhip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int32_t step, void* stream) {
+  ADDHIP_REQUIRE(param && grad && exp_avg && exp_avg_sq && count > 0 && step >= 1, "adamw: bad arguments");
+  // bias corrections in double like torch's python-scalar path (torch/optim/adamw.py single-tensor)
+  double bc1 = 1.0 - pow((double)beta1, (double)step);
+  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  float step_size = (float)((double)lr / bc1);
+  float bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adamw_kernel, dim3(elem_grid(count)), dim3(256), 0, ST, param, grad, exp_avg, exp_avg_sq, (long long)count, lr, beta1, beta2, eps,
+                     weight_decay, step_size, bc2_sqrt);
+  return addhip::check_launch("adamw_kernel");
+}
+
+extern "C" int addhip_return_tracker_fold(const float* ep_stats, int32_t T, float* state, void* stream) {
+  ADDHIP_REQUIRE(ep_stats && state && T > 0, "return_tracker_fold: bad arguments");
+  hipLaunchKernelGGL(return_tracker_fold_kernel, dim3(1), dim3(64), 0, ST, ep_stats, T, state);
+  return addhip::check_launch("return_tracker_fold_kernel");
+}

@@ -1,0 +1,71 @@
+"""Struct builders for the C ABI: turn add-gym's config keys into the parameter blocks of
+include/addhip.h.  Pure host logic (no GPU needed)."""
+import numpy as np
+
+from . import _lib as L
+
+F = np.float32
+
+
+def obs_dims(task):
+    """(obs_dim, disc_dim) for the flags the HIP path implements (add_observation.py:231-274, 520-554)."""
+    hc = 1 if task.get("root_height_obs", False) else 0
+    k = len(task.get("tar_obs_steps", [1])) if task.get("enable_tar_obs", False) else 0
+    obs_dim = hc + 6 + L.NUM_DOF + k * ((3 if hc else 2) + 6 + L.NUM_DOF)
+    return obs_dim, L.HIST * L.DISC_STEP_W
+
+
+def pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def check_supported(task):
+    """The HIP path covers the observation flags of configs/task/pose.yaml plus the global/height toggles.
+    Anything else fails loudly instead of silently computing something different."""
+    if task.get("enable_vel_obs", False):
+        raise NotImplementedError("task.enable_vel_obs=True is not implemented in the HIP hot path yet")
+    if task.get("enable_phase_obs", True):
+        raise NotImplementedError("task.enable_phase_obs=True is not implemented in the HIP hot path yet (pose.yaml sets it False)")
+    if task.get("num_disc_obs_steps", L.HIST) != L.HIST:
+        raise NotImplementedError("task.num_disc_obs_steps must be 3")
+    if task.get("visualize_ref_char", False):
+        raise NotImplementedError("task.visualize_ref_char needs a viewer (out of scope)")
+    if len(task.get("tar_obs_steps", [1])) > L.MAX_TAR:
+        raise NotImplementedError(f"at most {L.MAX_TAR} target steps")
+    jw = task.get("joint_err_w", None)
+    if jw is not None and any(float(w) != 1.0 for w in jw):
+        raise NotImplementedError("task.joint_err_w other than all-ones is not implemented")
+
+
+def make_task(task, dt, max_episode_length=None):
+    check_supported(task)
+    t = L.TaskT()
+    t.dt = dt
+    t.global_obs = int(bool(task.get("global_obs", False)))
+    t.root_height_obs = int(bool(task.get("root_height_obs", False)))
+    steps = list(task.get("tar_obs_steps", [1])) if task.get("enable_tar_obs", False) else []
+    t.num_tar_steps = len(steps)
+    # fp32 products exactly as the reference forms them (add_observation.py:215, 366-369)
+    tar = (F(dt) * np.asarray(steps, F)).astype(F)
+    for i, v in enumerate(tar):
+        t.tar_dt[i] = float(v)
+    demo = (F(-dt) * np.arange(L.HIST, dtype=F))[::-1].astype(F)
+    for i, v in enumerate(demo):
+        t.demo_dt[i] = float(v)
+    t.max_episode_length = float(task.get("max_episode_length", max_episode_length if max_episode_length is not None else 0.0))
+    t.enable_early_termination = int(bool(task["enable_early_termination"]))
+    t.pose_termination = int(bool(task.get("pose_termination", False)))
+    t.pose_termination_dist = float(task.get("pose_termination_dist", 1.0))
+    t.pose_w, t.vel_w = float(task["reward_pose_w"]), float(task["reward_vel_w"])
+    t.root_pose_w, t.root_vel_w = float(task["reward_root_pose_w"]), float(task["reward_root_vel_w"])
+    t.pose_scale, t.vel_scale = float(task["reward_pose_scale"]), float(task["reward_vel_scale"])
+    t.root_pose_scale, t.root_vel_scale = float(task["reward_root_pose_scale"]), float(task["reward_root_vel_scale"])
+    t.obs_dim, t.disc_dim = obs_dims(task)
+    t.obs_stride, t.disc_stride = pad4(t.obs_dim), pad4(t.disc_dim)
+    return t
+
+
+def gemm(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, epilogue=L.EPI_NONE, bias=None, mask=None, ldmask=0, a_mean=None, a_std=None,
+         split_k=1, alpha=1.0):
+    """Descriptor for addhip_gemm_f32: C[M,N] = alpha * sum_k A(m,k) B(n,k).  Pointers are raw addresses."""
+    return L.GemmT(M, N, K, A, lda, int(a_kc), B, ldb, int(b_kc), C, ldc, epilogue, bias, mask, ldmask, a_mean, a_std, split_k, alpha)

@@ -1,0 +1,269 @@
+/* addhip.h -- C ABI of the MI355X-native add-gym rollout+PPO hot path (libaddhip.so).
+ *
+ * The reference (rsamf/add-gym) has no FFI: its hot path is Python/TorchScript
+ * (SURVEY.md section 8b).  This header is the boundary a maintainer binds instead of those
+ * Python functions; every entry point names the reference function(s) it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (addhip_last_error() has the text);
+ *   - all buffers are caller-owned DEVICE pointers (e.g. PyTorch-ROCm allocations), fp32 unless
+ *     stated, row-major, rows 16-byte aligned; nothing is allocated or freed by the library;
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (void* so that the
+ *     header needs no HIP include); no call synchronises or reads device memory on the host,
+ *     so all of them can be captured into a hipGraph;
+ *   - no global state: pass the same structs each call.
+ *
+ * Layouts (D = 29 dofs)
+ *   pose row  [36] = root_pos xyz | root_rot wxyz | dof_pos[29]
+ *   vel  row  [36] = root_vel xyz | root_ang_vel xyz | dof_vel[29] | 0
+ *   obs row   [obs_stride >= obs_dim], disc row [disc_stride >= disc_dim]; pad columns are 0.
+ */
+#ifndef ADDHIP_H
+#define ADDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADDHIP_POSE_W 36
+#define ADDHIP_NUM_DOF 29
+#define ADDHIP_MAX_TAR_STEPS 8
+#define ADDHIP_HIST 3
+
+enum { ADDHIP_DONE_NULL = 0, ADDHIP_DONE_FAIL = 1, ADDHIP_DONE_SUCC = 2, ADDHIP_DONE_TIME = 3 };
+
+const char* addhip_last_error(void);
+int addhip_version(void);
+
+/* ---- reference-motion step tables: MotionLib._step_* (anim/motion_lib.py:285-320) ---- */
+typedef struct {
+  const float* pose;        /* [total_steps,36] */
+  const float* vel;         /* [total_steps,36] */
+  const int32_t* clip_start; /* [num_clips] row offset added to the frame index.  reference_compat:
+                                the RAW-frame start (motion_lib.py:280-282 quirk), else the step start */
+  const int32_t* clip_steps; /* [num_clips] rows of each clip (corrected mode clamp) */
+  const float* clip_len;    /* [num_clips] seconds (motion_lib.py:202) */
+  const int32_t* clip_loop; /* [num_clips] 0 CLAMP / 1 WRAP (anim/motion.py:6-8) */
+  int32_t num_clips;
+  int32_t total_steps;
+  int32_t reference_compat; /* 1: clamp frame to [0,total_steps-1] then add clip_start (motion_lib.py:322-326) */
+  float dt_inv;             /* round(1/dt) (motion_lib.py:23) */
+} addhip_motion_t;
+
+/* ---- task flags: configs/task/pose.yaml as read by add_observation.py:19-33, add_done.py:21-25,
+ *      add_reward.py:12-24 ---- */
+typedef struct {
+  float dt;                       /* engine.ctrl_dt */
+  int32_t global_obs, root_height_obs;
+  int32_t num_tar_steps;          /* len(tar_obs_steps) */
+  float tar_dt[ADDHIP_MAX_TAR_STEPS]; /* fl32(dt * step_k)   (add_observation.py:215) */
+  float demo_dt[ADDHIP_HIST];     /* fl32(-dt*j) flipped     (add_observation.py:366-369) */
+  float max_episode_length;
+  int32_t enable_early_termination, pose_termination;
+  float pose_termination_dist;
+  float pose_w, vel_w, root_pose_w, root_vel_w;
+  float pose_scale, vel_scale, root_pose_scale, root_vel_scale;
+  int32_t obs_dim, obs_stride, disc_dim, disc_stride;
+} addhip_task_t;
+
+/* ---- per-env state between the engine boundary and the agent ---- */
+typedef struct {
+  int32_t num_envs;
+  float* sim_pose;      /* [N,36] simulator state (engine getters, base_engine.py:103-215) */
+  float* sim_vel;       /* [N,36] */
+  float* time;          /* [N] Environment.time_buf (envs/env.py:124,155) */
+  float* time_off;      /* [N] ADDObservation._motion_time_offsets */
+  int32_t* motion_id;   /* [N] ADDObservation._motion_ids */
+  float* hist;          /* [N,3,36] pose history ring (util/circular_buffer.py), one shared head */
+  int32_t* done;        /* [N] ADDDone.done_buf */
+  const uint8_t* contact; /* [N] non-foot ground contact flag (robot.py:221-231) or NULL */
+  float* ref_pose;      /* [N,36] ADDObservation.ref_* */
+  float* ref_vel;       /* [N,36] */
+  /* return tracker (base_agent.py:564-621) */
+  float* ret_acc;       /* [N] */
+  int32_t* len_acc;     /* [N] */
+} addhip_env_t;
+
+/* outputs of one env step; any pointer may be NULL to skip that output */
+typedef struct {
+  float* obs;         /* [N,obs_stride]  next_obs slot of the experience buffer */
+  float* obs_next_in; /* [N,obs_stride]  obs slot t+1 (same values; overwritten for reset envs) or NULL */
+  float* disc_obs;    /* [N,disc_stride] */
+  float* disc_demo;   /* [N,disc_stride] */
+  float* reward;      /* [N] */
+  int32_t* done;      /* [N] experience-buffer slot (copy of env.done) */
+  int32_t* motion_id_rec;   /* [N] */
+  float* motion_time_rec;   /* [N] */
+  float* ep_stats;    /* [3] += (sum of finished returns, sum of finished lengths, #finished) or NULL */
+} addhip_step_out_t;
+
+/* ADDAgent._step_env after scene.step() (add_agent.py:204-219): time += dt (env.py:155);
+ * _update_ref_motion + _update_disc_hist (add_observation.py:163-207); compute_add_obs /
+ * compute_disc_obs x2 (add_observation.py:231-306, 356-419, 422-717); compute_reward
+ * (add_reward.py:103-177); compute_done (add_done.py:96-147); ReturnTracker.update
+ * (base_agent.py:596-621).  `head` = ring slot that receives the new state. */
+int addhip_env_step(const addhip_motion_t* m, const addhip_task_t* t, const addhip_env_t* e,
+                    const addhip_step_out_t* o, int32_t head, void* stream);
+
+/* adaptive start-time sampler state: AdaptiveSegmentSampler (learning/sampler.py) */
+typedef struct {
+  float* errors;          /* [num_clips,num_segments] */
+  const float* seg_size;  /* [num_clips] clip_len/num_segments (sampler.py:13-15) */
+  const float* clip_cdf;  /* [num_clips] inclusive CDF of the clip weights (motion_lib.py:35-39) */
+  int32_t num_segments;
+  float temperature;      /* <=0: max(err over the clips drawn in this batch)+1e-6 (sampler.py:66-69) */
+  float min_start_time;   /* (num_disc_obs_steps-1)*dt (add_motion.py:31) */
+  int32_t rand_reset;
+  /* scratch (device): */
+  uint32_t* temp_bits;    /* [1] running max of the drawn clips' errors (as float bits) */
+  float* err_sum;         /* [num_clips*num_segments] */
+  float* err_cnt;         /* [num_clips*num_segments] */
+} addhip_sampler_t;
+
+/* ADDAgent._reset_envs (add_agent.py:221-233) for every env whose done flag != NULL (or all envs
+ * when reset_all): ADDMotion.sample_time (add_motion.py:53-61, sampler.py:57-92), time=0, done=NULL,
+ * ref state -> simulator (add_observation.py:308-332), history refill (:334-344), observations
+ * recomputed for the reset envs.  u_clip/u_seg/u_jit: [N] uniforms in [0,1) (one draw per env;
+ * consumed only where a reset happens).  `head` = slot of the OLDEST ring entry after the push.
+ * Two launches (clip draw + batch temperature, then the rest). */
+int addhip_env_reset(const addhip_motion_t* m, const addhip_task_t* t, const addhip_env_t* e,
+                     const addhip_sampler_t* s, const float* u_clip, const float* u_seg,
+                     const float* u_jit, float* obs_out, float* disc_obs_out, float* disc_demo_out,
+                     int32_t reset_all, int32_t head, void* stream);
+
+/* lookup only: MotionLib.get_precomputed_motion_step (motion_lib.py:322-335) for M (id,time) pairs */
+int addhip_motion_lookup(const addhip_motion_t* m, const int32_t* ids, const float* times, int32_t count,
+                         int32_t* idx_out, float* pose_out, float* vel_out, void* stream);
+
+/* KinematicEngine.step (build-defined stand-in simulator behind base_engine.BaseEntity;
+ * control_dofs_position + scene.step): dof += lag*(target-dof), dof_vel = delta/dt */
+int addhip_kin_engine_step(float* sim_pose, float* sim_vel, const float* target, int32_t target_stride,
+                           int32_t num_envs, float lag, float dt, void* stream);
+
+/* ---- dense layers: torch.nn.Linear(+ReLU) stacks of PPOModel/ADDModel (ppo_model.py:13-21,
+ *      add_model.py:12-15, nets/fc_*layers_1024units.py) on fp32 MFMA ---- */
+enum { ADDHIP_EPI_NONE = 0, ADDHIP_EPI_BIAS = 1, ADDHIP_EPI_BIAS_RELU = 2, ADDHIP_EPI_MASK = 3 };
+typedef struct {
+  int32_t M, N, K;          /* C[M,N] = sum_k A(m,k) * B(n,k) */
+  const float* A; int32_t lda; int32_t a_kcontig; /* 1: A[m*lda+k], 0: A[k*lda+m] */
+  const float* B; int32_t ldb; int32_t b_kcontig; /* 1: B[n*ldb+k], 0: B[k*ldb+n] */
+  float* C; int32_t ldc;
+  int32_t epilogue;         /* ADDHIP_EPI_* */
+  const float* bias;        /* [N] for BIAS / BIAS_RELU */
+  const float* mask; int32_t ldmask; /* MASK: C = acc * (mask[m,n] > 0) */
+  const float* a_mean; const float* a_std; /* optional fused (a-mean)/std on A when a_kcontig (Normalizer.normalize, normalizer.py:107-110) */
+  int32_t split_k;          /* >1: C is [split_k, M, ldc] partial slabs (slab stride M*ldc) */
+  float alpha;              /* scale applied to acc before the epilogue */
+} addhip_gemm_t;
+int addhip_gemm_f32(const addhip_gemm_t* g, void* stream);
+
+/* out[n] (+)= scale * sum over `slabs` of in[s*slab_stride + n]  (split-K combine, grads) */
+int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count,
+                       float scale, int32_t accumulate, void* stream);
+/* out[n] (+)= scale * sum_m X[m*ld+n]   (bias gradients) */
+int addhip_col_sum(const float* X, int32_t M, int32_t N, int32_t ld, float* out, float scale,
+                   int32_t accumulate, void* stream);
+
+/* ---- rollout actor head: DistributionGaussianDiag.sample/log_prob (distribution_gaussian_diag.py:84-94)
+ *      + Normalizer.unnormalize (normalizer.py:112-114) + exp-buffer record (ppo_agent.py:72-109) ---- */
+int addhip_actor_sample(const float* mean, int32_t ld_mean, const float* noise /*[N,29] N(0,1)*/, float std,
+                        float logp_const /* fl32(-0.5*29*log(2pi)) - sum(logstd) */, const float* a_mean, const float* a_std, int32_t num_envs,
+                        int32_t deterministic, float* action /*[N,32]*/, float* a_logp, float* rand_mask,
+                        void* stream);
+
+/* counter-based Philox4x32-10 fills (stateless: element i of call (seed,stream_id) is fixed) */
+int addhip_fill_normal(float* out, int64_t count, uint64_t seed, uint64_t stream_id, void* stream_);
+int addhip_fill_uniform(float* out, int64_t count, uint64_t seed, uint64_t stream_id, void* stream_);
+
+/* ---- build-train-data (add_agent.py:110-139, amp_agent.py:194-206, sampler.py:20-55) ---- */
+/* norm_diff = (demo-agent)/max(mean_abs,1e-4); err = sum((agent-demo)^2) scatter-added per (clip,segment);
+ * also sum|demo-agent| per column into abs_sum (DiffNormalizer.record, diff_normalizer.py:24-31) */
+int addhip_disc_prep(const float* disc_obs, const float* disc_demo, int32_t stride, int32_t dim, int64_t rows,
+                     const float* mean_abs, float min_diff, float* norm_diff,
+                     const int32_t* motion_id, const float* motion_time, const addhip_sampler_t* s,
+                     int32_t num_clips, float* abs_sum, void* stream);
+/* errors = where(cnt>0, 0.9*errors + 0.1*sum/cnt, errors); clears sum/cnt (sampler.py:43-55) */
+int addhip_sampler_update(const addhip_sampler_t* s, int32_t num_clips, void* stream);
+/* r = task_w*task_r + disc_w * (-log(max(1-sigmoid(logit),1e-4))*scale); stats[0..1] += (sum, sumsq) of disc_r */
+int addhip_disc_reward(const float* logits, float* reward_inout, int64_t count, float scale, float task_w,
+                       float disc_w, float* stats, void* stream);
+
+/* row-wise GEMV head: out[m] = dot(H[m,:K], w) + b   (critic_out / disc_logits, ppo_model.py:18-21) */
+int addhip_head_gemv(const float* H, int32_t ld, int32_t K, int64_t rows, const float* w, const float* b,
+                     float* out, void* stream);
+
+/* PPOAgent._build_train_data (ppo_agent.py:111-159) + compute_td_lambda_return (base_agent.py:624-647):
+ * next_vals[done in {SUCC,FAIL}] = succ/fail value; reverse scan; adv = ret - vals; then mean/std (unbiased)
+ * over samples with rand_mask==1, normalise, clamp.  scratch: [>= 4 + 2*1024] floats. stats_out[0..1]=mean,std */
+int addhip_td_lambda_adv(const float* reward, float* next_vals, const float* vals, const int32_t* done,
+                         const float* rand_mask, int32_t T, int32_t N, float discount, float td_lambda,
+                         float succ_val, float fail_val, float adv_clip, float* tar_val, float* adv,
+                         float* scratch, float* stats_out, void* stream);
+
+/* ---- normalisers ---- */
+/* sum[n] += sum_m x[m,n]; sumsq[n] += sum_m x^2   (Normalizer.record, normalizer.py:25-35) */
+int addhip_norm_accum(const float* X, int64_t rows, int32_t dim, int32_t ld, float* sum, float* sumsq, void* stream);
+/* Normalizer.update (normalizer.py:37-80); count is int64 on device; new_count passed by value */
+int addhip_norm_merge(float* mean, float* std, float* mean_sq, int64_t* count, float* sum, float* sumsq,
+                      int64_t new_count, int32_t dim, float min_var, int32_t first, void* stream);
+/* DiffNormalizer.update (diff_normalizer.py:33-45) */
+int addhip_diffnorm_merge(float* mean_abs, int64_t* count, float* abs_sum, int64_t new_count, int32_t dim, void* stream);
+
+/* ---- minibatch assembly: ExperienceBuffer.sample (experience_buffer.py:74-82) fused with the
+ *      normalisations of _compute_loss (ppo_agent.py:194-196, add_agent.py:152-153) ---- */
+typedef struct {
+  const int64_t* idx; int32_t count;     /* rows into the flat [T*N] buffers */
+  const float* obs; int32_t obs_stride; int32_t obs_dim; const float* obs_mean; const float* obs_std;
+  const float* action; const float* a_mean; const float* a_std; /* action [.,32] */
+  const float* a_logp; const float* adv; const float* tar_val; const float* rand_mask;
+  const float* disc_obs; const float* disc_demo; int32_t disc_stride; int32_t disc_dim;
+  const float* mean_abs; float min_diff;
+  float* norm_obs; float* norm_action; float* o_logp; float* o_adv; float* o_tar_val; float* o_mask; float* norm_diff;
+} addhip_gather_t;
+int addhip_gather_minibatch(const addhip_gather_t* g, void* stream);
+
+/* ---- losses (forward value + gradient w.r.t. the head outputs) ---- */
+/* PPOAgent._compute_actor_loss (ppo_agent.py:221-275) + _compute_action_bound_loss (base_agent.py:522-546).
+ * d_mean[M,32] = d loss / d mean;  stats += {sum min-term, sum clip, sum ratio, sum bound, n_valid} */
+int addhip_actor_loss(const float* mean, const float* norm_action, const float* old_logp, const float* adv,
+                      const float* rand_mask, int32_t M, float std, float logp_const, float clip_ratio,
+                      float bound_weight, float loss_scale, const float* n_valid /*device [1]*/, float* d_mean,
+                      float* stats, void* stream);
+/* count of rand_mask == 1 -> out[0] */
+int addhip_count_mask(const float* rand_mask, int32_t M, float* out, void* stream);
+/* PPOAgent._compute_critic_loss (ppo_agent.py:209-219): v = H.w+b; dv = scale*2(v-tar)/M;
+ * dZ[m,:] = dv*w*(H>0) ; stats[0] += sum (tar-v)^2 ; dv_out for the dw/db reductions */
+int addhip_critic_head(const float* H, int32_t ld, int32_t K, int32_t M, const float* w, const float* b,
+                       const float* tar, float loss_scale, float* dZ, float* dv_out, float* stats, void* stream);
+/* ADDAgent._compute_disc_loss head part (add_agent.py:141-202, amp_agent.py:177-192): logits, BCE(0.1) on the
+ * M agent/demo differences and BCE(0.9) on the single zero-difference row `h_pos`; writes dlogit[M], dlogit_pos[1];
+ * stats += {sum bce_neg, bce_pos, sum logit_neg, logit_pos, #neg<0, pos>0} */
+int addhip_disc_head(const float* H, int32_t ld, int32_t K, int32_t M, const float* h_pos, const float* w,
+                     const float* b, float loss_scale, float* dlogit, float* dlogit_pos, float* stats, void* stream);
+/* out[m,k] = v[m] * w[k] * (H[m,k] > 0)    (back through a 1-wide head into the last hidden layer) */
+int addhip_outer_mask(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows,
+                      float* out, void* stream);
+/* out[m,k] = w[k] * (H[m,k] > 0)          (a2 of the gradient-penalty chain) */
+int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, void* stream);
+/* gradient penalty (add_agent.py:166-178): n=sqrt(|g|^2+1e-8); G = coef*2(n-1)/n * g / M; stats[0] += sum (n-1)^2 */
+int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, float* stats, void* stream);
+/* out[k] (+)= scale * sum_m v[m]*(mask? (Hmask[m,k]>0):1)*X[m,k]   (dw of 1-wide heads) */
+int addhip_weighted_col_sum(const float* v, const float* X, int32_t ld, int32_t K, int64_t rows, float* out,
+                            float scale, int32_t accumulate, void* stream);
+/* grad[i] += coef * w[i]  (2*lambda*W terms: disc_logit_reg, disc_weight_decay) ; stats_out += sum w^2 (optional) */
+int addhip_l2_grad(const float* w, float* grad, int64_t count, float coef, float* sumsq_out, void* stream);
+
+/* torch.optim.AdamW step on a flat buffer (mp_optimizer.py:14-40; lr, betas (0.9,0.999), eps 1e-8) */
+int addhip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+/* ReturnTracker running means over the T steps of an iteration (base_agent.py:596-621):
+ * ep_stats [T,3] -> state {episodes, mean_return, mean_ep_len} updated step by step */
+int addhip_return_tracker_fold(const float* ep_stats, int32_t T, float* state, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,30 @@
+"""CPU-only: the C-ABI library exists in-tree, loads, and exports every entry point that
+include/addhip.h declares (no compute calls: there is no GPU here)."""
+import os
+import re
+
+from tests.util import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    import add_gym_amd._lib as L
+
+    header = open(os.path.join(ROOT, "include", "addhip.h")).read()
+    declared = set(re.findall(r"\b(addhip_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = L.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/addhip.h but not exported by libaddhip.so"
+    bound = set(L.SIGNATURES) | {"addhip_last_error", "addhip_version"}
+    assert declared == bound, (declared ^ bound)
+    assert lib.addhip_version() >= 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import add_gym_amd._lib as L
+    import pytest
+
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libaddhip.so")
+    with pytest.raises(L.AddhipError):
+        L.load()

@@ -1,0 +1,257 @@
+"""GPU parity of the per-env HIP hot path (lookup, obs/disc obs, reward, done, reset, engine step)
+through the C ABI, against the golden vectors of the reference and against the CPU oracle."""
+import numpy as np
+import pytest
+
+from tests.util import DEFAULT_TASK, HipMotion, gload, oracle_lib, pack_pose, pack_vel, variant
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+FIELDS = ("root_pos", "root_rot", "root_vel", "root_ang_vel", "dof_pos", "dof_vel")
+# fp32 tolerance of the transcendental chains (atan2/sin/cos/exp on device vs host libm); indices,
+# clocks and done flags are compared bit-exactly
+ATOL = 5e-6
+
+
+def T(x, dtype=None):
+    import torch
+
+    return torch.tensor(np.ascontiguousarray(x), dtype=dtype, device="cuda")
+
+
+def make_env(L, n, pose, vel, time, off, ids, hist, contact=None):
+    import torch
+
+    st = dict(sim_pose=T(pose), sim_vel=T(vel), time=T(time, torch.float32), time_off=T(off, torch.float32), motion_id=T(ids, torch.int32),
+              hist=T(hist), done=torch.zeros(n, dtype=torch.int32, device="cuda"),
+              contact=None if contact is None else T(contact.astype(np.uint8)), ref_pose=torch.zeros(n, 36, device="cuda"),
+              ref_vel=torch.zeros(n, 36, device="cuda"), ret_acc=torch.zeros(n, device="cuda"), len_acc=torch.zeros(n, dtype=torch.int32, device="cuda"))
+    c = L.EnvT(n, *[L.ptr(st[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "done", "contact", "ref_pose", "ref_vel", "ret_acc", "len_acc")])
+    return st, c
+
+
+def make_out(L, n, task):
+    import torch
+
+    o = dict(obs=torch.full((n, task.obs_stride), 7.0, device="cuda"), obs2=torch.full((n, task.obs_stride), 7.0, device="cuda"),
+             disc=torch.full((n, task.disc_stride), 7.0, device="cuda"), demo=torch.full((n, task.disc_stride), 7.0, device="cuda"),
+             reward=torch.zeros(n, device="cuda"), done=torch.zeros(n, dtype=torch.int32, device="cuda"),
+             mid=torch.zeros(n, dtype=torch.int32, device="cuda"), mtime=torch.zeros(n, device="cuda"), ep=torch.zeros(3, device="cuda"))
+    c = L.StepOutT(*[L.ptr(o[k]) for k in ("obs", "obs2", "disc", "demo", "reward", "done", "mid", "mtime", "ep")])
+    return o, c
+
+
+def fixture_hist(v, prefix=""):
+    return np.concatenate([v[prefix + "hist_root_pos"], v[prefix + "hist_root_rot"], v[prefix + "hist_dof_pos"]], axis=-1).astype(F)
+
+
+VARIANTS = {"default": {}, "local": dict(global_obs=False), "noheight": dict(root_height_obs=False),
+            "local_noheight": dict(global_obs=False, root_height_obs=False)}
+
+
+@pytest.mark.parametrize("vname", list(VARIANTS))
+def test_env_step_matches_reference(vname):
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import make_task
+
+    v = variant(gload("obs_reward_done"), vname)
+    task = make_task({**DEFAULT_TASK, **VARIANTS[vname]}, 0.01)
+    mot = HipMotion()
+    n = v["time"].shape[0]
+    pose = pack_pose(v["root_pos"], v["root_rot"], v["dof_pos"])
+    vel = pack_vel(v["root_vel"], v["root_ang_vel"], v["dof_vel"])
+    head = int(v["hist_head"])
+    st, env = make_env(L, n, pose, vel, v["time"], v["time_off"], v["motion_ids"], fixture_hist(v), v["contact"])
+    o, out = make_out(L, n, task)
+    L.call("addhip_env_step", mot.c, task, env, out, head, L.current_stream())
+    torch.cuda.synchronize()
+    obs = o["obs"].cpu().numpy()
+    assert obs.shape[1] == task.obs_stride and np.all(obs[:, task.obs_dim:] == 0)
+    np.testing.assert_allclose(obs[:, :task.obs_dim], v["obs"], rtol=0, atol=ATOL)
+    assert np.array_equal(o["obs2"].cpu().numpy(), obs)
+    np.testing.assert_allclose(o["disc"].cpu().numpy()[:, :114], v["disc_obs"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(o["demo"].cpu().numpy()[:, :114], v["disc_obs_demo"], rtol=0, atol=ATOL)
+    assert np.all(o["disc"].cpu().numpy()[:, 114:] == 0)
+    np.testing.assert_allclose(o["reward"].cpu().numpy(), v["reward"], rtol=0, atol=ATOL)
+    # bit-exact: flags, clock, reference rows (pure gathers), recorded motion times
+    assert np.array_equal(o["done"].cpu().numpy(), v["done"])
+    assert np.array_equal(st["done"].cpu().numpy(), v["done"])
+    assert np.array_equal(st["time"].cpu().numpy(), v["time_post"])
+    assert np.array_equal(st["ref_pose"].cpu().numpy(), pack_pose(v["ref_root_pos"], v["ref_root_rot"], v["ref_dof_pos"]))
+    assert np.array_equal(st["ref_vel"].cpu().numpy()[:, :35], pack_vel(v["ref_root_vel"], v["ref_root_ang_vel"], v["ref_dof_vel"])[:, :35])
+    assert np.array_equal(o["mtime"].cpu().numpy(), (v["time_post"] + v["time_off"]).astype(F))
+    # ring: the new state landed in slot `head`, the other two slots are untouched
+    h = st["hist"].cpu().numpy()
+    assert np.array_equal(h[:, head], pose)
+    for s in range(3):
+        if s != head:
+            assert np.array_equal(h[:, s], fixture_hist(v)[:, s])
+    # return tracker: finished episodes were folded into ep_stats and cleared
+    fin = v["done"] != 0
+    ep = o["ep"].cpu().numpy()
+    assert ep[2] == fin.sum()
+    np.testing.assert_allclose(ep[0], v["reward"][fin].sum(), rtol=1e-5)
+    assert np.all(st["len_acc"].cpu().numpy()[fin] == 0) and np.all(st["len_acc"].cpu().numpy()[~fin] == 1)
+
+
+def _mid_bin_u(cdf, k):
+    lo = 0.0 if k == 0 else float(cdf[k - 1])
+    return F(0.5 * (lo + float(cdf[k])))
+
+
+@pytest.mark.parametrize("tag", ["one", "two"])
+def test_env_reset_matches_reference(tag):
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import make_task
+    from oracle.task import SegmentSampler
+
+    v = variant(gload("reset"), tag)
+    two = tag == "two"
+    task = make_task(DEFAULT_TASK, 0.01)
+    mot = HipMotion(two)
+    n = v["time"].shape[0]
+    pose = pack_pose(v["sim_root_pos"], v["sim_root_rot"], v["sim_dof_pos"])
+    vel = pack_vel(v["sim_root_vel"], v["sim_root_ang_vel"], v["sim_dof_vel"])
+    st, env = make_env(L, n, pose, vel, v["time"], v["time_off"], v["motion_ids"], fixture_hist(v))
+    env_ids = v["env_ids"]
+    done = np.zeros(n, np.int32)
+    done[env_ids] = 1
+    st["done"].copy_(T(done))
+    # the reference's multinomial / rand draws, re-expressed as the uniforms of the inverse-CDF sampler
+    weights = np.asarray([1.0, 3.0] if two else [1.0], F)
+    weights /= weights.sum()
+    clip_cdf = np.cumsum(weights).astype(F)
+    orc = SegmentSampler(mot.lengths, 0.01, 20, None, 0.02)
+    orc.errors = v["sampler_errors"].copy()
+    probs = orc.probs(v["draw_ids"])
+    u_clip, u_seg, u_jit = np.zeros(n, F), np.zeros(n, F), np.zeros(n, F)
+    for j, e in enumerate(env_ids):
+        u_clip[e] = _mid_bin_u(clip_cdf, int(v["draw_ids"][j]))
+        u_seg[e] = _mid_bin_u(np.cumsum(probs[j]), int(v["draw_segments"][j]))
+        u_jit[e] = v["draw_jitter"][j]
+    smp = dict(errors=T(v["sampler_errors"]), seg=T(orc.segment_sizes), cdf=T(clip_cdf), bits=torch.zeros(1, dtype=torch.int32, device="cuda"),
+               es=torch.zeros(orc.errors.size, device="cuda"), ec=torch.zeros(orc.errors.size, device="cuda"))
+    sc = L.SamplerT(L.ptr(smp["errors"]), L.ptr(smp["seg"]), L.ptr(smp["cdf"]), 20, -1.0, 0.02, 1, L.ptr(smp["bits"]), L.ptr(smp["es"]), L.ptr(smp["ec"]))
+    obs = torch.zeros(n, task.obs_stride, device="cuda")
+    disc = torch.zeros(n, task.disc_stride, device="cuda")
+    demo = torch.zeros(n, task.disc_stride, device="cuda")
+    head = int(v["hist_head"])
+    L.call("addhip_env_reset", mot.c, task, env, sc, L.ptr(T(u_clip)), L.ptr(T(u_seg)), L.ptr(T(u_jit)), L.ptr(obs), L.ptr(disc), L.ptr(demo), 0, head,
+           L.current_stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(st["motion_id"].cpu().numpy(), v["post_motion_ids"])
+    assert np.array_equal(st["time"].cpu().numpy(), v["post_time"])
+    assert np.array_equal(st["time_off"].cpu().numpy(), v["post_time_off"])  # quantised start times: bit-exact
+    assert np.all(st["done"].cpu().numpy() == 0)
+    post_pose = pack_pose(v["post_sim_root_pos"], v["post_sim_root_rot"], v["post_sim_dof_pos"])
+    post_vel = pack_vel(v["post_sim_root_vel"], v["post_sim_root_ang_vel"], v["post_sim_dof_vel"])
+    assert np.array_equal(st["sim_pose"].cpu().numpy(), post_pose)  # set_qpos payload == table rows
+    assert np.array_equal(st["sim_vel"].cpu().numpy()[:, :35], post_vel[:, :35])
+    assert np.array_equal(st["hist"].cpu().numpy(), fixture_hist(v, "post_"))
+    np.testing.assert_allclose(obs.cpu().numpy()[env_ids][:, :264], v["obs"][env_ids], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(disc.cpu().numpy()[env_ids][:, :114], v["disc_obs"][env_ids], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(demo.cpu().numpy()[env_ids][:, :114], v["disc_obs_demo"][env_ids], rtol=0, atol=ATOL)
+    untouched = np.setdiff1d(np.arange(n), env_ids)
+    assert np.all(obs.cpu().numpy()[untouched] == 0)
+
+
+def test_lookup_bit_exact():
+    import torch
+    import add_gym_amd._lib as L
+
+    g = gload("lookup")
+    for two, ids, times, ref in ((False, g["ids"], g["times"], g["idx"]), (True, g["two_ids"], g["two_times"], g["two_idx"])):
+        mot = HipMotion(two)
+        n = len(ids)
+        idx = torch.zeros(n, dtype=torch.int32, device="cuda")
+        pose = torch.zeros(n, 36, device="cuda")
+        L.call("addhip_motion_lookup", mot.c, L.ptr(T(ids, torch.int32)), L.ptr(T(times, torch.float32)), n, L.ptr(idx), L.ptr(pose), None, L.current_stream())
+        torch.cuda.synchronize()
+        assert np.array_equal(idx.cpu().numpy(), ref)
+        assert np.array_equal(pose.cpu().numpy(), mot.pose.cpu().numpy()[ref])
+    # the corrected multi-clip mode differs from the reference's quirk and never leaves a clip's rows
+    fixed = HipMotion(True, reference_compat=False)
+    idx = torch.zeros(len(g["two_ids"]), dtype=torch.int32, device="cuda")
+    L.call("addhip_motion_lookup", fixed.c, L.ptr(T(g["two_ids"], torch.int32)), L.ptr(T(g["two_times"], torch.float32)), len(idx), L.ptr(idx), None, None,
+           L.current_stream())
+    orc = oracle_lib(two=True, reference_compat=False)
+    assert np.array_equal(idx.cpu().numpy(), orc.step_index(g["two_ids"], g["two_times"]))
+
+
+def test_kin_engine_step_matches_oracle_sim():
+    import torch
+    import add_gym_amd._lib as L
+    from oracle.loop import KinematicSim
+
+    rng = np.random.RandomState(0)
+    n = 333
+    sim = KinematicSim(n, 29, 0.01)
+    sim.dof_pos[:] = rng.standard_normal((n, 29)).astype(F)
+    pose = T(pack_pose(sim.root_pos, sim.root_rot, sim.dof_pos))
+    vel = T(pack_vel(sim.root_vel, sim.root_ang, sim.dof_vel))
+    for _ in range(3):
+        act = rng.standard_normal((n, 32)).astype(F)
+        L.call("addhip_kin_engine_step", L.ptr(pose), L.ptr(vel), L.ptr(T(act)), 32, n, 0.5, 0.01, L.current_stream())
+        sim.step(act[:, :29])
+    torch.cuda.synchronize()
+    assert np.array_equal(pose.cpu().numpy()[:, 7:], sim.dof_pos)
+    assert np.array_equal(vel.cpu().numpy()[:, 6:35], sim.dof_vel)
+
+
+def test_env_step_full_size_properties():
+    """BASELINE config size (4096 envs): spot-check 256 envs against the oracle, permutation
+    equivariance over the whole batch, flags in range, pads zero."""
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import make_task
+    from oracle import task as OT
+
+    n = 4096
+    rng = np.random.RandomState(3)
+    lib = oracle_lib(golden_tables=True)
+    task = make_task(DEFAULT_TASK, 0.01)
+    mot = HipMotion()
+    ids = np.zeros(n, np.int64)
+    t_ref = rng.rand(n).astype(F) * 6.0
+    rp, rr, rv, ra, dp, dv = lib.get_step(ids, t_ref)
+    q = rr + rng.standard_normal((n, 4)).astype(F) * 0.05
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    sim = (rp + rng.standard_normal((n, 3)).astype(F) * 0.05, q.astype(F), rv + rng.standard_normal((n, 3)).astype(F) * 0.2,
+           ra + rng.standard_normal((n, 3)).astype(F) * 0.2, dp + rng.standard_normal((n, 29)).astype(F) * 0.1,
+           dv + rng.standard_normal((n, 29)).astype(F) * 0.5)
+    sim = tuple(x.astype(F) for x in sim)
+    time = (np.floor(rng.rand(n) * 300) * 0.01).astype(F)
+    off = (t_ref - time).astype(F)
+    hist = rng.standard_normal((n, 3, 36)).astype(F)
+    hist[:, :, 3:7] /= np.linalg.norm(hist[:, :, 3:7], axis=-1, keepdims=True)
+    contact = rng.rand(n) < 0.01
+    pose, vel = pack_pose(sim[0], sim[1], sim[4]), pack_vel(sim[2], sim[3], sim[5])
+
+    def run(perm):
+        st, env = make_env(L, n, pose[perm], vel[perm], time[perm], off[perm], ids[perm], hist[perm], contact[perm])
+        o, out = make_out(L, n, task)
+        L.call("addhip_env_step", mot.c, task, env, out, 1, L.current_stream())
+        torch.cuda.synchronize()
+        return {k: v.cpu().numpy() for k, v in o.items()}
+
+    ident = np.arange(n)
+    a = run(ident)
+    perm = rng.permutation(n)
+    b = run(perm)
+    for k in ("obs", "disc", "demo", "reward", "done"):
+        assert np.array_equal(a[k][perm], b[k]), k
+    assert set(np.unique(a["done"])) <= {0, 1, 2, 3}
+    assert np.all(np.isfinite(a["obs"])) and np.all(a["obs"][:, 264:] == 0)
+    sub = rng.choice(n, 256, replace=False)
+    ts = OT.TaskState(OT.TaskCfg(), lib, 256)
+    ts.time, ts.time_off, ts.motion_ids = time[sub].copy(), off[sub].copy(), ids[sub].copy()
+    ts.head = 1
+    ts.hist["root_pos"], ts.hist["root_rot"], ts.hist["dof_pos"] = hist[sub][:, :, 0:3].copy(), hist[sub][:, :, 3:7].copy(), hist[sub][:, :, 7:].copy()
+    obs, d_obs, d_demo, r, done = ts.step(tuple(x[sub] for x in sim), contact[sub])
+    np.testing.assert_allclose(a["obs"][sub][:, :264], obs, rtol=0, atol=ATOL)
+    np.testing.assert_allclose(a["disc"][sub][:, :114], d_obs, rtol=0, atol=ATOL)
+    np.testing.assert_allclose(a["demo"][sub][:, :114], d_demo, rtol=0, atol=ATOL)
+    np.testing.assert_allclose(a["reward"][sub], r, rtol=0, atol=ATOL)
+    assert np.array_equal(a["done"][sub], done)

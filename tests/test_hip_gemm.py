@@ -1,0 +1,117 @@
+"""fp32 MFMA GEMM (addhip_gemm_f32) against a float64 reference, all operand layouts,
+epilogues, fused input normalisation, split-K slabs, ragged shapes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def T(x):
+    import torch
+
+    return torch.tensor(np.ascontiguousarray(x), device="cuda")
+
+
+def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, seed=0):
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import gemm
+
+    rng = np.random.RandomState(seed)
+    A = rng.uniform(-1, 1, (M, K)).astype(F)
+    B = rng.uniform(-1, 1, (N, K)).astype(F)
+    bias = rng.uniform(-1, 1, N).astype(F)
+    mask = rng.uniform(-1, 1, (M, N)).astype(F)
+    mean = rng.uniform(-1, 1, K).astype(F)
+    std = rng.uniform(0.5, 2, K).astype(F)
+    lda = K if a_kc else M
+    ldb = K if b_kc else N
+    dA = T(A if a_kc else A.T.copy())
+    dB = T(B if b_kc else B.T.copy())
+    ldc = (N + 3) // 4 * 4
+    dC = torch.full((max(split_k, 1), M, ldc), 9.0, device="cuda")
+    dbias, dmask, dmean, dstd = T(bias), T(mask), T(mean), T(std)
+    g = gemm(M, N, K, L.ptr(dA), lda, a_kc, L.ptr(dB), ldb, b_kc, L.ptr(dC), ldc, epilogue, L.ptr(dbias), L.ptr(dmask), N,
+             L.ptr(dmean) if norm else None, L.ptr(dstd) if norm else None, split_k, alpha)
+    L.call("addhip_gemm_f32", g, L.current_stream())
+    torch.cuda.synchronize()
+    A64 = A.astype(np.float64)
+    if norm:
+        A64 = ((A - mean) / std).astype(np.float64)
+    ref = alpha * (A64 @ B.astype(np.float64).T)
+    scale = np.abs(A64) @ np.abs(B.astype(np.float64)).T
+    if epilogue in (1, 2):
+        ref = ref + bias
+    if epilogue == 2:
+        ref = np.maximum(ref, 0)
+    if epilogue == 3:
+        ref = np.where(mask > 0, ref, 0)
+    out = dC.cpu().numpy().astype(np.float64)
+    got = out.sum(0)[:, :N] if split_k > 1 else out[0][:, :N]
+    err = np.abs(got - ref)
+    assert np.all(err <= 4e-7 * scale * max(1.0, abs(alpha)) + 1e-6), (M, N, K, a_kc, b_kc, epilogue, split_k, float(err.max()))
+    if ldc > N:
+        assert np.all(out[0][:, N:] == 9.0)  # pad columns are never written
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("shape", [(256, 128, 64), (300, 200, 264), (128, 1024, 116), (64, 32, 512), (4100, 512, 1024)])
+def test_gemm_layouts(shape, a_kc, b_kc):
+    M, N, K = shape
+    if not a_kc:
+        M = (M + 3) // 4 * 4
+    run_gemm(M, N, K, a_kc, b_kc)
+
+
+@pytest.mark.parametrize("epi", [1, 2, 3])
+def test_gemm_epilogues(epi):
+    run_gemm(515, 1024, 264, 1, 1, epilogue=epi)
+    run_gemm(129, 32, 512, 1, 1, epilogue=epi)  # 29/32-wide head shape
+    run_gemm(257, 512, 1024, 1, 0, epilogue=epi)
+
+
+def test_gemm_fused_normalisation():
+    run_gemm(777, 1024, 264, 1, 1, epilogue=2, norm=True)
+
+
+@pytest.mark.parametrize("split", [2, 8, 16])
+def test_gemm_split_k_weight_grad_shape(split):
+    # dW[out,in] = dY^T X : both operands m-contiguous, reduction over the minibatch rows
+    run_gemm(1024, 264, 4096 + 17, 0, 0, split_k=split)
+    run_gemm(32, 512, 1000, 0, 0, split_k=split)
+
+
+def test_gemm_single_row_and_alpha():
+    run_gemm(1, 1024, 116, 1, 1, epilogue=2)
+    run_gemm(1, 512, 1024, 1, 1, epilogue=2)
+    run_gemm(200, 116, 1024, 1, 0, alpha=0.5)
+
+
+def test_gemm_rejects_bad_arguments():
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import gemm
+
+    x = torch.zeros(64, 30, device="cuda")
+    with pytest.raises(L.AddhipError):
+        L.call("addhip_gemm_f32", gemm(64, 64, 30, L.ptr(x), 30, 1, L.ptr(x), 30, 1, L.ptr(x), 64), L.current_stream())
+    with pytest.raises(L.AddhipError):
+        L.call("addhip_gemm_f32", gemm(0, 64, 32, L.ptr(x), 32, 1, L.ptr(x), 32, 1, L.ptr(x), 64), L.current_stream())
+
+
+def test_col_sum_and_slab_reduce():
+    import torch
+    import add_gym_amd._lib as L
+
+    rng = np.random.RandomState(1)
+    X = rng.standard_normal((5001, 300)).astype(F)
+    out = torch.full((300,), 5.0, device="cuda")
+    L.call("addhip_col_sum", L.ptr(T(X)), 5001, 300, 300, L.ptr(out), 2.0, 0, L.current_stream())
+    np.testing.assert_allclose(out.cpu().numpy(), 2.0 * X.astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
+    L.call("addhip_col_sum", L.ptr(T(X)), 5001, 300, 300, L.ptr(out), 1.0, 1, L.current_stream())
+    np.testing.assert_allclose(out.cpu().numpy(), 3.0 * X.astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
+    S = rng.standard_normal((6, 1000)).astype(F)
+    o2 = torch.ones(1000, device="cuda")
+    L.call("addhip_slab_reduce", L.ptr(T(S)), 6, 1000, L.ptr(o2), 1000, 0.5, 1, L.current_stream())
+    np.testing.assert_allclose(o2.cpu().numpy(), 1 + 0.5 * S.sum(0), rtol=1e-5, atol=1e-5)

@@ -1,0 +1,315 @@
+"""Learner-side HIP kernels through the C ABI against the CPU oracle (oracle/learn.py, oracle/task.py)
+and the reference's golden vectors."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import learn as OL
+from oracle import task as OT
+from tests.util import gload
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def T(x, dtype=None):
+    import torch
+
+    return torch.tensor(np.ascontiguousarray(x), dtype=dtype, device="cuda")
+
+
+def logp_const():
+    import torch
+
+    logstd = torch.full((29,), float(np.log(0.05)), dtype=torch.float32)
+    return float((-0.5 * 29 * np.log(2.0 * np.pi) - torch.sum(logstd)).item()), float(torch.exp(logstd)[0].item())
+
+
+def test_actor_sample_matches_reference_golden():
+    import torch
+    import add_gym_amd._lib as L
+
+    g = gload("actor_step")
+    model = OL.Model(OL.synth_params(int(g["seed"])))
+    on = OL.Normalizer(264, g["obs_mean"], g["obs_std"])
+    with torch.no_grad():
+        mean = model.actor_mean(OL.t32(on.normalize(g["obs"]))).numpy()
+    n = mean.shape[0]
+    mean32 = np.zeros((n, 32), F)
+    mean32[:, :29] = mean
+    c, std = logp_const()
+    act = torch.zeros(n, 32, device="cuda")
+    logp = torch.zeros(n, device="cuda")
+    mask = torch.zeros(n, device="cuda")
+    L.call("addhip_actor_sample", L.ptr(T(mean32)), 32, L.ptr(T(g["noise"])), std, c, L.ptr(T(g["a_mean"])), L.ptr(T(g["a_std"])), n, 0,
+           L.ptr(act), L.ptr(logp), L.ptr(mask), L.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(act.cpu().numpy()[:, :29], g["action"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["a_logp"], rtol=1e-5, atol=1e-4)
+    assert np.all(mask.cpu().numpy() == 1) and np.all(act.cpu().numpy()[:, 29:] == 0)
+
+
+def test_td_lambda_adv_matches_reference_golden():
+    import torch
+    import add_gym_amd._lib as L
+
+    g = gload("td_lambda_adv")
+    Tn, n = g["r"].shape
+    nv = T(g["next_vals"])
+    tar = torch.zeros(Tn, n, device="cuda")
+    adv = torch.zeros(Tn, n, device="cuda")
+    scratch = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    stats = torch.zeros(2, device="cuda")
+    L.call("addhip_td_lambda_adv", L.ptr(T(g["r"])), L.ptr(nv), L.ptr(T(g["vals"])), L.ptr(T(g["done"], torch.int32)), L.ptr(torch.ones(Tn, n, device="cuda")),
+           Tn, n, 0.99, 0.95, 0.0, 0.0, 4.0, L.ptr(tar), L.ptr(adv), L.ptr(scratch), L.ptr(stats), L.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(tar.cpu().numpy(), g["tar_val"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(stats.cpu().numpy(), [float(g["adv_mean"]), float(g["adv_std"])], rtol=1e-5)
+    np.testing.assert_allclose(adv.cpu().numpy(), g["adv"], rtol=1e-5, atol=1e-5)
+
+
+def test_normalizers_match_reference_golden():
+    import torch
+    import add_gym_amd._lib as L
+
+    g = gload("normalizers")
+    mean, std, msq = torch.zeros(7, device="cuda"), torch.ones(7, device="cuda"), torch.zeros(7, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    s1, s2 = torch.zeros(7, device="cuda"), torch.zeros(7, device="cuda")
+    ma, dcnt, sa = torch.ones(5, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(5, device="cuda")
+    for it in range(3):
+        for s in range(4):
+            x, y = T(g[f"x{it}_{s}"]), T(g[f"y{it}_{s}"])
+            L.call("addhip_norm_accum", L.ptr(x), 33, 7, 7, L.ptr(s1), L.ptr(s2), L.current_stream())
+            L.call("addhip_norm_accum", L.ptr(torch.abs(y).contiguous()), 33, 5, 5, L.ptr(sa), None, L.current_stream())
+        L.call("addhip_norm_merge", L.ptr(mean), L.ptr(std), L.ptr(msq), L.ptr(cnt), L.ptr(s1), L.ptr(s2), 132, 7, 1e-8, int(it == 0), L.current_stream())
+        L.call("addhip_diffnorm_merge", L.ptr(ma), L.ptr(dcnt), L.ptr(sa), 132, 5, L.current_stream())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(mean.cpu().numpy(), g[f"mean{it}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(std.cpu().numpy(), g[f"std{it}"], rtol=1e-5)
+        np.testing.assert_allclose(ma.cpu().numpy(), g[f"mean_abs{it}"], rtol=1e-5)
+        assert int(cnt.item()) == int(g[f"count{it}"][0]) and int(dcnt.item()) == int(g[f"dcount{it}"][0])
+
+
+def test_disc_prep_sampler_and_reward():
+    import torch
+    import add_gym_amd._lib as L
+
+    rng = np.random.RandomState(5)
+    rows, dim, stride = 6000, 114, 116
+    a = np.zeros((rows, stride), F)
+    d = np.zeros((rows, stride), F)
+    a[:, :dim] = rng.standard_normal((rows, dim))
+    d[:, :dim] = rng.standard_normal((rows, dim))
+    mean_abs = (rng.rand(stride) * 0.5 + 1e-5).astype(F)
+    lengths = np.asarray([6.6333, 2.0, 9.3], F)
+    ids = rng.randint(0, 3, rows)
+    times = (rng.rand(rows).astype(F) * lengths[ids] * 1.05).astype(F)
+    smp = OT.SegmentSampler(lengths, 0.01, 20, None, 0.02)
+    smp.errors = (rng.rand(3, 20) * 2).astype(F)
+    err0 = smp.errors.copy()
+    t = dict(err=T(err0), seg=T(smp.segment_sizes), cdf=T(np.asarray([0.3, 0.6, 1.0], F)), bits=torch.zeros(1, dtype=torch.int32, device="cuda"),
+             es=torch.zeros(60, device="cuda"), ec=torch.zeros(60, device="cuda"))
+    sc = L.SamplerT(L.ptr(t["err"]), L.ptr(t["seg"]), L.ptr(t["cdf"]), 20, -1.0, 0.02, 1, L.ptr(t["bits"]), L.ptr(t["es"]), L.ptr(t["ec"]))
+    nd = torch.full((rows, stride), 3.0, device="cuda")
+    abs_sum = torch.zeros(stride, device="cuda")
+    L.call("addhip_disc_prep", L.ptr(T(a)), L.ptr(T(d)), stride, dim, rows, L.ptr(T(mean_abs)), 1e-4, L.ptr(nd), L.ptr(T(ids, torch.int32)), L.ptr(T(times)),
+           sc, 3, L.ptr(abs_sum), L.current_stream())
+    L.call("addhip_sampler_update", sc, 3, L.current_stream())
+    torch.cuda.synchronize()
+    dn = OL.DiffNormalizer(dim)
+    dn.mean_abs = mean_abs[:dim]
+    np.testing.assert_allclose(nd.cpu().numpy()[:, :dim], dn.normalize(d[:, :dim] - a[:, :dim]), rtol=1e-6, atol=1e-6)
+    assert np.all(nd.cpu().numpy()[:, dim:] == 0)
+    np.testing.assert_allclose(abs_sum.cpu().numpy()[:dim], np.abs(d - a)[:, :dim].astype(np.float64).sum(0), rtol=1e-5)
+    diff = a[:, :dim] - d[:, :dim]
+    smp.update_errors(ids, times, np.sum(diff * diff, axis=-1, dtype=F))
+    np.testing.assert_allclose(t["err"].cpu().numpy().reshape(3, 20), smp.errors, rtol=1e-5)
+    assert float(t["es"].abs().sum()) == 0 and float(t["ec"].abs().sum()) == 0
+    # disc reward (amp_agent.py:194-206) + reward mix
+    logits = (rng.standard_normal(rows) * 4).astype(F)
+    task_r = rng.rand(rows).astype(F)
+    rew = T(task_r)
+    stats = torch.zeros(2, device="cuda")
+    L.call("addhip_disc_reward", L.ptr(T(logits)), L.ptr(rew), rows, 2.0, 0.0, 1.0, L.ptr(stats), L.current_stream())
+    torch.cuda.synchronize()
+    dr = OL.disc_reward(logits, 2.0)
+    np.testing.assert_allclose(rew.cpu().numpy(), dr, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(stats.cpu().numpy()[0], dr.astype(np.float64).sum(), rtol=1e-5)
+
+
+def test_gather_minibatch():
+    import torch
+    import add_gym_amd._lib as L
+
+    rng = np.random.RandomState(6)
+    R, Mb = 3000, 777
+    obs = rng.standard_normal((R, 264)).astype(F)
+    act = np.zeros((R, 32), F)
+    act[:, :29] = rng.standard_normal((R, 29))
+    do, dd = np.zeros((R, 116), F), np.zeros((R, 116), F)
+    do[:, :114], dd[:, :114] = rng.standard_normal((R, 114)), rng.standard_normal((R, 114))
+    sc = {k: rng.standard_normal(R).astype(F) for k in ("logp", "adv", "tar", "mask")}
+    om, os_ = rng.standard_normal(264).astype(F), (rng.rand(264) + 0.5).astype(F)
+    am, as_ = rng.standard_normal(29).astype(F), (rng.rand(29) + 0.5).astype(F)
+    ma = (rng.rand(116) * 0.3).astype(F)
+    idx = rng.randint(0, R, Mb).astype(np.int64)
+    d = {k: T(v) for k, v in dict(obs=obs, act=act, do=do, dd=dd, om=om, os=os_, am=am, as_=as_, ma=ma, idx=idx, **sc).items()}
+    o = dict(no=torch.zeros(Mb, 264, device="cuda"), na=torch.ones(Mb, 32, device="cuda"), lp=torch.zeros(Mb, device="cuda"), ad=torch.zeros(Mb, device="cuda"),
+             tv=torch.zeros(Mb, device="cuda"), mk=torch.zeros(Mb, device="cuda"), nd=torch.ones(Mb, 116, device="cuda"))
+    g = L.GatherT(L.ptr(d["idx"]), Mb, L.ptr(d["obs"]), 264, 264, L.ptr(d["om"]), L.ptr(d["os"]), L.ptr(d["act"]), L.ptr(d["am"]), L.ptr(d["as_"]),
+                  L.ptr(d["logp"]), L.ptr(d["adv"]), L.ptr(d["tar"]), L.ptr(d["mask"]), L.ptr(d["do"]), L.ptr(d["dd"]), 116, 114, L.ptr(d["ma"]), 1e-4,
+                  L.ptr(o["no"]), L.ptr(o["na"]), L.ptr(o["lp"]), L.ptr(o["ad"]), L.ptr(o["tv"]), L.ptr(o["mk"]), L.ptr(o["nd"]))
+    L.call("addhip_gather_minibatch", g, L.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o["no"].cpu().numpy(), (obs[idx] - om) / os_, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(o["na"].cpu().numpy()[:, :29], (act[idx][:, :29] - am) / as_, rtol=1e-6, atol=1e-6)
+    assert np.all(o["na"].cpu().numpy()[:, 29:] == 0) and np.all(o["nd"].cpu().numpy()[:, 114:] == 0)
+    np.testing.assert_allclose(o["nd"].cpu().numpy()[:, :114], (dd[idx] - do[idx])[:, :114] / np.maximum(ma[:114], 1e-4), rtol=1e-6, atol=1e-6)
+    for k, kk in (("lp", "logp"), ("ad", "adv"), ("tv", "tar"), ("mk", "mask")):
+        assert np.array_equal(o[k].cpu().numpy(), sc[kk][idx])
+
+
+def test_actor_loss_head_gradient():
+    import torch
+    import add_gym_amd._lib as L
+
+    rng = np.random.RandomState(7)
+    M = 1000
+    mean = (rng.standard_normal((M, 29)) * 0.7).astype(F)
+    mean[:20] *= 3  # bound violations
+    na = (mean + rng.standard_normal((M, 29)) * 0.05).astype(F)
+    adv = np.clip(rng.standard_normal(M), -4, 4).astype(F)
+    mask = (rng.rand(M) < 0.9).astype(F)
+    c, std = logp_const()
+    mt = torch.tensor(mean, requires_grad=True)
+    d = (torch.tensor(na) - mt) / std
+    logp = -0.5 * torch.sum(d * d, -1) + c
+    old = (logp.detach() + torch.tensor(rng.standard_normal(M).astype(F) * 0.3)).numpy()
+    sel = torch.tensor(mask) == 1.0
+    ratio = torch.exp(logp - torch.tensor(old))[sel]
+    a = torch.tensor(adv)[sel]
+    loss = -torch.mean(torch.minimum(a * ratio, a * torch.clamp(ratio, 0.8, 1.2)))
+    vmin, vmax = torch.clamp_max(mt[sel] + 1, 0), torch.clamp_min(mt[sel] - 1, 0)
+    bound = torch.mean(torch.sum(vmin ** 2, -1) + torch.sum(vmax ** 2, -1))
+    (loss + 10.0 * bound).backward()
+    pad = lambda x: np.concatenate([x, np.zeros((M, 3), F)], -1)
+    nv = torch.zeros(1, device="cuda")
+    dm = torch.zeros(M, 32, device="cuda")
+    stats = torch.zeros(8, device="cuda")
+    dmask = T(mask)
+    L.call("addhip_count_mask", L.ptr(dmask), M, L.ptr(nv), L.current_stream())
+    L.call("addhip_actor_loss", L.ptr(T(pad(mean))), L.ptr(T(pad(na))), L.ptr(T(old)), L.ptr(T(adv)), L.ptr(dmask), M, std, c, 0.2, 10.0, 1.0, L.ptr(nv),
+           L.ptr(dm), L.ptr(stats), L.current_stream())
+    torch.cuda.synchronize()
+    assert float(nv.item()) == mask.sum()
+    g = mt.grad.numpy()
+    np.testing.assert_allclose(dm.cpu().numpy()[:, :29], g, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(g).max())
+    s = stats.cpu().numpy()
+    nvf = mask.sum()
+    np.testing.assert_allclose(-s[0] / nvf, loss.item(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(s[3] / nvf, bound.item(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(s[2] / nvf, ratio.mean().item(), rtol=1e-4)
+    np.testing.assert_allclose(s[1] / nvf, (torch.abs(ratio - 1) > 0.2).float().mean().item(), atol=2.0 / nvf)
+
+
+def test_critic_and_disc_heads_and_grad_penalty():
+    import torch
+    import add_gym_amd._lib as L
+
+    rng = np.random.RandomState(8)
+    M, K = 999, 512
+    H = np.maximum(rng.standard_normal((M + 1, K)), 0).astype(F)
+    w, b = (rng.standard_normal(K) * 0.1).astype(F), np.asarray([0.3], F)
+    tar = rng.standard_normal(M).astype(F)
+    dH, dw, db = T(H), T(w), T(b)
+    # critic (ppo_agent.py:209-219)
+    dZ, dv, st = torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda"), torch.zeros(8, device="cuda")
+    L.call("addhip_critic_head", L.ptr(dH), K, K, M, L.ptr(dw), L.ptr(db), L.ptr(T(tar)), 1.0, L.ptr(dZ), L.ptr(dv), L.ptr(st), L.current_stream())
+    Ht = torch.tensor(H[:M], requires_grad=True)
+    wt, bt = torch.tensor(w, requires_grad=True), torch.tensor(b, requires_grad=True)
+    v = Ht @ wt + bt
+    loss = torch.mean((torch.tensor(tar) - v) ** 2)
+    loss.backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(st.cpu().numpy()[0] / M, loss.item(), rtol=1e-5)
+    np.testing.assert_allclose(dZ.cpu().numpy(), Ht.grad.numpy() * (H[:M] > 0), rtol=1e-4, atol=1e-8)
+    dwv = torch.zeros(K, device="cuda")
+    L.call("addhip_weighted_col_sum", L.ptr(dv), L.ptr(dH), K, K, M, L.ptr(dwv), 1.0, 0, L.current_stream())
+    np.testing.assert_allclose(dwv.cpu().numpy(), wt.grad.numpy(), rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(dv.cpu().numpy().sum(), bt.grad.item(), rtol=1e-3, atol=1e-6)
+    # discriminator head (add_agent.py:141-163, amp_agent.py:177-192); row M is the zero-difference sample
+    dl, st2 = torch.zeros(M + 1, device="cuda"), torch.zeros(8, device="cuda")
+    L.call("addhip_disc_head", L.ptr(dH), K, K, M, L.ptr(dH) + M * K * 4, L.ptr(dw), L.ptr(db), 0.5, L.ptr(dl), L.ptr(dl) + M * 4, L.ptr(st2), L.current_stream())
+    Ht = torch.tensor(H, requires_grad=True)
+    logit = Ht @ torch.tensor(w) + torch.tensor(b)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    lneg, lpos = bce(logit[:M], torch.full((M,), 0.1)), bce(logit[M:], torch.full((1,), 0.9))
+    (0.5 * 0.5 * (lneg + lpos)).backward()
+    torch.cuda.synchronize()
+    s = st2.cpu().numpy()
+    np.testing.assert_allclose([s[0] / M, s[1]], [lneg.item(), lpos.item()], rtol=1e-5)
+    np.testing.assert_allclose(s[2] / M, logit[:M].mean().item(), rtol=1e-4, atol=1e-6)
+    assert s[4] == float((logit[:M] < 0).sum()) and s[5] == float(logit[M] > 0)
+    out = torch.zeros(M + 1, K, device="cuda")
+    L.call("addhip_outer_mask", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, L.ptr(out), L.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), Ht.grad.numpy() * (H > 0), rtol=1e-4, atol=1e-9)
+    # gradient penalty (add_agent.py:166-178)
+    g = np.zeros((M, 116), F)
+    g[:, :114] = rng.standard_normal((M, 114)) * 0.1
+    g[0, :114] = 0  # |g| = 0 row: sqrt(eps) branch
+    gt = torch.tensor(g[:, :114], requires_grad=True)
+    n = torch.sqrt(torch.sum(gt * gt, -1) + 1e-8)
+    gp = torch.mean((n - 1) ** 2)
+    (20.0 * 0.5 * gp).backward()
+    G, st3 = torch.ones(M, 116, device="cuda"), torch.zeros(8, device="cuda")
+    L.call("addhip_grad_penalty", L.ptr(T(g)), 116, 114, M, 10.0, L.ptr(G), L.ptr(st3), L.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(st3.cpu().numpy()[0] / M, gp.item(), rtol=1e-5)
+    np.testing.assert_allclose(G.cpu().numpy()[:, :114], gt.grad.numpy(), rtol=1e-4, atol=1e-8)
+    assert np.all(G.cpu().numpy()[:, 114:] == 0)
+
+
+def test_adamw_matches_torch():
+    import torch
+    import add_gym_amd._lib as L
+
+    rng = np.random.RandomState(9)
+    n = 100003
+    p0 = rng.standard_normal(n).astype(F)
+    p = torch.nn.Parameter(torch.tensor(p0))
+    opt = torch.optim.AdamW([p], 1e-4, weight_decay=0.0)
+    dp, m, v = T(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        g = (rng.standard_normal(n) * (10.0 ** rng.randint(-4, 2, n))).astype(F)
+        p.grad = torch.tensor(g)
+        opt.step()
+        L.call("addhip_adamw", L.ptr(dp), L.ptr(T(g)), L.ptr(m), L.ptr(v), n, 1e-4, 0.9, 0.999, 1e-8, 0.0, step, L.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dp.cpu().numpy(), p.detach().numpy(), rtol=1e-6, atol=1e-8)
+
+
+def test_philox_fills_and_return_tracker():
+    import torch
+    import add_gym_amd._lib as L
+
+    n = 1 << 20
+    a, b, u = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    L.call("addhip_fill_normal", L.ptr(a), n, 123, 7, L.current_stream())
+    L.call("addhip_fill_normal", L.ptr(b), n, 123, 7, L.current_stream())
+    L.call("addhip_fill_uniform", L.ptr(u), n, 123, 8, L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)  # counter-based: same (seed, stream) -> same numbers
+    assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3 and abs((a ** 4).mean().item() - 3) < 0.05
+    assert 0 <= u.min().item() and u.max().item() < 1 and abs(u.mean().item() - 0.5) < 2e-3
+    ep = np.zeros((5, 3), F)
+    ep[1] = [6.0, 30.0, 3.0]
+    ep[3] = [2.0, 8.0, 1.0]
+    state = T(np.asarray([2.0, 1.5, 12.0], F))
+    L.call("addhip_return_tracker_fold", L.ptr(T(ep)), 5, L.ptr(state), L.current_stream())
+    torch.cuda.synchronize()
+    m1 = (3 / 5) * 2.0 + (2 / 5) * 1.5
+    m2 = (1 / 6) * 2.0 + (5 / 6) * m1
+    np.testing.assert_allclose(state.cpu().numpy(), [6.0, m2, (1 / 6) * 8 + (5 / 6) * ((3 / 5) * 10 + (2 / 5) * 12)], rtol=1e-6)

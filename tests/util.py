@@ -46,3 +46,47 @@ def oracle_lib(two=False, reference_compat=True, golden_tables=False):
 
 def variant(g, prefix):
     return {k[len(prefix) + 1:]: g[k] for k in g.files if k.startswith(prefix + ".")}
+
+
+# ---------------------------------------------------------------- GPU-side helpers
+DEFAULT_TASK = dict(
+    global_obs=True, root_height_obs=True, enable_vel_obs=False, enable_phase_obs=False, enable_tar_obs=True,
+    tar_obs_steps=[1, 2, 3, 4, 5, 6], num_disc_obs_steps=3, max_episode_length=20.0, enable_early_termination=True,
+    pose_termination=True, pose_termination_dist=1.0, rand_reset=True,
+    reward_pose_w=0.5, reward_vel_w=0.1, reward_root_pose_w=0.15, reward_root_vel_w=0.1,
+    reward_pose_scale=0.25, reward_vel_scale=0.01, reward_root_pose_scale=5.0, reward_root_vel_scale=1.0,
+)
+
+
+def pack_pose(root_pos, root_rot, dof_pos):
+    return np.concatenate([root_pos, root_rot, dof_pos], axis=-1).astype(np.float32)
+
+
+def pack_vel(root_vel, root_ang, dof_vel):
+    z = np.zeros(root_vel.shape[:-1] + (1,), np.float32)
+    return np.concatenate([root_vel, root_ang, dof_vel, z], axis=-1).astype(np.float32)
+
+
+class HipMotion:
+    """addhip_motion_t over the golden step tables (device tensors kept alive here)."""
+
+    def __init__(self, two=False, reference_compat=True):
+        import torch
+        import add_gym_amd._lib as L
+
+        m = gload("motion_small")
+        pre = "two_step_" if two else "step_"
+        dev = "cuda"
+        self.pose = torch.tensor(pack_pose(m[pre + "root_pos"], m[pre + "root_rot"], m[pre + "dof_pos"]), device=dev)
+        self.vel = torch.tensor(pack_vel(m[pre + "root_vel"], m[pre + "root_ang_vel"], m[pre + "dof_vel"]), device=dev)
+        lengths = m[("two_" if two else "") + "lengths"].astype(np.float32)
+        steps = np.asarray([int(np.ceil(float(l) / 0.01)) for l in lengths], np.int32)
+        raw_start = m[("two_" if two else "") + "start_idx"].astype(np.int32)
+        step_start = np.concatenate([[0], np.cumsum(steps)[:-1]]).astype(np.int32)
+        self.start = torch.tensor(raw_start if reference_compat else step_start, device=dev)
+        self.steps = torch.tensor(steps, device=dev)
+        self.len = torch.tensor(lengths, device=dev)
+        self.loop = torch.zeros(len(lengths), dtype=torch.int32, device=dev)
+        self.lengths = lengths
+        self.c = L.MotionT(L.ptr(self.pose), L.ptr(self.vel), L.ptr(self.start), L.ptr(self.steps), L.ptr(self.len), L.ptr(self.loop),
+                           len(lengths), int(self.pose.shape[0]), int(reference_compat), 100.0)
