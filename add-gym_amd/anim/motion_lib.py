@@ -132,8 +132,10 @@ class MotionLib:
         """Row indices only (int32, bit-exact vs motion_lib.py:322-326)."""
         n = motion_ids.shape[0]
         idx = torch.empty(n, dtype=torch.int32, device=self._device)
-        L.call("addhip_motion_lookup", self.c_struct, L.ptr(motion_ids.to(torch.int32).contiguous()),
-               L.ptr(motion_times.to(torch.float32).contiguous()), n, L.ptr(idx), None, None, L.current_stream())
+        # keep both converted inputs referenced until the launch is enqueued (a temporary freed between
+        # two ptr() calls could be recycled by the caching allocator for the next one)
+        ids32, t32 = motion_ids.to(torch.int32).contiguous(), motion_times.to(torch.float32).contiguous()
+        L.call("addhip_motion_lookup", self.c_struct, L.ptr(ids32), L.ptr(t32), n, L.ptr(idx), None, None, L.current_stream())
         return idx
 
     def get_precomputed_motion_step(self, motion_ids, motion_times):
@@ -141,6 +143,6 @@ class MotionLib:
         n = motion_ids.shape[0]
         pose = torch.empty(n, L.POSE_W, device=self._device)
         vel = torch.empty(n, L.POSE_W, device=self._device)
-        L.call("addhip_motion_lookup", self.c_struct, L.ptr(motion_ids.to(torch.int32).contiguous()),
-               L.ptr(motion_times.to(torch.float32).contiguous()), n, None, L.ptr(pose), L.ptr(vel), L.current_stream())
+        ids32, t32 = motion_ids.to(torch.int32).contiguous(), motion_times.to(torch.float32).contiguous()
+        L.call("addhip_motion_lookup", self.c_struct, L.ptr(ids32), L.ptr(t32), n, None, L.ptr(pose), L.ptr(vel), L.current_stream())
         return pose[:, 0:3], pose[:, 3:7], vel[:, 0:3], vel[:, 3:6], pose[:, 7:], vel[:, 6:35]

@@ -13,6 +13,19 @@ FIELDS = ("root_pos", "root_rot", "root_vel", "root_ang_vel", "dof_pos", "dof_ve
 ATOL = 5e-6
 
 
+_KEEP = []
+
+
+def P(t):
+    """Device address of a tensor that is kept alive until the test module is torn down: launches are
+    asynchronous, so a temporary freed right after ptr() could be recycled by the caching allocator
+    before the kernel has read it."""
+    import add_gym_amd._lib as L
+
+    _KEEP.append(t)
+    return L.ptr(t)
+
+
 def T(x, dtype=None):
     import torch
 
@@ -138,7 +151,7 @@ def test_env_reset_matches_reference(tag):
     disc = torch.zeros(n, task.disc_stride, device="cuda")
     demo = torch.zeros(n, task.disc_stride, device="cuda")
     head = int(v["hist_head"])
-    L.call("addhip_env_reset", mot.c, task, env, sc, L.ptr(T(u_clip)), L.ptr(T(u_seg)), L.ptr(T(u_jit)), L.ptr(obs), L.ptr(disc), L.ptr(demo), 0, head,
+    L.call("addhip_env_reset", mot.c, task, env, sc, P(T(u_clip)), P(T(u_seg)), P(T(u_jit)), L.ptr(obs), L.ptr(disc), L.ptr(demo), 0, head,
            L.current_stream())
     torch.cuda.synchronize()
     assert np.array_equal(st["motion_id"].cpu().numpy(), v["post_motion_ids"])
@@ -167,14 +180,14 @@ def test_lookup_bit_exact():
         n = len(ids)
         idx = torch.zeros(n, dtype=torch.int32, device="cuda")
         pose = torch.zeros(n, 36, device="cuda")
-        L.call("addhip_motion_lookup", mot.c, L.ptr(T(ids, torch.int32)), L.ptr(T(times, torch.float32)), n, L.ptr(idx), L.ptr(pose), None, L.current_stream())
+        L.call("addhip_motion_lookup", mot.c, P(T(ids, torch.int32)), P(T(times, torch.float32)), n, L.ptr(idx), L.ptr(pose), None, L.current_stream())
         torch.cuda.synchronize()
         assert np.array_equal(idx.cpu().numpy(), ref)
         assert np.array_equal(pose.cpu().numpy(), mot.pose.cpu().numpy()[ref])
     # the corrected multi-clip mode differs from the reference's quirk and never leaves a clip's rows
     fixed = HipMotion(True, reference_compat=False)
     idx = torch.zeros(len(g["two_ids"]), dtype=torch.int32, device="cuda")
-    L.call("addhip_motion_lookup", fixed.c, L.ptr(T(g["two_ids"], torch.int32)), L.ptr(T(g["two_times"], torch.float32)), len(idx), L.ptr(idx), None, None,
+    L.call("addhip_motion_lookup", fixed.c, P(T(g["two_ids"], torch.int32)), P(T(g["two_times"], torch.float32)), len(idx), L.ptr(idx), None, None,
            L.current_stream())
     orc = oracle_lib(two=True, reference_compat=False)
     assert np.array_equal(idx.cpu().numpy(), orc.step_index(g["two_ids"], g["two_times"]))
@@ -193,7 +206,7 @@ def test_kin_engine_step_matches_oracle_sim():
     vel = T(pack_vel(sim.root_vel, sim.root_ang, sim.dof_vel))
     for _ in range(3):
         act = rng.standard_normal((n, 32)).astype(F)
-        L.call("addhip_kin_engine_step", L.ptr(pose), L.ptr(vel), L.ptr(T(act)), 32, n, 0.5, 0.01, L.current_stream())
+        L.call("addhip_kin_engine_step", L.ptr(pose), L.ptr(vel), P(T(act)), 32, n, 0.5, 0.01, L.current_stream())
         sim.step(act[:, :29])
     torch.cuda.synchronize()
     assert np.array_equal(pose.cpu().numpy()[:, 7:], sim.dof_pos)

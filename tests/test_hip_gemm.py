@@ -7,6 +7,19 @@ pytestmark = pytest.mark.gpu
 F = np.float32
 
 
+_KEEP = []
+
+
+def P(t):
+    """Device address of a tensor that is kept alive until the test module is torn down: launches are
+    asynchronous, so a temporary freed right after ptr() could be recycled by the caching allocator
+    before the kernel has read it."""
+    import add_gym_amd._lib as L
+
+    _KEEP.append(t)
+    return L.ptr(t)
+
+
 def T(x):
     import torch
 
@@ -107,11 +120,11 @@ def test_col_sum_and_slab_reduce():
     rng = np.random.RandomState(1)
     X = rng.standard_normal((5001, 300)).astype(F)
     out = torch.full((300,), 5.0, device="cuda")
-    L.call("addhip_col_sum", L.ptr(T(X)), 5001, 300, 300, L.ptr(out), 2.0, 0, L.current_stream())
+    L.call("addhip_col_sum", P(T(X)), 5001, 300, 300, L.ptr(out), 2.0, 0, L.current_stream())
     np.testing.assert_allclose(out.cpu().numpy(), 2.0 * X.astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
-    L.call("addhip_col_sum", L.ptr(T(X)), 5001, 300, 300, L.ptr(out), 1.0, 1, L.current_stream())
+    L.call("addhip_col_sum", P(T(X)), 5001, 300, 300, L.ptr(out), 1.0, 1, L.current_stream())
     np.testing.assert_allclose(out.cpu().numpy(), 3.0 * X.astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
     S = rng.standard_normal((6, 1000)).astype(F)
     o2 = torch.ones(1000, device="cuda")
-    L.call("addhip_slab_reduce", L.ptr(T(S)), 6, 1000, L.ptr(o2), 1000, 0.5, 1, L.current_stream())
+    L.call("addhip_slab_reduce", P(T(S)), 6, 1000, L.ptr(o2), 1000, 0.5, 1, L.current_stream())
     np.testing.assert_allclose(o2.cpu().numpy(), 1 + 0.5 * S.sum(0), rtol=1e-5, atol=1e-5)

@@ -13,6 +13,19 @@ pytestmark = pytest.mark.gpu
 F = np.float32
 
 
+_KEEP = []
+
+
+def P(t):
+    """Device address of a tensor that is kept alive until the test module is torn down: launches are
+    asynchronous, so a temporary freed right after ptr() could be recycled by the caching allocator
+    before the kernel has read it."""
+    import add_gym_amd._lib as L
+
+    _KEEP.append(t)
+    return L.ptr(t)
+
+
 def T(x, dtype=None):
     import torch
 
@@ -42,7 +55,7 @@ def test_actor_sample_matches_reference_golden():
     act = torch.zeros(n, 32, device="cuda")
     logp = torch.zeros(n, device="cuda")
     mask = torch.zeros(n, device="cuda")
-    L.call("addhip_actor_sample", L.ptr(T(mean32)), 32, L.ptr(T(g["noise"])), std, c, L.ptr(T(g["a_mean"])), L.ptr(T(g["a_std"])), n, 0,
+    L.call("addhip_actor_sample", P(T(mean32)), 32, P(T(g["noise"])), std, c, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0,
            L.ptr(act), L.ptr(logp), L.ptr(mask), L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(act.cpu().numpy()[:, :29], g["action"], rtol=0, atol=1e-5)
@@ -61,7 +74,7 @@ def test_td_lambda_adv_matches_reference_golden():
     adv = torch.zeros(Tn, n, device="cuda")
     scratch = torch.zeros(4096, dtype=torch.float64, device="cuda")
     stats = torch.zeros(2, device="cuda")
-    L.call("addhip_td_lambda_adv", L.ptr(T(g["r"])), L.ptr(nv), L.ptr(T(g["vals"])), L.ptr(T(g["done"], torch.int32)), L.ptr(torch.ones(Tn, n, device="cuda")),
+    L.call("addhip_td_lambda_adv", P(T(g["r"])), L.ptr(nv), P(T(g["vals"])), P(T(g["done"], torch.int32)), P(torch.ones(Tn, n, device="cuda")),
            Tn, n, 0.99, 0.95, 0.0, 0.0, 4.0, L.ptr(tar), L.ptr(adv), L.ptr(scratch), L.ptr(stats), L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(tar.cpu().numpy(), g["tar_val"], rtol=1e-6, atol=1e-6)
@@ -82,7 +95,7 @@ def test_normalizers_match_reference_golden():
         for s in range(4):
             x, y = T(g[f"x{it}_{s}"]), T(g[f"y{it}_{s}"])
             L.call("addhip_norm_accum", L.ptr(x), 33, 7, 7, L.ptr(s1), L.ptr(s2), L.current_stream())
-            L.call("addhip_norm_accum", L.ptr(torch.abs(y).contiguous()), 33, 5, 5, L.ptr(sa), None, L.current_stream())
+            L.call("addhip_norm_accum", P(torch.abs(y).contiguous()), 33, 5, 5, L.ptr(sa), None, L.current_stream())
         L.call("addhip_norm_merge", L.ptr(mean), L.ptr(std), L.ptr(msq), L.ptr(cnt), L.ptr(s1), L.ptr(s2), 132, 7, 1e-8, int(it == 0), L.current_stream())
         L.call("addhip_diffnorm_merge", L.ptr(ma), L.ptr(dcnt), L.ptr(sa), 132, 5, L.current_stream())
         torch.cuda.synchronize()
@@ -114,7 +127,7 @@ def test_disc_prep_sampler_and_reward():
     sc = L.SamplerT(L.ptr(t["err"]), L.ptr(t["seg"]), L.ptr(t["cdf"]), 20, -1.0, 0.02, 1, L.ptr(t["bits"]), L.ptr(t["es"]), L.ptr(t["ec"]))
     nd = torch.full((rows, stride), 3.0, device="cuda")
     abs_sum = torch.zeros(stride, device="cuda")
-    L.call("addhip_disc_prep", L.ptr(T(a)), L.ptr(T(d)), stride, dim, rows, L.ptr(T(mean_abs)), 1e-4, L.ptr(nd), L.ptr(T(ids, torch.int32)), L.ptr(T(times)),
+    L.call("addhip_disc_prep", P(T(a)), P(T(d)), stride, dim, rows, P(T(mean_abs)), 1e-4, L.ptr(nd), P(T(ids, torch.int32)), P(T(times)),
            sc, 3, L.ptr(abs_sum), L.current_stream())
     L.call("addhip_sampler_update", sc, 3, L.current_stream())
     torch.cuda.synchronize()
@@ -132,7 +145,7 @@ def test_disc_prep_sampler_and_reward():
     task_r = rng.rand(rows).astype(F)
     rew = T(task_r)
     stats = torch.zeros(2, device="cuda")
-    L.call("addhip_disc_reward", L.ptr(T(logits)), L.ptr(rew), rows, 2.0, 0.0, 1.0, L.ptr(stats), L.current_stream())
+    L.call("addhip_disc_reward", P(T(logits)), L.ptr(rew), rows, 2.0, 0.0, 1.0, L.ptr(stats), L.current_stream())
     torch.cuda.synchronize()
     dr = OL.disc_reward(logits, 2.0)
     np.testing.assert_allclose(rew.cpu().numpy(), dr, rtol=1e-5, atol=1e-6)
@@ -200,7 +213,7 @@ def test_actor_loss_head_gradient():
     stats = torch.zeros(8, device="cuda")
     dmask = T(mask)
     L.call("addhip_count_mask", L.ptr(dmask), M, L.ptr(nv), L.current_stream())
-    L.call("addhip_actor_loss", L.ptr(T(pad(mean))), L.ptr(T(pad(na))), L.ptr(T(old)), L.ptr(T(adv)), L.ptr(dmask), M, std, c, 0.2, 10.0, 1.0, L.ptr(nv),
+    L.call("addhip_actor_loss", P(T(pad(mean))), P(T(pad(na))), P(T(old)), P(T(adv)), L.ptr(dmask), M, std, c, 0.2, 10.0, 1.0, L.ptr(nv),
            L.ptr(dm), L.ptr(stats), L.current_stream())
     torch.cuda.synchronize()
     assert float(nv.item()) == mask.sum()
@@ -226,7 +239,7 @@ def test_critic_and_disc_heads_and_grad_penalty():
     dH, dw, db = T(H), T(w), T(b)
     # critic (ppo_agent.py:209-219)
     dZ, dv, st = torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda"), torch.zeros(8, device="cuda")
-    L.call("addhip_critic_head", L.ptr(dH), K, K, M, L.ptr(dw), L.ptr(db), L.ptr(T(tar)), 1.0, L.ptr(dZ), L.ptr(dv), L.ptr(st), L.current_stream())
+    L.call("addhip_critic_head", L.ptr(dH), K, K, M, L.ptr(dw), L.ptr(db), P(T(tar)), 1.0, L.ptr(dZ), L.ptr(dv), L.ptr(st), L.current_stream())
     Ht = torch.tensor(H[:M], requires_grad=True)
     wt, bt = torch.tensor(w, requires_grad=True), torch.tensor(b, requires_grad=True)
     v = Ht @ wt + bt
@@ -265,7 +278,7 @@ def test_critic_and_disc_heads_and_grad_penalty():
     gp = torch.mean((n - 1) ** 2)
     (20.0 * 0.5 * gp).backward()
     G, st3 = torch.ones(M, 116, device="cuda"), torch.zeros(8, device="cuda")
-    L.call("addhip_grad_penalty", L.ptr(T(g)), 116, 114, M, 10.0, L.ptr(G), L.ptr(st3), L.current_stream())
+    L.call("addhip_grad_penalty", P(T(g)), 116, 114, M, 10.0, L.ptr(G), L.ptr(st3), L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(st3.cpu().numpy()[0] / M, gp.item(), rtol=1e-5)
     np.testing.assert_allclose(G.cpu().numpy()[:, :114], gt.grad.numpy(), rtol=1e-4, atol=1e-8)
@@ -286,7 +299,7 @@ def test_adamw_matches_torch():
         g = (rng.standard_normal(n) * (10.0 ** rng.randint(-4, 2, n))).astype(F)
         p.grad = torch.tensor(g)
         opt.step()
-        L.call("addhip_adamw", L.ptr(dp), L.ptr(T(g)), L.ptr(m), L.ptr(v), n, 1e-4, 0.9, 0.999, 1e-8, 0.0, step, L.current_stream())
+        L.call("addhip_adamw", L.ptr(dp), P(T(g)), L.ptr(m), L.ptr(v), n, 1e-4, 0.9, 0.999, 1e-8, 0.0, step, L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(dp.cpu().numpy(), p.detach().numpy(), rtol=1e-6, atol=1e-8)
 
@@ -308,7 +321,7 @@ def test_philox_fills_and_return_tracker():
     ep[1] = [6.0, 30.0, 3.0]
     ep[3] = [2.0, 8.0, 1.0]
     state = T(np.asarray([2.0, 1.5, 12.0], F))
-    L.call("addhip_return_tracker_fold", L.ptr(T(ep)), 5, L.ptr(state), L.current_stream())
+    L.call("addhip_return_tracker_fold", P(T(ep)), 5, L.ptr(state), L.current_stream())
     torch.cuda.synchronize()
     m1 = (3 / 5) * 2.0 + (2 / 5) * 1.5
     m2 = (1 / 6) * 2.0 + (5 / 6) * m1
