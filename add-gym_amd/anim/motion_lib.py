@@ -31,6 +31,12 @@ class MotionLib:
         self._device, self._kin, self._dt = device, kin_char_model, dt
         self._dt_inv = round(1 / dt)  # motion_lib.py:23
         self.reference_compat = bool(reference_compat)
+        if frames_list is None and str(motion_file).startswith("synthetic:"):
+            from .synth import parse_synthetic, synth_clip
+
+            clips, nframes = parse_synthetic(motion_file)
+            frames_list = [synth_clip(kin_char_model, list(motion_order), c, nframes) for c in range(clips)]
+            weights = [1.0] * clips
         if frames_list is None:
             files, weights = self._fetch_motion_files(motion_file)
             frames_list = [motion_io.load_motion(f).frames for f in files]

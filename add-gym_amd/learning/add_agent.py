@@ -1,0 +1,649 @@
+"""ADDAgent: rollout + PPO/ADD update loop on one MI355X, same surface as the reference's
+add_gym.learning.add.add_agent.ADDAgent (constructed from the Hydra tree, .train_model / .test_model
+/ .save / .load; main.py:73-112), with every per-step and per-minibatch computation running in
+libaddhip (HIP) on device-resident buffers.  No host synchronisation inside an iteration except one
+read of the logged scalars at its end.
+
+Restates (host orchestration only): BaseAgent.train_model/_train_iter/_rollout_train
+(base_agent.py:79-114, 353-391), PPOAgent._build_train_data/_update_model (ppo_agent.py:111-192),
+ADDAgent._build_train_data/_compute_disc_loss/_step_env/_reset_envs (add_agent.py:110-233).
+"""
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..anim.motion_lib import MotionLib
+from ..envs.env import ImitationEnvironment
+from ..hotpath import gemm, make_task
+from ..util.logger import Logger
+from .model import Model, NetRunner, Plan
+
+
+class AgentMode:
+    TRAIN, TEST = 0, 1
+
+
+class ADDAgent:
+    NAME = "ADD"
+
+    def __init__(self, env_config, distributed=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ADDAgent needs a GPU: the hot path is HIP-only (no CPU fallback)")
+        L.load()
+        self._device = torch.device("cuda:0")  # device masking: the rank's GPU is logical device 0 (main.py:143-158)
+        dev = self._device
+        self._cfg = env_config
+        cfg = self._config = env_config["agent"]
+        task = self._task_cfg = env_config["task"]
+        self._distributed = bool(distributed) and torch.distributed.is_available() and torch.distributed.is_initialized()
+        self._world = torch.distributed.get_world_size() if self._distributed else 1
+        self._rank = torch.distributed.get_rank() if self._distributed else 0
+        self._seed = int(env_config.get("seed", 0)) * 1000003 + self._rank
+
+        self._env = ImitationEnvironment(env_config, dev)
+        env = self._env
+        self.N = N = env.num_envs
+        self._load_params(cfg)
+        self.T = T = self._steps_per_iter
+
+        # ---- motion library + sampler (add_motion.py:14-33)
+        kin = env.robot._kin_char_model
+        self._motion_lib = MotionLib(task["motion_file"], list(task["motion_joint_order"]), kin, env.ctrl_dt, dev,
+                                     reference_compat=task.get("reference_compat", True))
+        lib = self._motion_lib
+        self._task = make_task(task, env.ctrl_dt, max_episode_length=lib.get_total_length())
+        tk = self._task
+        scfg = task.get("sampler", {}) or {}
+        self._num_segments = int(scfg.get("num_segments", 20))
+        C = lib.get_num_motions()
+        self._num_clips = C
+        seg = (lib.get_motion_lengths() / self._num_segments).to(dev)  # sampler.py:13-15
+        cdf = torch.cumsum(lib.get_motion_weights(), 0).to(dev)
+        self._smp = dict(errors=torch.ones(C, self._num_segments, device=dev), seg=seg, cdf=cdf,
+                         bits=torch.zeros(1, dtype=torch.int32, device=dev), esum=torch.zeros(C * self._num_segments, device=dev),
+                         ecnt=torch.zeros(C * self._num_segments, device=dev))
+        temp = scfg.get("temperature", None)
+        self._smp_c = L.SamplerT(L.ptr(self._smp["errors"]), L.ptr(seg), L.ptr(cdf), self._num_segments, -1.0 if temp is None else float(temp),
+                                 float((task.get("num_disc_obs_steps", 1) - 1) * env.ctrl_dt), int(bool(task.get("rand_reset", True))),
+                                 L.ptr(self._smp["bits"]), L.ptr(self._smp["esum"]), L.ptr(self._smp["ecnt"]))
+
+        # ---- per-env state
+        OS, DS = tk.obs_stride, tk.disc_stride
+        self._obs_dim, self._disc_dim = tk.obs_dim, tk.disc_dim
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        ent = env.robot.entity
+        self._fast_engine = hasattr(ent, "hot_state")
+        if self._fast_engine:
+            sim_pose, sim_vel, contact = ent.hot_state()
+        else:
+            sim_pose, sim_vel, contact = z(N, L.POSE_W), z(N, L.POSE_W), z(N, dt=torch.uint8)
+        if not self._fast_engine:  # contact predicate inputs (add_done.py:36-57)
+            names = list(task.get("contact_bodies", []))
+            allowed = [ent.get_link(name=nm).idx for nm in names]
+            self._noncontact_ids = torch.tensor([l.idx for l in ent.links if l.idx not in allowed], dtype=torch.long, device=dev)
+        self._S = S = dict(sim_pose=sim_pose, sim_vel=sim_vel, contact=contact, time=env.time_buf, time_off=z(N), motion_id=z(N, dt=torch.int32),
+                           hist=z(N, L.HIST, L.POSE_W), done=z(N, dt=torch.int32), ref_pose=z(N, L.POSE_W), ref_vel=z(N, L.POSE_W),
+                           ret_acc=z(N), len_acc=z(N, dt=torch.int32), ret_acc_test=z(N), len_acc_test=z(N, dt=torch.int32))
+        self._env_c = L.EnvT(N, *[L.ptr(S[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "done", "contact",
+                                                         "ref_pose", "ref_vel", "ret_acc", "len_acc")])
+        self._env_c_test = L.EnvT(N, *[L.ptr(S[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "done", "contact",
+                                                              "ref_pose", "ref_vel", "ret_acc_test", "len_acc_test")])
+        self._head = 0  # ring slot that receives the next state (circular_buffer.py:8)
+
+        # ---- experience buffer (experience_buffer.py; 13 buffers of base/ppo/amp/add agents), obs has T+1 slots
+        self._B = B = dict(obs=z(T + 1, N, OS), next_obs=z(T, N, OS), action=z(T + 1, N, 32), a_logp=z(T + 1, N), rand_mask=z(T + 1, N), reward=z(T, N),
+                           done=z(T, N, dt=torch.int32), disc_obs=z(T + 1, N, DS), disc_demo=z(T + 1, N, DS), motion_id=z(T, N, dt=torch.int32),
+                           motion_time=z(T, N), tar_val=z(T, N), adv=z(T, N), next_vals=z(T, N), vals=z(T, N), ep_stats=z(T, 3))
+        self._total_samples = 0
+        self._sample_count = 0
+        self._iter = 0
+
+        # ---- normalisers (base_agent.py:226-252, add_agent.py:84-91)
+        lo, hi = kin.action_bounds()
+        a_mean, a_std = 0.5 * (hi + lo), 0.5 * (hi - lo)
+        self._a_low, self._a_high = lo, hi
+        self._Nrm = dict(obs_mean=z(OS), obs_std=torch.ones(OS, device=dev), obs_msq=z(OS), obs_cnt=z(1, dt=torch.int64), obs_sum=z(OS), obs_sumsq=z(OS),
+                         a_mean=torch.cat([a_mean, torch.zeros(3)]).to(dev), a_std=torch.cat([a_std, torch.ones(3)]).to(dev),
+                         a_cnt=z(1, dt=torch.int64), d_abs=torch.ones(DS, device=dev), d_cnt=z(1, dt=torch.int64), d_sum=z(DS))
+        self._obs_norm_first = True
+
+        # ---- model + optimiser state (mp_optimizer.py:25-40)
+        self._model = Model(cfg["model"], tk.obs_dim, OS, tk.disc_dim, DS, dev, seed=self._seed)
+        opt = cfg["optimizer"]
+        if opt["type"] != "Adam":
+            raise NotImplementedError("optimizer.type must be 'Adam' (-> AdamW like the reference's MPOptimizer)")
+        self._lr = float(opt["learning_rate"])
+        self._wd = float(opt.get("weight_decay", 0.0))
+        if float(opt.get("grad_clip", 0.0)) > 0:
+            raise NotImplementedError("optimizer.grad_clip > 0 is not implemented (the reference's default config never enables it)")
+        if self._distributed:  # DDP ctor behaviour: every rank starts from rank 0's weights (base_agent.py:50-57)
+            torch.distributed.broadcast(self._model.params, 0)
+
+        self._build_workspace()
+        self._build_plans()
+        self._mode = AgentMode.TRAIN
+        self._is_restored = False
+        self._logger = None
+        self._test_state = z(3)
+        self._train_state = z(3)
+        self._timers = {}
+        # optional externally supplied random draws (parity tests replay the reference's draws through these):
+        #   {"noise": [T][N,29], "uniforms": {tag: [3,N]}, "perms": iterator of int64 permutations, "pre_step": fn(t)}
+        self.inject = None
+
+    # ------------------------------------------------------------------ config (base/ppo/amp agents' _load_params)
+    def _load_params(self, c):
+        self._discount = float(c["discount"])
+        self._iters_per_output = int(c["iters_per_output"])
+        self._normalizer_samples = c.get("normalizer_samples", math.inf)
+        self._test_episodes = int(c["test_episodes"])
+        self._steps_per_iter = int(c["steps_per_iter"])
+        self._update_epochs = int(c["update_epochs"])
+        self._batch_size = int(c["batch_size"])
+        self._td_lambda = float(c["td_lambda"])
+        self._ppo_clip_ratio = float(c["ppo_clip_ratio"])
+        self._norm_adv_clip = float(c["norm_adv_clip"])
+        self._action_bound_weight = float(c["action_bound_weight"])
+        if float(c["action_entropy_weight"]) != 0 or float(c["action_reg_weight"]) != 0:
+            raise NotImplementedError("action_entropy_weight / action_reg_weight != 0 are not implemented (add_g1.yaml sets both to 0)")
+        self._critic_loss_weight = float(c["critic_loss_weight"])
+        if float(c.get("exp_prob_beg", 1.0)) != 1.0 or float(c.get("exp_prob_end", 1.0)) != 1.0:
+            raise NotImplementedError("exploration-probability annealing is not implemented (defaults: always explore)")
+        self._disc_loss_weight = float(c["disc_loss_weight"])
+        self._disc_logit_reg = float(c["disc_logit_reg"])
+        self._disc_grad_penalty = float(c["disc_grad_penalty"])
+        self._disc_weight_decay = float(c["disc_weight_decay"])
+        self._disc_reward_scale = float(c["disc_reward_scale"])
+        self._task_reward_weight = float(c["task_reward_weight"])
+        self._disc_reward_weight = float(c["disc_reward_weight"])
+        self._max_samples = c.get("max_samples", int(1e6))
+
+    # ------------------------------------------------------------------ workspace + plans
+    def _build_workspace(self):
+        dev, N, T, m = self._device, self.N, self.T, self._model
+        self.Mb = Mb = self._batch_size * N  # ppo_agent.py:176
+        self._eval_rows = min(T * N, 65536)
+        rows = max(N, Mb + 1, self._eval_rows)
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        from .model import split_k_for
+
+        need = 32 * 32 * m.actor.hidden[-1]  # actor-head weight-gradient slabs
+        for net in m.nets:
+            for i, h in enumerate(net.hidden):
+                in_ld = net.in_ld if i == 0 else net.hidden[i - 1]
+                need = max(need, 2 * split_k_for(h, in_ld, Mb + 1) * h * in_ld)  # x2: gradient-penalty product shares the reduce
+        self._slabs = z(need)
+        self._run_actor = NetRunner(m, m.actor, rows, dev, self._slabs)
+        self._run_critic = NetRunner(m, m.critic, rows, dev, self._slabs)
+        self._run_disc = NetRunner(m, m.disc, rows, dev, self._slabs)
+        OS, DS = self._task.obs_stride, self._task.disc_stride
+        hd = m.disc.hidden
+        self._W = dict(mean=z(rows, 32), d_mean=z(rows, 32), noise=z(N, L.NUM_DOF), u=z(3, N), logits=z(rows), nv=z(1),
+                       norm_obs=z(Mb, OS), norm_act=z(Mb, 32), mb_logp=z(Mb), mb_adv=z(Mb), mb_tar=z(Mb), mb_mask=z(Mb), norm_diff=z(rows + 1, DS),
+                       dv=z(Mb), dlogit=z(Mb + 1), a2=z(Mb, hd[-1]), a1=z(Mb, hd[0]), g=z(Mb, DS), G=z(Mb, DS), e1=z(Mb, hd[0]), da2=z(Mb, hd[-1]),
+                       stats=z(32), scratch=z(4096, dt=torch.float64), adv_stats=z(2), rstats=z(2), perm_idx=z(Mb, dt=torch.int64))
+
+    def _gemm(self, plan, *a, **k):
+        g = gemm(*a, **k)
+        plan.hold(g)
+        plan.add("addhip_gemm_f32", g)
+
+    def _build_plans(self):
+        m, W, B, S, Nm, tk = self._model, self._W, self._B, self._S, self._Nrm, self._task
+        N, T, Mb = self.N, self.T, self.Mb
+        OS, DS = tk.obs_stride, tk.disc_stride
+        ra, rc, rd = self._run_actor, self._run_critic, self._run_disc
+        hA, hC, hD = m.actor.hidden[-1], m.critic.hidden[-1], m.disc.hidden[-1]
+
+        # ---- rollout step t: decide action (ppo_agent.py:72-109) -> engine -> env step (add_agent.py:204-219) -> reset
+        self._act_plans, self._step_out, self._reset_args = [], [], []
+        for t in range(T + 1):
+            p = Plan()
+            ra.forward(p, L.ptr(B["obs"][t]), N, a_mean=L.ptr(Nm["obs_mean"]), a_std=L.ptr(Nm["obs_std"]))
+            self._gemm(p, N, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
+            self._act_plans.append(p)
+        for t in range(T):
+            self._step_out.append(L.StepOutT(L.ptr(B["next_obs"][t]), L.ptr(B["obs"][t + 1]), L.ptr(B["disc_obs"][t]), L.ptr(B["disc_demo"][t]),
+                                             L.ptr(B["reward"][t]), L.ptr(B["done"][t]), L.ptr(B["motion_id"][t]), L.ptr(B["motion_time"][t]),
+                                             L.ptr(B["ep_stats"][t])))
+
+        # ---- update step on one gathered minibatch (ppo_agent.py:194-275, add_agent.py:141-202)
+        p = self._update_plan = Plan()
+        ls_d = self._disc_loss_weight
+        # actor
+        ra.forward(p, L.ptr(W["norm_obs"]), Mb)
+        self._gemm(p, Mb, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
+        p.add("addhip_count_mask", L.ptr(W["mb_mask"]), Mb, L.ptr(W["nv"]))
+        p.add("addhip_actor_loss", L.ptr(W["mean"]), L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_mask"]), Mb, m.std32,
+              m.logp_const, self._ppo_clip_ratio, self._action_bound_weight, 1.0, L.ptr(W["nv"]), L.ptr(W["d_mean"]), L.ptr(W["stats"]))
+        sA = 32
+        self._gemm(p, 32, hA, Mb, L.ptr(W["d_mean"]), 32, 0, L.ptr(ra.h[-1]), hA, 0, L.ptr(self._slabs), hA, split_k=sA)
+        p.add("addhip_slab_reduce", L.ptr(self._slabs), sA, 32 * hA, m.g("actor", "Wh"), 32 * hA, 1.0, 0)
+        p.add("addhip_col_sum", L.ptr(W["d_mean"]), Mb, 32, 32, m.g("actor", "bh"), 1.0, 0)
+        self._gemm(p, Mb, hA, 32, L.ptr(W["d_mean"]), 32, 1, m.p("actor", "Wh"), hA, 0, L.ptr(ra.dz[-1]), hA, L.EPI_MASK, mask=L.ptr(ra.h[-1]), ldmask=hA)
+        ra.backward(p, L.ptr(W["norm_obs"]), Mb)
+        # critic
+        rc.forward(p, L.ptr(W["norm_obs"]), Mb)
+        p.add("addhip_critic_head", L.ptr(rc.h[-1]), hC, hC, Mb, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(W["mb_tar"]), self._critic_loss_weight,
+              L.ptr(rc.dz[-1]), L.ptr(W["dv"]), L.ptr(W["stats"]) + 4 * 8)
+        p.add("addhip_weighted_col_sum", L.ptr(W["dv"]), L.ptr(rc.h[-1]), hC, hC, Mb, m.g("critic", "Wh"), 1.0, 0)
+        p.add("addhip_col_sum", L.ptr(W["dv"]), Mb, 1, 1, m.g("critic", "bh"), 1.0, 0)
+        rc.backward(p, L.ptr(W["norm_obs"]), Mb)
+        # discriminator: Mb agent/demo differences + one zero-difference row (row Mb of norm_diff stays 0)
+        Md = Mb + 1
+        nd = L.ptr(W["norm_diff"])
+        rd.forward(p, nd, Md)
+        p.add("addhip_disc_head", L.ptr(rd.h[-1]), hD, hD, Mb, L.ptr(rd.h[-1]) + 4 * Mb * hD, m.p("disc", "Wh"), m.p("disc", "bh"), ls_d,
+              L.ptr(W["dlogit"]), L.ptr(W["dlogit"]) + 4 * Mb, L.ptr(W["stats"]) + 4 * 12)
+        p.add("addhip_outer_mask", L.ptr(W["dlogit"]), m.p("disc", "Wh"), L.ptr(rd.h[-1]), hD, hD, Md, L.ptr(rd.dz[-1]))
+        p.add("addhip_weighted_col_sum", L.ptr(W["dlogit"]), L.ptr(rd.h[-1]), hD, hD, Md, m.g("disc", "Wh"), 1.0, 0)
+        p.add("addhip_col_sum", L.ptr(W["dlogit"]), Md, 1, 1, m.g("disc", "bh"), 1.0, 0)
+        # gradient penalty chain (hand-derived double backward, add_agent.py:166-178): g = ((w3*m2) W2 * m1) W1
+        h1, h2 = rd.h[0], rd.h[1] if len(rd.h) > 1 else None
+        if len(m.disc.hidden) != 2:
+            raise NotImplementedError("the gradient-penalty chain is written for the 2-hidden-layer discriminator (fc_2layers_*)")
+        d1, d2 = m.disc.hidden
+        p.add("addhip_bcast_mask", m.p("disc", "Wh"), L.ptr(h2), d2, d2, Mb, L.ptr(W["a2"]))
+        self._gemm(p, Mb, d1, d2, L.ptr(W["a2"]), d2, 1, m.p("disc", "W1"), d1, 0, L.ptr(W["a1"]), d1, L.EPI_MASK, mask=L.ptr(h1), ldmask=d1)
+        self._gemm(p, Mb, DS, d1, L.ptr(W["a1"]), d1, 1, m.p("disc", "W0"), DS, 0, L.ptr(W["g"]), DS)
+        p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, L.ptr(W["G"]), L.ptr(W["stats"]) + 4 * 20)
+        # second-order terms: da1 = G W1^T ; e1 = da1 * m1 ; da2 = (e1 W2^T) * m2
+        self._gemm(p, Mb, d1, DS, L.ptr(W["G"]), DS, 1, m.p("disc", "W0"), DS, 1, L.ptr(W["e1"]), d1, L.EPI_MASK, mask=L.ptr(h1), ldmask=d1)
+        self._gemm(p, Mb, d2, d1, L.ptr(W["e1"]), d1, 1, m.p("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, mask=L.ptr(h2), ldmask=d2)
+        p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
+        rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1"]), d1, L.ptr(W["G"]), DS, Mb), 1: (L.ptr(W["a2"]), d2, L.ptr(W["e1"]), d1, Mb)})
+        # L2 terms (add_agent.py:161-164, 181-186): logit reg on the head weights, weight decay on all disc weights
+        wd = self._disc_weight_decay
+        p.add("addhip_l2_grad", m.p("disc", "W0"), m.g("disc", "W0"), m.n_elem("disc", "W0"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
+        p.add("addhip_l2_grad", m.p("disc", "W1"), m.g("disc", "W1"), m.n_elem("disc", "W1"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
+        p.add("addhip_l2_grad", m.p("disc", "Wh"), m.g("disc", "Wh"), m.n_elem("disc", "Wh"), 2.0 * ls_d * (wd + self._disc_logit_reg), L.ptr(W["stats"]) + 4 * 25)
+
+        self._gather_c = L.GatherT(L.ptr(W["perm_idx"]), Mb, L.ptr(B["obs"]), OS, tk.obs_dim, L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(B["action"]),
+                                   L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), L.ptr(B["a_logp"]), L.ptr(B["adv"]), L.ptr(B["tar_val"]), L.ptr(B["rand_mask"]),
+                                   L.ptr(B["disc_obs"]), L.ptr(B["disc_demo"]), DS, tk.disc_dim, L.ptr(Nm["d_abs"]), 1e-4, L.ptr(W["norm_obs"]),
+                                   L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_tar"]), L.ptr(W["mb_mask"]), L.ptr(W["norm_diff"]))
+
+    # ------------------------------------------------------------------ public surface
+    def get_num_envs(self):
+        return self.N
+
+    def calc_num_params(self):
+        return self._model.num_params()
+
+    def set_mode(self, mode):
+        assert mode in (AgentMode.TRAIN, AgentMode.TEST)
+        self._mode = mode
+
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    # ------------------------------------------------------------------ env reset / step
+    def _draw_uniforms(self, tag):
+        if self.inject is not None and "uniforms" in self.inject:
+            self._W["u"].copy_(self.inject["uniforms"][tag])
+            return
+        L.call("addhip_fill_uniform", L.ptr(self._W["u"]), 3 * self.N, self._seed, (2 << 40) + tag, self._stream())
+
+    def _sync_foreign_engine_in(self):
+        """Slow path for engines without hot_state(): gather the BaseEntity getters into the packed rows."""
+        r, S = self._env.robot, self._S
+        S["sim_pose"].copy_(torch.cat([r.base_pos, r.base_quat, r.dof_pos], dim=-1))
+        S["sim_vel"][:, :35].copy_(torch.cat([r.base_lin_vel, r.base_ang_vel, r.dof_vel], dim=-1))
+        if hasattr(self, "_noncontact_ids"):
+            S["contact"].copy_(r.get_ground_contact_forces_v2(self._env.plane, self._noncontact_ids).to(torch.uint8))
+
+    def _sync_foreign_engine_out(self, reset_mask):
+        ids = reset_mask.nonzero(as_tuple=False).flatten()
+        if len(ids) > 0:
+            ent = self._env.robot.entity
+            ent.set_qpos(self._S["sim_pose"][ids], envs_idx=ids)            # add_observation.py:314-322
+            ent.set_dofs_velocity(self._S["sim_vel"][ids, :35], envs_idx=ids)  # :323-331
+
+    def _reset_envs(self, reset_all, obs_slot, disc_slot, demo_slot, tag):
+        """ADDAgent._reset_envs (add_agent.py:221-233), masked on device (no host nonzero)."""
+        S = self._S
+        mask = None
+        if not self._fast_engine:
+            mask = torch.ones(self.N, dtype=torch.bool, device=self._device) if reset_all else (S["done"] != 0)
+        self._draw_uniforms(tag)
+        u = self._W["u"]
+        L.call("addhip_env_reset", self._motion_lib.c_struct, self._task, self._env_c, self._smp_c, L.ptr(u[0]), L.ptr(u[1]), L.ptr(u[2]),
+               L.ptr(obs_slot), L.ptr(disc_slot), L.ptr(demo_slot), int(reset_all), self._head, self._stream())
+        if not self._fast_engine:
+            self._sync_foreign_engine_out(mask)
+
+    def _decide_action(self, t, slot_t, deterministic):
+        """PPOAgent._decide_action (ppo_agent.py:72-104) + record (ppo_agent.py:106-109)."""
+        B, W, Nm, m = self._B, self._W, self._Nrm, self._model
+        st = self._stream()
+        self._act_plans[slot_t].run(st)
+        if not deterministic and self.inject is not None and "noise" in self.inject:
+            W["noise"].copy_(self.inject["noise"][t])
+        elif not deterministic:
+            L.call("addhip_fill_normal", L.ptr(W["noise"]), self.N * L.NUM_DOF, self._seed, (1 << 40) + self._iter * self.T + t, st)
+        L.call("addhip_actor_sample", L.ptr(W["mean"]), 32, L.ptr(W["noise"]), m.std32, m.logp_const, L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), self.N,
+               int(deterministic), L.ptr(B["action"][slot_t]), L.ptr(B["a_logp"][slot_t]), L.ptr(B["rand_mask"][slot_t]), st)
+
+    def _step_env(self, slot_t, out_c, env_c):
+        """Environment.step (env.py:150-155) then the fused HIP env step."""
+        env = self._env
+        env.robot.apply_action(self._B["action"][slot_t])
+        env.scene.step()
+        if not self._fast_engine:
+            self._sync_foreign_engine_in()
+        L.call("addhip_env_step", self._motion_lib.c_struct, self._task, env_c, out_c, self._head, self._stream())
+        self._head = (self._head + 1) % L.HIST
+
+    # ------------------------------------------------------------------ training loop
+    def _rollout_train(self):
+        B, T = self._B, self.T
+        B["ep_stats"].zero_()
+        for t in range(T):
+            self._decide_action(t, t, False)
+            if self.inject is not None and "pre_step" in self.inject:
+                self.inject["pre_step"](t)
+            self._step_env(t, self._step_out[t], self._env_c)
+            # obs slot t+1 already holds the post-step obs; reset envs overwrite theirs (base_agent.py:449-453)
+            self._reset_envs(False, B["obs"][t + 1], B["disc_obs"][t + 1], B["disc_demo"][t + 1], (self._iter * T + t) * 2 + 1)
+        self._total_samples += T * self.N
+
+    def _forward_rows(self, runner, src, rows, normalize):
+        p = Plan()
+        Nm = self._Nrm
+        runner.forward(p, src, rows, a_mean=L.ptr(Nm["obs_mean"]) if normalize else None, a_std=L.ptr(Nm["obs_std"]) if normalize else None)
+        p.run(self._stream())
+
+    def _build_train_data(self):
+        """add_agent.py:110-139 then ppo_agent.py:111-159."""
+        B, W, Nm, m, tk = self._B, self._W, self._Nrm, self._model, self._task
+        T, N = self.T, self.N
+        rows_total = T * N
+        st = self._stream()
+        W["rstats"].zero_()
+        chunk = self._eval_rows
+        hD, hC = m.disc.hidden[-1], m.critic.hidden[-1]
+        record = self._need_normalizer_update()
+        for r0 in range(0, rows_total, chunk):
+            rows = min(chunk, rows_total - r0)
+            do = L.ptr(B["disc_obs"]) + 4 * r0 * tk.disc_stride
+            dd = L.ptr(B["disc_demo"]) + 4 * r0 * tk.disc_stride
+            L.call("addhip_disc_prep", do, dd, tk.disc_stride, tk.disc_dim, rows, L.ptr(Nm["d_abs"]), 1e-4, L.ptr(W["norm_diff"]),
+                   L.ptr(B["motion_id"]) + 4 * r0, L.ptr(B["motion_time"]) + 4 * r0, self._smp_c, self._num_clips,
+                   L.ptr(Nm["d_sum"]) if record else None, st)
+            self._forward_rows(self._run_disc, L.ptr(W["norm_diff"]), rows, False)
+            L.call("addhip_head_gemv", L.ptr(self._run_disc.h[-1]), hD, hD, rows, m.p("disc", "Wh"), m.p("disc", "bh"), L.ptr(W["logits"]), st)
+            L.call("addhip_disc_reward", L.ptr(W["logits"]), L.ptr(B["reward"]) + 4 * r0, rows, self._disc_reward_scale, self._task_reward_weight,
+                   self._disc_reward_weight, L.ptr(W["rstats"]), st)
+            for src, dst in ((B["next_obs"], B["next_vals"]), (B["obs"], B["vals"])):
+                self._forward_rows(self._run_critic, L.ptr(src) + 4 * r0 * tk.obs_stride, rows, True)
+                L.call("addhip_head_gemv", L.ptr(self._run_critic.h[-1]), hC, hC, rows, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(dst) + 4 * r0, st)
+        W["norm_diff"][:self.Mb + 1].zero_()  # row Mb must stay the zero-difference sample for the update plan
+        L.call("addhip_sampler_update", self._smp_c, self._num_clips, st)
+        succ = self._env.get_reward_succ() / (1.0 - self._discount)  # base_agent.py:472-480
+        fail = self._env.get_reward_fail() / (1.0 - self._discount)
+        L.call("addhip_td_lambda_adv", L.ptr(B["reward"]), L.ptr(B["next_vals"]), L.ptr(B["vals"]), L.ptr(B["done"]), L.ptr(B["rand_mask"]), T, N,
+               self._discount, self._td_lambda, succ, fail, self._norm_adv_clip, L.ptr(B["tar_val"]), L.ptr(B["adv"]), L.ptr(W["scratch"]),
+               L.ptr(W["adv_stats"]), st)
+
+    def _next_minibatch_indices(self):
+        """ExperienceBuffer._sample_rand_idx (experience_buffer.py:92-113): consecutive slices of a permutation of the
+        T*N samples, redrawn when exhausted; device-side randperm (torch RNG is plumbing here)."""
+        total, n = self.T * self.N, self.Mb
+        if self.inject is not None and "perms" in self.inject:
+            randperm = lambda: next(self.inject["perms"]).to(self._device)
+        else:
+            randperm = lambda: torch.randperm(total, device=self._device)
+        if not hasattr(self, "_perm") or self._perm is None:
+            self._perm, self._perm_head = randperm(), 0
+        if self._perm_head + n <= total:
+            idx = self._perm[self._perm_head:self._perm_head + n]
+            self._perm_head += n
+        else:
+            idx0 = self._perm[self._perm_head:]
+            rem = n - (total - self._perm_head)
+            self._perm = randperm()
+            idx = torch.cat([idx0, self._perm[:rem]])
+            self._perm_head = rem
+        sample_count = min(self._total_samples, total)
+        self._W["perm_idx"].copy_(torch.remainder(idx, sample_count))
+
+    def _update_model(self):
+        """ppo_agent.py:171-192."""
+        W, m = self._W, self._model
+        st = self._stream()
+        total = self.T * self.N
+        num_batches = int(np.ceil(float(min(self._total_samples, total)) / self.Mb))
+        W["stats"].zero_()
+        steps = 0
+        for _ in range(self._update_epochs):
+            for _ in range(num_batches):
+                self._next_minibatch_indices()
+                L.call("addhip_gather_minibatch", self._gather_c, st)
+                self._update_plan.run(st)
+                if self._world > 1:  # the exchange step: mean gradient over ranks (RCCL all-reduce over xGMI)
+                    torch.distributed.all_reduce(m.grads)
+                    m.grads.mul_(1.0 / self._world)
+                m.opt_step += 1
+                L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, self._lr, 0.9, 0.999, 1e-8,
+                       self._wd, m.opt_step, st)
+                steps += 1
+        return steps
+
+    def _need_normalizer_update(self):
+        return self._sample_count < self._normalizer_samples
+
+    def _update_normalizers(self):
+        """amp_agent.py:61-63 -> Normalizer.update (normalizer.py:37-80, all-reduced) + DiffNormalizer.update."""
+        B, Nm, tk, st = self._B, self._Nrm, self._task, self._stream()
+        rows = self.T * self.N
+        L.call("addhip_norm_accum", L.ptr(B["obs"]), rows, tk.obs_stride, tk.obs_stride, L.ptr(Nm["obs_sum"]), L.ptr(Nm["obs_sumsq"]), st)
+        count = rows
+        if self._world > 1:
+            torch.distributed.all_reduce(Nm["obs_sum"])
+            torch.distributed.all_reduce(Nm["obs_sumsq"])
+            count = rows * self._world
+        L.call("addhip_norm_merge", L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(Nm["obs_msq"]), L.ptr(Nm["obs_cnt"]), L.ptr(Nm["obs_sum"]),
+               L.ptr(Nm["obs_sumsq"]), count, tk.obs_stride, 1e-8, int(self._obs_norm_first), st)
+        self._obs_norm_first = False
+        # pad columns of the obs rows are identically 0 -> mean 0, var clamps to min_var; keep their std at 1
+        Nm["obs_std"][tk.obs_dim:] = 1.0
+        L.call("addhip_diffnorm_merge", L.ptr(Nm["d_abs"]), L.ptr(Nm["d_cnt"]), L.ptr(Nm["d_sum"]), rows, tk.disc_stride, st)
+
+    def _train_iter(self):
+        """base_agent.py:353-374.  Returns the info dict with the reference's keys."""
+        t0 = time.perf_counter()
+        B = self._B
+        # carry: the last obs of the previous iteration is the first of this one
+        if self._iter_started:
+            B["obs"][0].copy_(B["obs"][self.T])
+        self._iter_started = True
+        self._rollout_train()
+        self._build_train_data()
+        steps = self._update_model()
+        if self._need_normalizer_update():
+            self._update_normalizers()
+        L.call("addhip_return_tracker_fold", L.ptr(B["ep_stats"]), self.T, L.ptr(self._train_state), self._stream())
+        info = self._collect_info(steps)
+        self._timers["iter_s"] = time.perf_counter() - t0
+        return info
+
+    def _collect_info(self, steps):
+        """One device->host read per iteration: the 17 logged scalars (ppo_agent.py:190-192, add_agent.py:190-199)."""
+        W = self._W
+        s = W["stats"].double().cpu().numpy() / max(steps, 1)
+        adv = W["adv_stats"].cpu().numpy()
+        rs = W["rstats"].double().cpu().numpy()
+        trk = self._train_state.cpu().numpy()
+        Mb, M1 = float(self.Mb), float(self.Mb)
+        nvalid = Mb  # rand_action_mask is 1 everywhere (exp_prob = 1)
+        actor_min, clipf, ratio, bound = -s[0] / nvalid, s[1] / nvalid, s[2] / nvalid, s[3] / nvalid
+        actor_loss = actor_min + self._action_bound_weight * bound
+        critic_loss = s[8] / Mb
+        bce_neg, bce_pos = s[12] / M1, s[13]
+        gp = s[20] / Mb
+        w_all, w_logit = s[24] + s[25], s[25]
+        disc_loss = 0.5 * (bce_pos + bce_neg) + self._disc_logit_reg * w_logit + self._disc_grad_penalty * gp + self._disc_weight_decay * w_all
+        n = self.T * self.N
+        dr_mean = rs[0] / n
+        dr_std = math.sqrt(max(rs[1] - n * dr_mean * dr_mean, 0.0) / max(n - 1, 1))
+        info = {
+            "loss": actor_loss + self._critic_loss_weight * critic_loss + self._disc_loss_weight * disc_loss,
+            "critic_loss": critic_loss, "actor_loss": actor_loss, "clip_frac": clipf, "imp_ratio": ratio, "action_bound_loss": bound,
+            "disc_loss": disc_loss, "disc_grad_penalty": gp, "disc_logit_loss": w_logit, "disc_pos_acc": s[17], "disc_neg_acc": s[16] / M1,
+            "disc_pos_logit": s[15], "disc_neg_logit": s[14] / M1, "adv_mean": float(adv[0]), "adv_std": float(adv[1]),
+            "disc_reward_mean": dr_mean, "disc_reward_std": dr_std,
+            "mean_return": float(trk[1]), "mean_ep_len": float(trk[2]), "num_eps": int(trk[0]),
+        }
+        return info
+
+    def _init_train(self):
+        if not self._is_restored:
+            self._iter, self._sample_count = 0, 0
+        self._total_samples = 0
+        self._perm = None
+        self._iter_started = False
+        self._train_state.zero_()
+        self._S["ret_acc"].zero_()
+        self._S["len_acc"].zero_()
+
+    def reset_all_envs(self, tag=0):
+        B = self._B
+        self._reset_envs(True, B["obs"][0], B["disc_obs"][self.T], B["disc_demo"][self.T], tag)
+        self._iter_started = False
+
+    def train_model(self, out_model_file, int_output_dir, log_file):
+        """base_agent.py:79-114."""
+        start = time.time()
+        self.reset_all_envs()
+        self._logger = Logger(log_file if self._rank == 0 else None, world=self._world)
+        self._init_train()
+        test_info = {"mean_return": 0.0, "mean_ep_len": 0.0, "num_eps": 0}
+        while self._sample_count < self._max_samples:
+            output_iter = self._iter % self._iters_per_output == 0
+            if output_iter:
+                test_info = self.test_model(self._test_episodes)
+            train_info = self._train_iter()
+            self._sample_count = self._total_samples
+            if self._sample_count >= self._max_samples:
+                output_iter = True
+                test_info = self.test_model(self._test_episodes)
+            self._log_train_info(train_info, test_info, start)
+            self._logger.print_log()
+            if output_iter:
+                self._logger.write_log()
+                self._output_train_model(self._iter, out_model_file, int_output_dir)
+                self._train_state.zero_()
+                self._S["ret_acc"].zero_()
+                self._S["len_acc"].zero_()
+                self.reset_all_envs(tag=self._iter + 1)
+            self._iter += 1
+
+    def test_model(self, num_episodes):
+        """base_agent.py:116-126, 393-425: deterministic actions until every env has finished its quota of episodes.
+        (Host-synchronous by design: it is outside the throughput path.)"""
+        self.set_mode(AgentMode.TEST)
+        if int(num_episodes) == 0:
+            self.set_mode(AgentMode.TRAIN)
+            return {"mean_return": 0.0, "mean_ep_len": 0.0, "num_eps": 0}
+        B, S = self._B, self._S
+        self.reset_all_envs(tag=(7 << 20) + self._iter)
+        S["ret_acc_test"].zero_()
+        S["len_acc_test"].zero_()
+        self._test_state.zero_()
+        eps_per_env = torch.zeros(self.N, dtype=torch.long, device=self._device)
+        min_eps = int(np.ceil(num_episodes / self.N))
+        ep = torch.zeros(1, 3, device=self._device)
+        out = L.StepOutT(L.ptr(B["obs"][0]), None, L.ptr(B["disc_obs"][self.T]), L.ptr(B["disc_demo"][self.T]), None, None, None, None, L.ptr(ep))
+        k = 0
+        while True:
+            self._decide_action(0, 0, True)
+            ep.zero_()
+            self._step_env(0, out, self._env_c_test)
+            eps_per_env += (S["done"] != 0).long()
+            L.call("addhip_return_tracker_fold", L.ptr(ep), 1, L.ptr(self._test_state), self._stream())
+            self._reset_envs(False, B["obs"][0], B["disc_obs"][self.T], B["disc_demo"][self.T], (9 << 20) + k)
+            k += 1
+            if bool(torch.all(eps_per_env > min_eps - 1)):
+                break
+        st = self._test_state.cpu().numpy()
+        self.set_mode(AgentMode.TRAIN)
+        self._iter_started = False
+        return {"mean_return": float(st[1]), "mean_ep_len": float(st[2]), "num_eps": int(st[0])}
+
+    # ------------------------------------------------------------------ logging / checkpoints
+    def _log_train_info(self, train_info, test_info, start_time):
+        """base_agent.py:482-520 + ppo_agent.py:277-279: same keys, same order."""
+        lg = self._logger
+        ti = dict(train_info)
+        lg.log("Iteration", self._iter, collection="1_Info")
+        lg.log("Wall_Time", (time.time() - start_time) / 3600.0, collection="1_Info")
+        lg.log("Samples", self._sample_count, collection="1_Info")
+        lg.log("Test_Return", test_info["mean_return"], collection="0_Main")
+        lg.log("Test_Episode_Length", test_info["mean_ep_len"], collection="0_Main", quiet=True)
+        lg.log("Test_Episodes", test_info["num_eps"], collection="1_Info", quiet=True)
+        lg.log("Train_Return", ti.pop("mean_return"), collection="0_Main")
+        lg.log("Train_Episode_Length", ti.pop("mean_ep_len"), collection="0_Main", quiet=True)
+        lg.log("Train_Episodes", ti.pop("num_eps"), collection="1_Info", quiet=True)
+        for k, v in ti.items():
+            lg.log(k.title(), v)
+        lg.log("Exp_Prob", 1.0)
+
+    def state_dict(self):
+        Nm, tk = self._Nrm, self._task
+        sd = {"_obs_norm._count": Nm["obs_cnt"].cpu(), "_obs_norm._mean": Nm["obs_mean"][:tk.obs_dim].cpu(), "_obs_norm._std": Nm["obs_std"][:tk.obs_dim].cpu(),
+              "_a_norm._count": Nm["a_cnt"].cpu(), "_a_norm._mean": Nm["a_mean"][:L.NUM_DOF].cpu(), "_a_norm._std": Nm["a_std"][:L.NUM_DOF].cpu(),
+              "_disc_obs_norm._count": Nm["d_cnt"].cpu(), "_disc_obs_norm._mean_abs": Nm["d_abs"][:tk.disc_dim].cpu()}
+        sd.update(self._model.export())
+        return sd
+
+    def _optimizer_state_dict(self):
+        """torch.optim.AdamW.state_dict() layout over the 22 trainable tensors in registration order (mp_optimizer.py:48-52)."""
+        m = self._model
+        ea, es = m.export(m.exp_avg), m.export(m.exp_avg_sq)
+        keys = [k for k in ea if k != "_model._action_dist._logstd_net"]
+        state = {i: {"step": torch.tensor(float(m.opt_step)), "exp_avg": ea[k], "exp_avg_sq": es[k]} for i, k in enumerate(keys)} if m.opt_step > 0 else {}
+        group = dict(lr=self._lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=self._wd, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                     differentiable=False, fused=None, decoupled_weight_decay=True, params=list(range(len(keys))))
+        return {"state": state, "param_groups": [group]}
+
+    def save(self, out_file):
+        """base_agent.py:148-155: same dict layout and tensor names, so reference tooling (publish/push_to_hf.py) keeps working."""
+        torch.save({"model": self.state_dict(), "optimizer": self._optimizer_state_dict(), "iter": self._iter, "sample_count": self._sample_count}, out_file)
+
+    def load(self, in_file):
+        """base_agent.py:157-208: accepts a full checkpoint or a bare state dict, with or without the DDP `.module` prefix."""
+        ck = torch.load(in_file, map_location="cpu", weights_only=True)
+        self._is_restored = True
+        if "model" in ck and "optimizer" in ck:
+            sd, opt = ck["model"], ck["optimizer"]
+            self._iter, self._sample_count = int(ck.get("iter", 0)), int(ck.get("sample_count", 0))
+        else:
+            sd, opt, self._is_restored = ck, None, False
+        sd = {k.replace("_model.module.", "_model."): v for k, v in sd.items()}
+        Nm, tk, m = self._Nrm, self._task, self._model
+        m.load(sd)
+        Nm["obs_cnt"].copy_(sd["_obs_norm._count"])
+        Nm["obs_mean"][:tk.obs_dim] = sd["_obs_norm._mean"].to(self._device)
+        Nm["obs_std"][:tk.obs_dim] = sd["_obs_norm._std"].to(self._device)
+        self._obs_norm_first = True  # mean_sq is rebuilt lazily like normalizer.py:38-39
+        Nm["d_cnt"].copy_(sd["_disc_obs_norm._count"])
+        Nm["d_abs"][:tk.disc_dim] = sd["_disc_obs_norm._mean_abs"].to(self._device)
+        if opt is not None and opt.get("state"):
+            keys = [k for k in m.export() if k != "_model._action_dist._logstd_net"]
+            ea = {k: opt["state"][i]["exp_avg"] for i, k in enumerate(keys)}
+            es = {k: opt["state"][i]["exp_avg_sq"] for i, k in enumerate(keys)}
+            m.load(ea, m.exp_avg)
+            m.load(es, m.exp_avg_sq)
+            m.opt_step = int(float(opt["state"][0]["step"]))
+        Logger.print(f"Loaded model parameters from {in_file}")
+
+    def _output_train_model(self, it, out_model_file, int_output_dir):
+        if self._rank != 0:
+            return
+        self.save(out_model_file)
+        if int_output_dir != "":
+            self.save(os.path.join(int_output_dir, "model_{:010d}.pt".format(it)))

@@ -1,0 +1,238 @@
+"""Parameters of the actor / critic / discriminator MLPs in ONE flat fp32 device buffer
+(+ same-layout gradient and AdamW moment buffers), with the call plans that run their forward
+and backward passes through libaddhip (fp32 MFMA GEMMs + fused epilogues).
+
+Architecture = the reference's ADDModel for configs/agent/add_g1.yaml (ppo_model.py:36-59,
+add_model.py:29-46, nets/fc_3layers_1024units.py, nets/fc_2layers_1024units.py):
+  actor  obs -> 1024 -> 1024 -> 512 -> 29 (ReLU; fixed logstd)      critic obs -> 1024 -> 1024 -> 512 -> 1
+  disc   disc_obs -> 1024 -> 512 -> 1
+Device layout differences (all invisible in checkpoints): rows of the 29-wide actor head are padded
+to 32, the 114-wide discriminator input to 116 columns, 1-wide heads are stored as vectors.
+"""
+import math
+
+import torch
+
+from .. import _lib as L
+from ..hotpath import gemm
+
+NET_SIZES = {"fc_3layers_1024units": [1024, 1024, 512], "fc_2layers_1024units": [1024, 512],
+             "fc_2layers_512units": [512, 256], "fc_2layers_256units": [256, 128], "fc_2layers_128units": [128, 64],
+             "fc_2layers_64units": [64, 32]}  # nets/*.py layer_sizes
+
+
+def build_net_sizes(name):
+    """nets/net_builder.py:5-11: networks are chosen by module name."""
+    if name not in NET_SIZES:
+        raise ValueError(f"Unsupported net: {name}")
+    return NET_SIZES[name]
+
+
+class Mlp:
+    """One network: hidden Linear+ReLU stack and a linear head, as views into the flat buffers."""
+
+    def __init__(self, name, in_dim, in_ld, hidden, head_dim):
+        self.name, self.in_dim, self.in_ld, self.hidden, self.head_dim = name, in_dim, in_ld, list(hidden), head_dim
+        self.head_rows = 32 if head_dim > 1 else 1  # 29-wide head padded to 32 rows; 1-wide head = vector
+        self.specs = []  # (key, shape)
+        prev = in_ld
+        for i, h in enumerate(hidden):
+            self.specs += [(f"W{i}", (h, prev)), (f"b{i}", (h,))]
+            prev = h
+        self.specs += [("Wh", (self.head_rows, prev)), ("bh", (max(4, self.head_rows),))]
+
+
+class Model:
+    def __init__(self, model_cfg, obs_dim, obs_ld, disc_dim, disc_ld, device, seed=0):
+        self.device = device
+        self.actor = Mlp("actor", obs_dim, obs_ld, build_net_sizes(model_cfg["actor_net"]), L.NUM_DOF)
+        self.critic = Mlp("critic", obs_dim, obs_ld, build_net_sizes(model_cfg["critic_net"]), 1)
+        self.disc = Mlp("disc", disc_dim, disc_ld, build_net_sizes(model_cfg["disc_net"]), 1)
+        self.nets = [self.actor, self.critic, self.disc]
+        self.action_std = float(model_cfg["action_std"])
+        if model_cfg.get("actor_std_type", "FIXED") != "FIXED":
+            raise NotImplementedError("only actor_std_type FIXED (configs/agent/add_g1.yaml) is implemented")
+        self.init_output_scale = float(model_cfg["actor_init_output_scale"])
+        off = 0
+        self.offsets = {}
+        for net in self.nets:
+            for key, shape in net.specs:
+                n = math.prod(shape)
+                self.offsets[(net.name, key)] = (off, shape)
+                off += (n + 3) // 4 * 4
+        self.count = off
+        self.params = torch.zeros(off, device=device)
+        self.grads = torch.zeros(off, device=device)
+        self.exp_avg = torch.zeros(off, device=device)
+        self.exp_avg_sq = torch.zeros(off, device=device)
+        self.opt_step = 0
+        self._init_params(seed)
+        # distribution_gaussian_diag.py:24-31, 63-94: fp32 logstd vector -> std and the log-prob constant
+        logstd = torch.full((L.NUM_DOF,), float(math.log(self.action_std)), dtype=torch.float32)
+        self.std32 = float(torch.exp(logstd)[0].item())
+        self.logp_const = float((-0.5 * L.NUM_DOF * math.log(2.0 * math.pi) - torch.sum(logstd)).item())
+
+    # ---- views
+    def view(self, net, key, buf=None):
+        off, shape = self.offsets[(net, key)]
+        buf = self.params if buf is None else buf
+        return buf[off:off + math.prod(shape)].view(shape)
+
+    def p(self, net, key, buf=None):
+        off, _ = self.offsets[(net, key)]
+        base = (self.params if buf is None else buf).data_ptr()
+        return base + 4 * off
+
+    def g(self, net, key):
+        return self.p(net, key, self.grads)
+
+    def n_elem(self, net, key):
+        return math.prod(self.offsets[(net, key)][1])
+
+    # ---- init: nn.Linear default weights, zero biases, special heads
+    def _init_params(self, seed):
+        gen = torch.Generator().manual_seed(seed)
+
+        def uniform(shape, bound):
+            return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+
+        for net in self.nets:
+            for i, h in enumerate(net.hidden):
+                fan_in = net.in_dim if i == 0 else net.hidden[i - 1]
+                w = self.view(net.name, f"W{i}")
+                w.zero_()
+                w[:, :fan_in] = uniform((h, fan_in), 1.0 / math.sqrt(fan_in)).to(self.device)
+            fan_in = net.hidden[-1]
+            bound = {"actor": self.init_output_scale, "critic": 1.0 / math.sqrt(fan_in), "disc": 1.0}[net.name]
+            wh = self.view(net.name, "Wh")
+            wh.zero_()
+            wh[:net.head_dim] = uniform((net.head_dim, fan_in), bound).to(self.device)
+
+    # ---- reference checkpoint keys <-> flat buffers
+    def _key_map(self):
+        m = []
+        for net, prefix, head in ((self.actor, "_model._actor_layers", "_model._action_dist._mean_net"),
+                                  (self.critic, "_model._critic_layers", "_model._critic_out"),
+                                  (self.disc, "_model._disc_layers", "_model._disc_logits")):
+            for i in range(len(net.hidden)):
+                m.append((f"{prefix}.{2 * i}.weight", net, f"W{i}"))
+                m.append((f"{prefix}.{2 * i}.bias", net, f"b{i}"))
+            m.append((f"{head}.weight", net, "Wh"))
+            m.append((f"{head}.bias", net, "bh"))
+        return m
+
+    def _ref_shape(self, net, key):
+        if key.startswith("W") and key != "Wh":
+            i = int(key[1:])
+            return (net.hidden[i], net.in_dim if i == 0 else net.hidden[i - 1])
+        if key.startswith("b") and key != "bh":
+            return (net.hidden[int(key[1:])],)
+        return (net.head_dim, net.hidden[-1]) if key == "Wh" else (net.head_dim,)
+
+    def export(self, buf=None):
+        """{reference key: cpu tensor of the reference shape} from params (or another flat buffer)."""
+        out = {}
+        for name, net, key in self._key_map():
+            v = self.view(net.name, key, buf)
+            shape = self._ref_shape(net, key)
+            if v.dim() == 2:
+                v = v[:shape[0], :shape[1]]
+            else:
+                v = v[:shape[0]]
+            out[name] = v.detach().clone().cpu()
+        out["_model._action_dist._logstd_net"] = torch.full((L.NUM_DOF,), float(math.log(self.action_std)), dtype=torch.float32)
+        return out
+
+    def load(self, state, buf=None):
+        for name, net, key in self._key_map():
+            if name not in state:
+                raise KeyError(f"checkpoint is missing {name}")
+            src = state[name].to(torch.float32)
+            v = self.view(net.name, key, buf)
+            v.zero_()
+            if v.dim() == 2:
+                v[:src.shape[0], :src.shape[1]] = src.to(self.device)
+            else:
+                v[:src.shape[0]] = src.to(self.device)
+
+    def num_params(self):
+        return sum(math.prod(self._ref_shape(net, key)) for _, net, key in self._key_map())
+
+
+def split_k_for(out_dim, in_dim, rows):
+    tiles = ((out_dim + 127) // 128) * ((in_dim + 127) // 128)
+    s = max(1, min(32, -(-512 // tiles)))
+    while s > 1 and rows // s < 256:
+        s //= 2
+    return s
+
+
+class Plan:
+    """A recorded sequence of C-ABI calls (argument tuples are prebuilt once; replay costs one
+    ctypes call per kernel)."""
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []
+        self._lib = L.load()
+
+    def add(self, name, *args):
+        self.calls.append((name, getattr(self._lib, name), args))
+
+    def hold(self, *objs):
+        self.keep.extend(objs)
+
+    def run(self, stream):
+        for name, fn, args in self.calls:
+            rc = fn(*args, stream)
+            if rc != 0:
+                raise L.AddhipError(f"{name} failed ({rc}): {self._lib.addhip_last_error().decode()}")
+
+
+class NetRunner:
+    """Forward / backward call recording for one Mlp over `rows` rows with its own activation buffers."""
+
+    def __init__(self, model, net, rows, device, slabs):
+        self.m, self.net, self.rows, self.slabs = model, net, rows, slabs
+        self.h = [torch.zeros(rows, h, device=device) for h in net.hidden]
+        self.dz = [torch.zeros(rows, h, device=device) for h in net.hidden]
+
+    def forward(self, plan, x_ptr, rows, a_mean=None, a_std=None):
+        net, m = self.net, self.m
+        prev, ld, k = x_ptr, net.in_ld, net.in_ld
+        for i, h in enumerate(net.hidden):
+            g = gemm(rows, h, k, prev, ld, 1, m.p(net.name, f"W{i}"), k, 1, L.ptr(self.h[i]), h, L.EPI_BIAS_RELU, m.p(net.name, f"b{i}"),
+                     a_mean=a_mean if i == 0 else None, a_std=a_std if i == 0 else None)
+            plan.hold(g)
+            plan.add("addhip_gemm_f32", g)
+            prev, ld, k = L.ptr(self.h[i]), h, h
+
+    def backward(self, plan, x_ptr, rows, extra_dw=None):
+        """dz[-1] must hold d loss / d (pre-activation of the last hidden layer).  extra_dw: {layer: (A_ptr, lda, B_ptr, ldb)}
+        second product accumulated into dW of that layer (the gradient-penalty terms)."""
+        net, m = self.net, self.m
+        n = len(net.hidden)
+        for i in reversed(range(n)):
+            out_d = net.hidden[i]
+            in_ld = net.in_ld if i == 0 else net.hidden[i - 1]
+            inp = x_ptr if i == 0 else L.ptr(self.h[i - 1])
+            s = split_k_for(out_d, in_ld, rows)
+            slab = out_d * in_ld
+            g = gemm(out_d, in_ld, rows, L.ptr(self.dz[i]), out_d, 0, inp, in_ld, 0, L.ptr(self.slabs), in_ld, split_k=s)
+            plan.hold(g)
+            plan.add("addhip_gemm_f32", g)
+            total = s
+            if extra_dw and i in extra_dw:
+                a_ptr, lda, b_ptr, ldb, erows = extra_dw[i]
+                g2 = gemm(out_d, in_ld, erows, a_ptr, lda, 0, b_ptr, ldb, 0, L.ptr(self.slabs) + 4 * s * slab, in_ld, split_k=s)
+                plan.hold(g2)
+                plan.add("addhip_gemm_f32", g2)
+                total = 2 * s
+            plan.add("addhip_slab_reduce", L.ptr(self.slabs), total, slab, m.g(net.name, f"W{i}"), slab, 1.0, 0)
+            plan.add("addhip_col_sum", L.ptr(self.dz[i]), rows, out_d, out_d, m.g(net.name, f"b{i}"), 1.0, 0)
+            if i > 0:
+                prev_d = net.hidden[i - 1]
+                g3 = gemm(rows, prev_d, out_d, L.ptr(self.dz[i]), out_d, 1, m.p(net.name, f"W{i}"), prev_d, 0, L.ptr(self.dz[i - 1]), prev_d,
+                          L.EPI_MASK, mask=L.ptr(self.h[i - 1]), ldmask=prev_d)
+                plan.hold(g3)
+                plan.add("addhip_gemm_f32", g3)

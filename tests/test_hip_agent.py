@@ -1,0 +1,270 @@
+"""Agent-level GPU parity: one minibatch loss/gradient/AdamW step and one complete training iteration
+(rollout + build-train-data + update) of the HIP engine against the reference's golden vectors and the CPU oracle,
+with the reference's random draws replayed."""
+import numpy as np
+import pytest
+
+from oracle import learn as OL
+from tests.util import DEFAULT_TASK, gload, kin_meta
+from tests.test_oracle_vs_golden import _check_summary
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def make_cfg(num_envs, steps_per_iter=32, **agent_over):
+    import add_gym_amd  # noqa: F401
+    from add_gym_amd.config import load_config
+
+    cfg = load_config("train", [f"engine.num_envs={num_envs}", f"agent.steps_per_iter={steps_per_iter}"])
+    cfg["agent"].update(agent_over)
+    cfg["task"]["motion_joint_order"] = kin_meta()["motion_joint_order"]
+    return cfg
+
+
+def make_agent(cfg, frames_list, weights):
+    """ADDAgent on the golden clip frames (MotionLib accepts in-memory frames)."""
+    import add_gym_amd.learning.add_agent as A
+    from add_gym_amd.anim.motion_lib import MotionLib
+
+    orig = A.MotionLib
+
+    def lib(motion_file, order, kin, dt, dev, reference_compat=True):
+        return MotionLib(None, order, kin, dt, dev, reference_compat=reference_compat, frames_list=frames_list, weights=weights)
+
+    A.MotionLib = lib
+    try:
+        return A.ADDAgent(cfg)
+    finally:
+        A.MotionLib = orig
+
+
+def T(x, dtype=None):
+    import torch
+
+    return torch.tensor(np.ascontiguousarray(x), dtype=dtype, device="cuda")
+
+
+def test_minibatch_loss_gradients_and_adamw_match_reference():
+    import torch
+    import add_gym_amd._lib as L
+
+    g = gload("losses")
+    M = g["in.obs"].shape[0]
+    cfg = make_cfg(M // 4, steps_per_iter=8)
+    ag = make_agent(cfg, [gload("motion_small")["frames"]], [1.0])
+    assert ag.Mb == M
+    params = OL.synth_params(int(g["seed"]))
+    ag._model.load({k: torch.tensor(v) for k, v in params.items()})
+    on = OL.Normalizer(264, g["obs_mean"], g["obs_std"])
+    an = OL.Normalizer(29, g["a_mean"], g["a_std"])
+    dn = OL.DiffNormalizer(114)
+    dn.mean_abs = g["disc_mean_abs"]
+    mb = dict(norm_obs=on.normalize(g["in.obs"]), norm_action=an.normalize(g["in.action"]), a_logp=g["in.a_logp"], adv=g["in.adv"],
+              tar_val=g["in.tar_val"], rand_action_mask=g["in.rand_action_mask"], norm_diff=dn.normalize(g["in.disc_obs_demo"] - g["in.disc_obs"]))
+    W = ag._W
+    W["norm_obs"].copy_(T(mb["norm_obs"]))
+    W["norm_act"].zero_()
+    W["norm_act"][:, :29] = T(mb["norm_action"])
+    W["mb_logp"].copy_(T(mb["a_logp"]))
+    W["mb_adv"].copy_(T(mb["adv"]))
+    W["mb_tar"].copy_(T(mb["tar_val"]))
+    W["mb_mask"].copy_(T(mb["rand_action_mask"]))
+    W["norm_diff"].zero_()
+    W["norm_diff"][:M, :114] = T(mb["norm_diff"])
+    model = OL.Model(params)
+    opt = OL.AdamW(model, 1e-4)
+    st = L.current_stream()
+    m = ag._model
+    for step in range(3):
+        W["stats"].zero_()
+        ag._update_plan.run(st)
+        torch.cuda.synchronize()
+        grads_hip = {k: v.numpy() for k, v in m.export(m.grads).items() if k != "_model._action_dist._logstd_net"}
+        loss, info = OL.compute_loss(model, OL.LossCfg(), mb)
+        grads_orc = opt.step(loss)
+        if step == 0:
+            # (1) against the oracle, tensor by tensor, full gradients
+            for k, go in grads_orc.items():
+                gh = grads_hip[k]
+                scale = np.abs(go).max() + 1e-12
+                assert np.abs(gh - go).max() <= 2e-4 * scale + 1e-9, (k, float(np.abs(gh - go).max()), float(scale))
+            # (2) against the reference's own gradients (golden summaries)
+            _check_summary(g, "grad", grads_hip, rtol=5e-4)
+            # logged scalars of the step
+            ag._total_samples = ag.T * ag.N
+            stats = ag._collect_info(1)
+            nv = float(mb["rand_action_mask"].sum())
+            fix = M / nv  # _collect_info assumes every sample explores; this fixture masks 10 % out
+            for k, scale in (("critic_loss", 1), ("disc_loss", 1), ("disc_grad_penalty", 1), ("disc_logit_loss", 1), ("disc_pos_acc", 1),
+                             ("disc_neg_acc", 1), ("disc_pos_logit", 1), ("disc_neg_logit", 1), ("clip_frac", fix), ("imp_ratio", fix),
+                             ("action_bound_loss", fix)):
+                np.testing.assert_allclose(stats[k] * scale, float(g["info." + k]), rtol=2e-4, atol=2e-4, err_msg=k)
+        m.opt_step += 1
+        L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, 1e-4, 0.9, 0.999, 1e-8, 0.0, m.opt_step, st)
+        torch.cuda.synchronize()
+        if step in (0, 2):
+            ph = {k: v.numpy() for k, v in m.export().items() if k != "_model._action_dist._logstd_net"}
+            # Adam's early steps move every weight by ~lr*sign(g): where a gradient is ~0 its sign is rounding noise, so
+            # a few elements may differ by up to 2*lr per step; everything else must agree to fp32 rounding
+            _check_param_summary(g, f"param{step + 1}", ph, step + 1)
+            for k, v in model.p.items():
+                d = np.abs(ph[k] - v.detach().numpy())
+                assert d.max() <= 2.1e-4 * (step + 1), (k, float(d.max()))
+                assert (d > 5e-6).mean() < 0.01, (k, float((d > 5e-6).mean()))
+    # padded rows / columns of the device layout never receive gradient
+    assert float(m.view("actor", "Wh", m.grads)[29:].abs().max()) == 0
+    assert float(m.view("disc", "W0", m.grads)[:, 114:].abs().max()) == 0
+
+
+def _check_param_summary(g, prefix, named, steps, lr=1e-4, long_run=False):
+    """Parameters after `steps` Adam steps against the reference's summaries.  Adam's early steps move each weight by
+    ~lr*sign(g); where a gradient is ~0 its sign is rounding noise, so individual elements may differ by up to 2*lr per
+    step while everything else agrees to fp32 rounding."""
+    for name, val in named.items():
+        f = np.asarray(val, np.float64).reshape(-1)
+        ref_l2 = float(g[f"{prefix}.{name}.l2"])
+        assert abs(np.sqrt(np.square(f).sum()) - ref_l2) <= 2e-4 * max(ref_l2, 1e-12), (prefix, name)
+        stride = max(1, f.size // 64)
+        d = np.abs(np.asarray(val, F).reshape(-1)[::stride][:64] - g[f"{prefix}.{name}.sample"])
+        if long_run:  # a whole iteration (40 steps): rounding noise compounds; bound it against the distance travelled (<= lr*steps)
+            # (elements whose gradient hovers around 0 random-walk by +-lr per step: allow them the full travel, few of them)
+            assert d.max() <= lr * steps and np.percentile(d, 90) <= 0.05 * lr * steps and d.mean() <= 0.01 * lr * steps, \
+                (prefix, name, float(d.max()), float(d.mean()))
+            continue
+        assert d.max() <= 2.1 * lr * steps, (prefix, name, float(d.max()))
+        assert (d > 5e-6).mean() <= 0.08, (prefix, name, float((d > 5e-6).mean()))
+
+
+def _mid(cdf, k):
+    lo = 0.0 if k == 0 else float(cdf[k - 1])
+    return F(0.5 * (lo + float(cdf[k])))
+
+
+def test_one_full_iteration_matches_reference_and_oracle():
+    """BASELINE config 1 stand-in: the reference's own iteration (fake kinematic engine, recorded draws) replayed
+    through the HIP engine."""
+    import torch
+    from oracle import loop as LP
+    from oracle import task as OT
+    from tests.util import oracle_lib
+
+    g = gload("loop_1iter")
+    Tn, n = g["noise"].shape[:2]
+    cfg = make_cfg(n, steps_per_iter=Tn)
+    ag = make_agent(cfg, [gload("motion_small")["frames"]], [1.0])
+    ag._model.load({k: torch.tensor(v) for k, v in OL.synth_params(int(g["seed"])).items()})
+
+    # ---- oracle run alongside: supplies the per-step sampler probabilities needed to turn the reference's
+    # multinomial draws into the uniforms of the device sampler, and a second opinion on every output
+    lib = oracle_lib(golden_tables=True)
+    orc = LP.Agent(LP.AgentCfg(), OT.TaskCfg(), lib, n, OL.synth_params(int(g["seed"])))
+    init = dict(ids=g["init_ids"], segments=g["init_segments"], jitter=g["init_jitter"])
+    resets = []
+    for t in range(Tn):
+        k = int(g["reset_count"][t])
+        resets.append(dict(ids=g["reset_ids"][t, :k], segments=g["reset_segments"][t, :k], jitter=g["reset_jitter"][t, :k]))
+    plan = g["contact_plan"]
+
+    def uniforms(env_ids, draw):
+        u = np.zeros((3, n), F)
+        probs = orc.task.sampler.probs(draw["ids"]) if len(env_ids) else None
+        for j, e in enumerate(env_ids):
+            u[0, e] = 0.5  # single clip
+            u[1, e] = _mid(np.cumsum(probs[j]), int(draw["segments"][j]))
+            u[2, e] = draw["jitter"][j]
+        return T(u)
+
+    inj_u = {0: uniforms(np.arange(n), init)}
+    orc.init(init)
+    orc_info = orc.train_iter(LP.Draws(g["noise"], resets, g["perms"]), [(plan[t] >= 0) for t in range(Tn)])
+    for t in range(Tn):
+        ids = np.nonzero(orc.buf["done"][t] != 0)[0]
+        # sampler errors do not change during the rollout, so probabilities computed after the fact are the ones in effect
+        inj_u[(0 * Tn + t) * 2 + 1] = uniforms(ids, resets[t])
+    # the oracle updated its sampler errors at the end of the iteration; the draws above must use the initial (all-ones) table
+    assert np.all(g["reset_count"] == [(orc.buf["done"][t] != 0).sum() for t in range(Tn)])
+
+    ent = ag._env.robot.entity
+    contact_flags = T((plan >= 0).astype(np.uint8))
+
+    def pre_step(t):
+        ent.forced_contact.copy_(contact_flags[t])
+
+    perms = iter([torch.tensor(p) for p in g["perms"]])
+    ag.inject = dict(noise=T(g["noise"]), uniforms=inj_u, perms=perms, pre_step=pre_step)
+    ag.reset_all_envs(tag=0)
+    ag._init_train()
+    info = ag._train_iter()
+    torch.cuda.synchronize()
+    B = ag._B
+    done = B["done"].cpu().numpy()
+    assert np.array_equal(done, g["buf.done"])                                   # bit-exact flags, whole rollout
+    assert np.array_equal(B["motion_time"].cpu().numpy(), g["buf.motion_times"])  # bit-exact clocks and reset times
+    np.testing.assert_allclose(B["obs"][Tn - 1].cpu().numpy(), g["buf.obs_last"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(B["reward"].cpu().numpy(), g["buf.reward"], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(B["adv"].cpu().numpy(), g["buf.adv"], rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(B["adv"].cpu().numpy(), orc.buf["adv"], rtol=5e-3, atol=5e-3)
+    for k, key in (("obs", "obs"), ("next_obs", "next_obs"), ("a_logp", "a_logp"), ("tar_val", "tar_val")):
+        ref = float(g[f"buf.{k}.abs"])
+        got = B[key][:Tn].double().abs().sum().item()
+        assert abs(got - ref) <= 5e-5 * ref, (k, got, ref)
+    for k in ("adv_mean", "adv_std", "disc_reward_mean", "disc_reward_std", "loss", "actor_loss", "critic_loss", "disc_loss", "clip_frac", "imp_ratio",
+              "disc_grad_penalty", "disc_logit_loss", "disc_pos_acc", "disc_neg_acc", "disc_pos_logit", "disc_neg_logit", "mean_return", "mean_ep_len",
+              "num_eps"):
+        np.testing.assert_allclose(info[k], float(g["info." + k]), rtol=1e-2, atol=5e-4, err_msg=k)
+        np.testing.assert_allclose(info[k], orc_info[k], rtol=1e-2, atol=5e-4, err_msg="oracle:" + k)
+    Nm = ag._Nrm
+    np.testing.assert_allclose(Nm["obs_mean"][:264].cpu().numpy(), g["obs_mean"], rtol=1e-4, atol=1e-5)
+    scale = g["obs_mean"] ** 2 + g["obs_std"] ** 2
+    assert np.all(np.abs(Nm["obs_std"][:264].cpu().numpy() ** 2 - g["obs_std"] ** 2) <= 5e-6 * scale + 1e-9)
+    np.testing.assert_allclose(Nm["d_abs"][:114].cpu().numpy(), g["disc_mean_abs"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ag._smp["errors"].cpu().numpy(), g["sampler_errors"], rtol=1e-4)
+    ph = {k: v.numpy() for k, v in ag._model.export().items() if k != "_model._action_dist._logstd_net"}
+    _check_param_summary(g, "param", ph, 40, long_run=True)
+
+
+def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
+    import torch
+
+    cfg = make_cfg(16, steps_per_iter=4)
+    ag = make_agent(cfg, [gload("motion_small")["frames"]], [1.0])
+    ag._model.opt_step = 3
+    ag._model.exp_avg.normal_()
+    path = str(tmp_path / "model.pt")
+    ag.save(path)
+    ck = torch.load(path, weights_only=True)
+    assert set(ck) == {"model", "optimizer", "iter", "sample_count"}
+    names = {n for n, _ in OL.PARAM_SHAPES}
+    assert names <= set(ck["model"])
+    for n, shape in OL.PARAM_SHAPES:
+        assert tuple(ck["model"][n].shape) == shape, n
+    assert {"_obs_norm._count", "_obs_norm._mean", "_obs_norm._std", "_a_norm._mean", "_disc_obs_norm._mean_abs", "_model._action_dist._logstd_net"} <= set(ck["model"])
+    assert len(ck["optimizer"]["state"]) == 22
+    before = ag._model.params.clone()
+    ag._model.params.zero_()
+    ag.load(path)
+    assert torch.equal(ag._model.params, before) and ag._model.opt_step == 3
+    # DDP-prefixed checkpoints load too (base_agent.py:190-203)
+    ck["model"] = {k.replace("_model.", "_model.module."): v for k, v in ck["model"].items()}
+    torch.save(ck, path)
+    ag._model.params.zero_()
+    ag.load(path)
+    assert torch.equal(ag._model.params, before)
+
+
+def test_training_runs_and_learns_signal(tmp_path):
+    """Two iterations of train_model at a small size through the public surface (log file keys, checkpoint written)."""
+    cfg = make_cfg(256, steps_per_iter=8, iters_per_output=1, test_episodes=0, max_samples=2 * 8 * 256)
+    cfg["task"]["motion_file"] = "synthetic:2x300"
+    import add_gym_amd.learning.add_agent as A
+
+    ag = A.ADDAgent(cfg)
+    out = tmp_path / "model.pt"
+    ag.train_model(str(out), str(tmp_path), str(tmp_path / "log.txt"))
+    assert out.exists()
+    header = (tmp_path / "log.txt").read_text().splitlines()[0].split()
+    for k in ("Iteration", "Wall_Time", "Samples", "Test_Return", "Train_Return", "Loss", "Critic_Loss", "Actor_Loss", "Clip_Frac", "Imp_Ratio",
+              "Disc_Loss", "Disc_Grad_Penalty", "Disc_Logit_Loss", "Disc_Pos_Acc", "Disc_Neg_Acc", "Adv_Mean", "Adv_Std", "Disc_Reward_Mean", "Exp_Prob"):
+        assert k in header, k
+    assert ag._sample_count == 2 * 8 * 256
