@@ -182,11 +182,12 @@ class KinematicScene(BaseScene):
 class KinematicEngine(BaseEngine):
     def __init__(self, lag: float = 0.5, **cfg):
         self._lag, self.cfg = lag, cfg
-        self._device = torch.device("cuda:0")
+        self._device = None
 
     def init(self, backend: str, precision: str) -> None:
         if backend != "gpu" or not torch.cuda.is_available():
             raise RuntimeError("KinematicEngine runs on the GPU only (its step is a HIP kernel); no CPU fallback")
+        self._device = torch.device("cuda", torch.cuda.current_device())
         L.load()
 
     def create_scene(self, show_viewer, sim_options, rigid_options, vis_options=None, viewer_options=None):

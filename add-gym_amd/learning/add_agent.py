@@ -34,7 +34,9 @@ class ADDAgent:
         if not torch.cuda.is_available():
             raise RuntimeError("ADDAgent needs a GPU: the hot path is HIP-only (no CPU fallback)")
         L.load()
-        self._device = torch.device("cuda:0")  # device masking: the rank's GPU is logical device 0 (main.py:143-158)
+        # one process per GPU: the rank's device is torch's current device (set by the launcher before construction;
+        # with the reference's device-masking launch pattern, main.py:143-158, that is logical device 0)
+        self._device = torch.device("cuda", torch.cuda.current_device())
         dev = self._device
         self._cfg = env_config
         cfg = self._config = env_config["agent"]

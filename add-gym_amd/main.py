@@ -8,12 +8,11 @@ import torch
 
 
 def _init_distributed():
-    """main.py:128-176: auto-detect torchrun, mask the device so the rank's GPU is logical device 0, init RCCL."""
+    """main.py:128-176: auto-detect torchrun, bind the rank to its GPU, init RCCL."""
     if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ or int(os.environ["WORLD_SIZE"]) == 1:
         return False
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    os.environ.setdefault("HIP_VISIBLE_DEVICES", str(local_rank))
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))  # one process per GPU
     torch.distributed.init_process_group(backend="nccl")  # "nccl" is RCCL on ROCm
     return True
 

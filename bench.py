@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of rollout + update (BaseAgent._train_iter, base_agent.py:353-374; test rollouts
+excluded), G1 imitation, 4096 envs/GPU, fp32 PPO + ADD discriminator (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one training iteration: T=32 env steps of all envs (actor MLP, engine step, fused obs/reward/done kernel,
+masked reset) + build-train-data (disc reward, critic values, TD(lambda), advantage) + 5 epochs x 8 minibatches of
+forward/backward/AdamW.  Synthetic G1 clips, random-init weights, the KinematicEngine stand-in simulator (physics is
+out of scope: DESIGN.md).  Environments are sharded across ranks (weak scaling); the only data-path collective is the
+all-reduce (RCCL) of the flat fp32 gradient each optimiser step plus the once-per-iteration normaliser sums.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the fp32 MFMA GEMM, timed live with HIP events on the
+launch stream) and `cpu_baseline` (the CPU oracle's loop on a bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_32x32x2_f32
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy ceiling)
+ENV_STEP_BYTES = 4573         # algorithmic bytes per env-step of the fused obs/reward/done kernel
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=256)
+    return ap.parse_args()
+
+
+def time_gemms(agent, reps=3):
+    """Average duration of the gemm_kernel launches of one optimiser step, each bracketed by HIP events recorded on the
+    stream the kernel is launched on (torch's current stream == the stream handed to the C ABI)."""
+    import torch
+    import add_gym_amd._lib as L
+
+    st = torch.cuda.current_stream()
+    calls = [(fn, args) for name, fn, args in agent._update_plan.calls if name == "addhip_gemm_f32"]
+    flops = 0.0
+    for _, args in calls:
+        g = args[0]
+        flops += 2.0 * g.M * g.N * g.K
+    ms = 0.0
+    for _ in range(reps):
+        for fn, args in calls:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = fn(*args, st.cuda_stream)
+            e1.record(st)
+            assert rc == 0
+            e1.synchronize()
+            ms += e0.elapsed_time(e1)
+    ms /= reps
+    return dict(launches=len(calls), flops=flops, ms=ms)
+
+
+def time_env_step(agent, reps=20):
+    import torch
+    import add_gym_amd._lib as L
+
+    st = torch.cuda.current_stream()
+    out = agent._step_out[0]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        L.call("addhip_env_step", agent._motion_lib.c_struct, agent._task, agent._env_c, out, 0, st.cuda_stream)
+    e0.record(st)
+    for _ in range(reps):
+        L.call("addhip_env_step", agent._motion_lib.c_struct, agent._task, agent._env_c, out, 0, st.cuda_stream)
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def host_cores():
+    """CPU share of this job: cgroup quota if set, else the affinity mask, capped at 16 (the GPU box gives one GPU's job
+    16 cores; os.cpu_count() reports the whole host and oversubscribing OpenMP by 10x makes torch-CPU crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(num_envs, steps_per_iter):
+    """The CPU oracle's iteration (oracle/loop.py) on a bounded sample of the same workload, all host cores."""
+    import numpy as np
+    import torch
+    from oracle import learn as OL
+    from oracle import loop as LP
+    from oracle import task as OT
+    from oracle.kin import KinTree
+    from oracle.motion import MotionLib
+    import add_gym_amd  # noqa: F401
+    from add_gym_amd.anim.kin_char_model import KinCharModel
+    from add_gym_amd.anim.synth import synth_clip
+    from add_gym_amd.config import load_config
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    cfg = load_config("train", [])
+    xml = cfg["robot"]["urdf_path"]
+    order = list(cfg["task"]["motion_joint_order"])
+    kin_p = KinCharModel()
+    kin_p.load_char_file(xml)
+    frames = synth_clip(kin_p, order, 0, 900)
+    lib = MotionLib([frames], [1.0], order, KinTree(xml), 0.01)
+    rng = np.random.RandomState(0)
+    n, Tn = num_envs, steps_per_iter
+    ag = LP.Agent(LP.AgentCfg(steps_per_iter=Tn), OT.TaskCfg(), lib, n, OL.synth_params(1, bias_scale=0.0))
+    draw = lambda k: dict(ids=np.zeros(k, np.int64), segments=rng.randint(0, 20, k), jitter=rng.rand(k).astype(np.float32))
+    ag.init(draw(n))
+    total = Tn * n
+    perms = [rng.permutation(total) for _ in range(8)]
+    draws = LP.Draws(rng.standard_normal((Tn, n, 29)).astype(np.float32), lambda t, ids: draw(len(ids)), perms)
+    t0 = time.perf_counter()
+    ag.train_iter(draws)
+    dt = time.perf_counter() - t0
+    return dict(value=total / dt, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"1 iteration of the CPU oracle (numpy + torch-CPU fp32, {cores} threads): {n} envs x {Tn} steps rollout + "
+                       f"5 epochs x {Tn // 4} minibatches update, {dt:.1f} s")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path is HIP-only)")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    distributed = world > 1
+    if distributed:
+        dist.init_process_group(backend="nccl")  # RCCL
+    import add_gym_amd  # noqa: F401
+    from add_gym_amd.config import load_config
+    from add_gym_amd.learning.add_agent import ADDAgent
+
+    cfg = load_config("train", [f"engine.num_envs={a.envs}", "task.motion_file=synthetic:1x3600", f"seed={1 + rank}"])
+    agent = ADDAgent(cfg, distributed=distributed)
+    agent.reset_all_envs()
+    agent._init_train()
+
+    def sync():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        agent._train_iter()
+        agent._iter += 1
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        agent._train_iter()
+        agent._iter += 1
+    sync()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    env_steps = agent.T * agent.N * world * a.steps
+    out = {
+        "metric": "env-steps/sec (rollout+update), G1 imitation, 4096 envs/GPU",
+        "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (generated G1 clip, random-init weights, kinematic stand-in simulator)",
+        "config": {"workload": "G1 walk-like synthetic motion, num_envs=%d/GPU, fp32 PPO + ADD discriminator (BASELINE configs[1])" % a.envs,
+                   "envs_per_gpu": a.envs, "steps_per_iter": agent.T, "update_epochs": agent._update_epochs, "minibatch_rows": agent.Mb,
+                   "params": agent.calc_num_params(), "parallelism": "dp%d (envs sharded, gradient all-reduce)" % world},
+    }
+    if rank == 0:
+        print(f"[bench] timed region done: {env_steps / dt:.0f} env-steps/s; measuring kernels + cpu baseline", file=sys.stderr, flush=True)
+        g = time_gemms(agent)
+        tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all GEMM launches of one optimiser step)",
+                           "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                           "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"]}
+        ms = time_env_step(agent)
+        gbs = ENV_STEP_BYTES * agent.N / (ms * 1e-3) / 1e9
+        out["roofline_env_step"] = {"bound": "hbm", "kernel": "env_step_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "us_per_launch": ms * 1e3, "envs": agent.N}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_envs, agent.T)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -151,7 +151,7 @@ class Agent:
             buf["motion_times"].append(self.task.motion_times())
             self.disc_norm.record(d_demo - d_obs)  # add_agent.py:106-108
             ids = np.nonzero(done != T.DONE_NULL)[0]
-            self.reset_envs(ids, draws.resets[t])
+            self.reset_envs(ids, draws.resets(t, ids) if callable(draws.resets) else draws.resets[t])
         self.buf = {k: np.stack(v) for k, v in buf.items()}
         return self.buf
 
