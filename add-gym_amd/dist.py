@@ -1,0 +1,37 @@
+"""The exchange steps of the data-parallel path (one process per GPU; `nccl` == RCCL over xGMI on ROCm, `gloo` in CPU
+tests).  Environments are independent, so ranks only ever exchange:
+  * the flat fp32 gradient, averaged, once per optimiser step (the DDP semantics the reference intends: base_agent.py:47-57;
+    SURVEY.md section 0 shows its own wiring never fires);
+  * the observation-normaliser sums once per iteration (normalizer.py:41-58);
+  * the logged scalars (util/logger.py:160-184).
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def all_reduce_mean_(flat):
+    """In-place mean over ranks of one flat buffer (one collective per optimiser step: 17.4 MB for the G1 model)."""
+    w = world_size()
+    if w > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / w)
+    return flat
+
+
+def all_reduce_sum_(*tensors):
+    """In-place sums over ranks (normaliser statistics); returns the world size so callers can scale their counts."""
+    w = world_size()
+    if w > 1:
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return w
+
+
+def broadcast_(flat, src=0):
+    if world_size() > 1:
+        dist.broadcast(flat, src)
+    return flat

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
+from .. import dist as D
 from ..anim.motion_lib import MotionLib
 from ..envs.env import ImitationEnvironment
 from ..hotpath import gemm, make_task
@@ -123,7 +124,7 @@ class ADDAgent:
         if float(opt.get("grad_clip", 0.0)) > 0:
             raise NotImplementedError("optimizer.grad_clip > 0 is not implemented (the reference's default config never enables it)")
         if self._distributed:  # DDP ctor behaviour: every rank starts from rank 0's weights (base_agent.py:50-57)
-            torch.distributed.broadcast(self._model.params, 0)
+            D.broadcast_(self._model.params, 0)
 
         self._build_workspace()
         self._build_plans()
@@ -427,8 +428,7 @@ class ADDAgent:
                 L.call("addhip_gather_minibatch", self._gather_c, st)
                 self._update_plan.run(st)
                 if self._world > 1:  # the exchange step: mean gradient over ranks (RCCL all-reduce over xGMI)
-                    torch.distributed.all_reduce(m.grads)
-                    m.grads.mul_(1.0 / self._world)
+                    D.all_reduce_mean_(m.grads)
                 m.opt_step += 1
                 L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, self._lr, 0.9, 0.999, 1e-8,
                        self._wd, m.opt_step, st)
@@ -445,9 +445,7 @@ class ADDAgent:
         L.call("addhip_norm_accum", L.ptr(B["obs"]), rows, tk.obs_stride, tk.obs_stride, L.ptr(Nm["obs_sum"]), L.ptr(Nm["obs_sumsq"]), st)
         count = rows
         if self._world > 1:
-            torch.distributed.all_reduce(Nm["obs_sum"])
-            torch.distributed.all_reduce(Nm["obs_sumsq"])
-            count = rows * self._world
+            count = rows * D.all_reduce_sum_(Nm["obs_sum"], Nm["obs_sumsq"])
         L.call("addhip_norm_merge", L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(Nm["obs_msq"]), L.ptr(Nm["obs_cnt"]), L.ptr(Nm["obs_sum"]),
                L.ptr(Nm["obs_sumsq"]), count, tk.obs_stride, 1e-8, int(self._obs_norm_first), st)
         self._obs_norm_first = False
