@@ -15,66 +15,71 @@
 // Replaces: torch.nn.Linear forward/backward inside PPOModel.eval_actor/eval_critic
 // (ppo_model.py:13-21), ADDModel.eval_disc (add_model.py:12-15) and their autograd.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BK = 16;
-constexpr int LDK = BK + 4;
-
-template <int ROWS, bool KC>
+// K depth of one LDS tile: 32 (two 36.9 KB stages -> exactly two 128x128 workgroups per CU, so the usual
+// 512- and 1024-tile grids run as whole waves of workgroups over the 256 CUs) or 16 for the small tiles.
+template <int ROWS, bool KC, int BK>
 struct Tile {
-  static constexpr int LD = KC ? LDK : (ROWS + 4);
+  static constexpr int LDK = BK + 4;  // 20 / 36 dwords: a ds_read_b128 lane group covers all 64 banks
   static constexpr int SIZE = KC ? ROWS * LDK : BK * (ROWS + 4);
   static constexpr int F4 = ROWS * BK / 4;            // float4 per tile
   static constexpr int PER_THREAD = (F4 + 255) / 256;  // float4 per thread
+  static constexpr int KQ = BK / 4;                    // float4 per k-contiguous row
 };
 
-// global -> registers for one operand tile.  (r0: first row of the tile in the M/N extent, k0: first k)
-template <int ROWS, bool KC>
-__device__ __forceinline__ void load_tile(float4* reg, const float* __restrict__ P, int ld, int r0,
-                                          int k0, int R, int kend, const float* mean, const float* stdv) {
+// global -> registers for one operand tile (r0: first row of the tile in the M/N extent, k0: first k).
+// GUARD=false is the interior fast path: the whole K range of the tile is in bounds, and rows beyond the
+// matrix are clamped to the last valid row -- their products only reach C rows/columns that are never stored.
+template <int ROWS, bool KC, int BK, bool GUARD, bool NORM>
+__device__ __forceinline__ void load_tile(float4* reg, const float* __restrict__ P, int ld, int r0, int k0, int R, int kend,
+                                          const float* __restrict__ mean, const float* __restrict__ stdv) {
   const int tid = threadIdx.x;
+  using TT = Tile<ROWS, KC, BK>;
 #pragma unroll
-  for (int i = 0; i < Tile<ROWS, KC>::PER_THREAD; ++i) {
-    int f = tid + 256 * i;
+  for (int i = 0; i < TT::PER_THREAD; ++i) {
+    const int f = tid + 256 * i;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < Tile<ROWS, KC>::F4) {
+    if (TT::F4 % 256 == 0 || f < TT::F4) {
       if (KC) {
-        int row = f >> 2, kq = (f & 3) * 4;
-        int r = r0 + row, k = k0 + kq;
-        if (r < R && k < kend) {
+        const int row = f / TT::KQ, kq = (f % TT::KQ) * 4;
+        const int r = min(r0 + row, R - 1), k = k0 + kq;
+        if (!GUARD || k < kend) {
           v = *reinterpret_cast<const float4*>(P + (size_t)r * ld + k);
-          if (mean) {  // Normalizer.normalize (normalizer.py:107-110)
-            float4 mu = *reinterpret_cast<const float4*>(mean + k);
-            float4 sd = *reinterpret_cast<const float4*>(stdv + k);
+          if (NORM) {  // Normalizer.normalize (normalizer.py:107-110)
+            const float4 mu = *reinterpret_cast<const float4*>(mean + k);
+            const float4 sd = *reinterpret_cast<const float4*>(stdv + k);
             v.x = (v.x - mu.x) / sd.x; v.y = (v.y - mu.y) / sd.y; v.z = (v.z - mu.z) / sd.z; v.w = (v.w - mu.w) / sd.w;
           }
         }
       } else {
         constexpr int RQ = ROWS / 4;
-        int kk = f / RQ, rq = (f - kk * RQ) * 4;
-        int r = r0 + rq, k = k0 + kk;
-        if (r < R && k < kend) v = *reinterpret_cast<const float4*>(P + (size_t)k * ld + r);
+        const int kk = f / RQ, rq = (f - kk * RQ) * 4;
+        const int r = min(r0 + rq, R - 4), k = k0 + kk;
+        if (!GUARD || k < kend) v = *reinterpret_cast<const float4*>(P + (size_t)k * ld + r);
       }
     }
     reg[i] = v;
   }
 }
 
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int BK>
 __device__ __forceinline__ void store_tile(float* lds, const float4* reg) {
   const int tid = threadIdx.x;
+  using TT = Tile<ROWS, KC, BK>;
 #pragma unroll
-  for (int i = 0; i < Tile<ROWS, KC>::PER_THREAD; ++i) {
-    int f = tid + 256 * i;
-    if (f < Tile<ROWS, KC>::F4) {
+  for (int i = 0; i < TT::PER_THREAD; ++i) {
+    const int f = tid + 256 * i;
+    if (TT::F4 % 256 == 0 || f < TT::F4) {
       if (KC) {
-        int row = f >> 2, kq = (f & 3) * 4;
-        *reinterpret_cast<float4*>(lds + row * LDK + kq) = reg[i];
+        const int row = f / TT::KQ, kq = (f % TT::KQ) * 4;
+        *reinterpret_cast<float4*>(lds + row * TT::LDK + kq) = reg[i];
       } else {
         constexpr int RQ = ROWS / 4;
-        int kk = f / RQ, rq = (f - kk * RQ) * 4;
+        const int kk = f / RQ, rq = (f - kk * RQ) * 4;
         *reinterpret_cast<float4*>(lds + kk * (ROWS + 4) + rq) = reg[i];
       }
     }
@@ -83,20 +88,24 @@ __device__ __forceinline__ void store_tile(float* lds, const float4* reg) {
 
 // fragment of one 32-row block for the 8-deep k chunk starting at kk: element j feeds MFMA j
 // (lane half h supplies k = kk + 4h + j; both operands use the same map so the products pair up)
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int BK>
 __device__ __forceinline__ float4 read_frag(const float* lds, int row, int kk, int h) {
-  if (KC) return *reinterpret_cast<const float4*>(lds + row * LDK + kk + 4 * h);
+  if (KC) return *reinterpret_cast<const float4*>(lds + row * Tile<ROWS, KC, BK>::LDK + kk + 4 * h);
   const float* p = lds + (kk + 4 * h) * (ROWS + 4) + row;
   return make_float4(p[0], p[ROWS + 4], p[2 * (ROWS + 4)], p[3 * (ROWS + 4)]);
 }
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
+constexpr int EPI_RUNTIME = -1;  // epilogue chosen from the descriptor at run time (cold combinations)
+
+// EPI: compile-time epilogue (ADDHIP_EPI_*) or EPI_RUNTIME; NORM: fused (a-mean)/std on A
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int BK, int EPI, bool NORM>
+__global__ __launch_bounds__(256, (BK == 16 && BM * BN == 128 * 128) ? 4 : 1) void gemm_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
   static_assert(WM * WN == 4, "4 wavefronts");
+  static_assert(!NORM || AKC, "fused normalisation needs a k-contiguous A");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   static_assert(FM >= 1 && FN >= 1, "wave tile must hold a 32x32 accumulator");
-  using TA = Tile<BM, AKC>;
-  using TB = Tile<BN, BKC>;
+  using TA = Tile<BM, AKC, BK>;
+  using TB = Tile<BN, BKC, BK>;
   __shared__ __attribute__((aligned(16))) float lds[2 * (TA::SIZE + TB::SIZE)];
   constexpr int STAGE = TA::SIZE + TB::SIZE;
 
@@ -115,6 +124,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
   const int kbeg = blockIdx.z * kchunk;
   const int kend = min(g.K, kbeg + kchunk);
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  const int nk_full = kend > kbeg ? (kend - kbeg) / BK : 0;  // tiles whose whole K range is in bounds
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm0 = (wave / WN) * TM, wn0 = (wave % WN) * TN;
@@ -129,11 +139,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
       for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
 
   float4 ra[TA::PER_THREAD], rb[TB::PER_THREAD];
+  auto fetch = [&](int kt) {
+    const int k0 = kbeg + kt * BK;
+    if (kt < nk_full) {
+      load_tile<BM, AKC, BK, false, NORM>(ra, g.A, g.lda, m0, k0, g.M, kend, g.a_mean, g.a_std);
+      load_tile<BN, BKC, BK, false, false>(rb, g.B, g.ldb, n0, k0, g.N, kend, nullptr, nullptr);
+    } else {
+      load_tile<BM, AKC, BK, true, NORM>(ra, g.A, g.lda, m0, k0, g.M, kend, g.a_mean, g.a_std);
+      load_tile<BN, BKC, BK, true, false>(rb, g.B, g.ldb, n0, k0, g.N, kend, nullptr, nullptr);
+    }
+  };
   if (nk > 0) {
-    load_tile<BM, AKC>(ra, g.A, g.lda, m0, kbeg, g.M, kend, g.a_mean, g.a_std);
-    load_tile<BN, BKC>(rb, g.B, g.ldb, n0, kbeg, g.N, kend, nullptr, nullptr);
-    store_tile<BM, AKC>(lds, ra);
-    store_tile<BN, BKC>(lds + TA::SIZE, rb);
+    fetch(0);
+    store_tile<BM, AKC, BK>(lds, ra);
+    store_tile<BN, BKC, BK>(lds + TA::SIZE, rb);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
@@ -141,17 +160,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
     const float* a_cur = lds + cur * STAGE;
     const float* b_cur = a_cur + TA::SIZE;
     const bool more = kt + 1 < nk;
-    if (more) {
-      load_tile<BM, AKC>(ra, g.A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, g.a_mean, g.a_std);
-      load_tile<BN, BKC>(rb, g.B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, nullptr, nullptr);
-    }
+    if (more) fetch(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 8) {
       float4 fa[FM], fb[FN];
 #pragma unroll
-      for (int a = 0; a < FM; ++a) fa[a] = read_frag<BM, AKC>(a_cur, wm0 + a * 32 + li, kk, lh);
+      for (int a = 0; a < FM; ++a) fa[a] = read_frag<BM, AKC, BK>(a_cur, wm0 + a * 32 + li, kk, lh);
 #pragma unroll
-      for (int b = 0; b < FN; ++b) fb[b] = read_frag<BN, BKC>(b_cur, wn0 + b * 32 + li, kk, lh);
+      for (int b = 0; b < FN; ++b) fb[b] = read_frag<BN, BKC, BK>(b_cur, wn0 + b * 32 + li, kk, lh);
 #pragma unroll
       for (int a = 0; a < FM; ++a)
 #pragma unroll
@@ -163,44 +179,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
         }
     }
     if (more) {
-      store_tile<BM, AKC>(lds + (cur ^ 1) * STAGE, ra);
-      store_tile<BN, BKC>(lds + (cur ^ 1) * STAGE + TA::SIZE, rb);
+      store_tile<BM, AKC, BK>(lds + (cur ^ 1) * STAGE, ra);
+      store_tile<BN, BKC, BK>(lds + (cur ^ 1) * STAGE + TA::SIZE, rb);
     }
     __syncthreads();
   }
 
   // epilogue: lane owns column n0+wn0+b*32+li; register x is row (x&3)+8*(x>>2)+4*lh of the 32x32 tile
+  const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
   float* C = g.C + (size_t)blockIdx.z * (size_t)g.M * g.ldc;
 #pragma unroll
   for (int b = 0; b < FN; ++b) {
     const int col = n0 + wn0 + b * 32 + li;
-    if (col >= g.N) continue;
-    const float bias = (g.epilogue == ADDHIP_EPI_BIAS || g.epilogue == ADDHIP_EPI_BIAS_RELU) ? g.bias[col] : 0.f;
+    const bool col_ok = col < g.N;
+    const float bias = (col_ok && (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU)) ? g.bias[col] : 0.f;
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
+      const int rbase = m0 + wm0 + a * 32 + 4 * lh;
+      float mk[16];
+      if (epi == ADDHIP_EPI_MASK) {  // all 16 mask loads in flight before any use
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const int row = rbase + (x & 3) + 8 * (x >> 2);
+          mk[x] = (col_ok && row < g.M) ? g.mask[(size_t)row * g.ldmask + col] : 0.f;
+        }
+      }
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
-        const int row = m0 + wm0 + a * 32 + (x & 3) + 8 * (x >> 2) + 4 * lh;
-        if (row >= g.M) continue;
+        const int row = rbase + (x & 3) + 8 * (x >> 2);
         float v = g.alpha * acc[a][b][x] + bias;
-        if (g.epilogue == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-        if (g.epilogue == ADDHIP_EPI_MASK) v = g.mask[(size_t)row * g.ldmask + col] > 0.f ? v : 0.f;
-        C[(size_t)row * g.ldc + col] = v;
+        if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        if (epi == ADDHIP_EPI_MASK) v = mk[x] > 0.f ? v : 0.f;
+        if (col_ok && row < g.M) C[(size_t)row * g.ldc + col] = v;
       }
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 int launch_cfg(const addhip_gemm_t& g, hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int split = g.split_k > 1 ? g.split_k : 1;
   dim3 grid(tiles_m * tiles_n, 1, split), block(256);
-#define ADDHIP_LAUNCH(AK, BKc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AK, BKc>), grid, block, 0, st, g, tiles_m, tiles_n)
-  if (g.a_kcontig && g.b_kcontig) ADDHIP_LAUNCH(true, true);
-  else if (g.a_kcontig && !g.b_kcontig) ADDHIP_LAUNCH(true, false);
-  else if (!g.a_kcontig && g.b_kcontig) ADDHIP_LAUNCH(false, true);
-  else ADDHIP_LAUNCH(false, false);
+  const bool norm = g.a_mean != nullptr;
+#define ADDHIP_LAUNCH(AK, BKc, EPI, NORM) \
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AK, BKc, BK, EPI, NORM>), grid, block, 0, st, g, tiles_m, tiles_n)
+  // hot combinations get a compile-time epilogue; everything else shares the run-time one
+  if (g.a_kcontig && g.b_kcontig) {
+    if (norm) {
+      if (g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_BIAS_RELU, true);
+      else return (addhip::set_error("gemm: fused normalisation is only built for the bias+ReLU epilogue"), -1);
+    } else if (g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_BIAS_RELU, false);
+    else if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_MASK, false);
+    else ADDHIP_LAUNCH(true, true, EPI_RUNTIME, false);
+  } else if (g.a_kcontig && !g.b_kcontig) {
+    if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_LAUNCH(true, false, ADDHIP_EPI_MASK, false);
+    else ADDHIP_LAUNCH(true, false, EPI_RUNTIME, false);
+  } else if (!g.a_kcontig && g.b_kcontig) {
+    ADDHIP_LAUNCH(false, true, EPI_RUNTIME, false);
+  } else {
+    if (g.epilogue == ADDHIP_EPI_NONE) ADDHIP_LAUNCH(false, false, ADDHIP_EPI_NONE, false);
+    else ADDHIP_LAUNCH(false, false, EPI_RUNTIME, false);
+  }
 #undef ADDHIP_LAUNCH
   return addhip::check_launch("gemm_kernel");
 }
@@ -256,12 +296,14 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   if (g.a_mean || g.a_std) ADDHIP_REQUIRE(g.a_kcontig && g.a_mean && g.a_std, "gemm: fused normalisation needs a k-contiguous A and both mean/std");
   if (g.alpha == 0.0f) g.alpha = 1.0f;
   hipStream_t st = (hipStream_t)stream;
-  if (g.N <= 32) return launch_cfg<128, 32, 4, 1>(g, st);
-  if (g.N <= 64) return launch_cfg<128, 64, 2, 2>(g, st);
+  if (g.N <= 32) return launch_cfg<128, 32, 4, 1, 16>(g, st);
+  if (g.N <= 64) return launch_cfg<128, 64, 2, 2, 16>(g, st);
   // keep >= ~1 block per CU on the skinny rollout shapes
   const long long tiles128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
-  if (tiles128 < 256) return launch_cfg<64, 128, 2, 2>(g, st);
-  return launch_cfg<128, 128, 2, 2>(g, st);
+  if (tiles128 < 256) return launch_cfg<64, 128, 2, 2, 16>(g, st);
+  static const int bk16 = getenv("ADDHIP_BK16") ? 1 : 0;
+  if (bk16) return launch_cfg<128, 128, 2, 2, 16>(g, st);
+  return launch_cfg<128, 128, 2, 2, 32>(g, st);
 }
 
 extern "C" int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count, float scale,
