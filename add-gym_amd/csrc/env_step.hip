@@ -1,13 +1,15 @@
 // Per-env hot path of the rollout: reference-motion frame lookup, history ring, observation /
 // discriminator-observation assembly, imitation reward, done flags, return tracker, masked reset.
 //
-// One wavefront (64 lanes) owns one env at a time.  All rows an env needs (simulator state,
-// reference frame, 6 target frames, 2 older demo frames, 2 older history frames: 16 x 36 floats)
-// are fetched with 16-byte loads -- 9 lanes per 144-byte row, 7 rows per wave instruction --
-// into a wave-private LDS tile; outputs are then produced output-major (lane = output column) so
-// every global store is a contiguous run of the obs / disc rows.  Reductions (pose / velocity
-// error sums, softmax over sampler segments) are wavefront shuffles.  HBM-bound by construction:
-// 4.6 KB of algorithmic traffic per env-step.
+// env_obs_kernel: one wavefront owns one env at a time.  The 16 rows an env needs (simulator pose,
+// reference pose+velocity, up to 8 target frames, 2 older demo frames, 2 older history frames; 144 B each)
+// are fetched in ONE pass -- 4 lanes per row, 36 B per lane -- into a wave-private LDS work area; the few values
+// that need arithmetic (tangent/normal vectors of 15 quaternions, target position offsets) are derived once per
+// env by 15+24 lanes; every output row is then a pure gather from LDS through an index map built once per
+// workgroup, so all global stores are contiguous runs of the obs / disc rows.  HBM-bound by construction:
+// 4.6 KB of algorithmic traffic per env-step; the instruction budget is ~250 wave-instructions per env.
+// env_reward_kernel: 16 lanes per env (reward, done flags, return tracker) on the rows the first kernel left
+// in ref_pose/ref_vel.  env_reset_kernel: masked reset, same staging/derive/emit code on clip rows.
 //
 // Reference functions restated here: see include/addhip.h at each entry point.
 #include "common.h"
@@ -17,28 +19,44 @@ using namespace addhip;
 
 namespace {
 
-constexpr int PW = ADDHIP_POSE_W;      // 36 floats per row
+constexpr int PW = ADDHIP_POSE_W;  // 36 floats per global row
 constexpr int ROWS = 16;
 constexpr int WAVES = 4;
-constexpr int R_SIM = 0, R_SIMV = 1, R_REF = 2, R_REFV = 3, R_TAR = 4, R_DEMO0 = 12, R_DEMO1 = 13, R_H0 = 14, R_H1 = 15;
+constexpr int R_SIM = 0, R_REF = 2, R_REFV = 3, R_TAR = 4, R_DEMO0 = 12, R_DEMO1 = 13, R_H0 = 14, R_H1 = 15;
+// LDS image of a row: 4 chunks of 9 floats padded to 12 so that each lane's chunk is 16-byte aligned
+constexpr int LROW = 48;
+__device__ __forceinline__ int row_off(int r, int c) { return r * LROW + (c / 9) * 12 + (c % 9); }
 
-// MotionLib.get_precomputed_motion_step index (anim/motion_lib.py:322-326): fp32 multiply by
-// round(1/dt), truncate toward zero, clamp, add the clip offset.  Bit-exact by construction:
-// explicit round-to-nearest multiply, no contraction.
-__device__ __forceinline__ int step_index(const addhip_motion_t& m, int id, float t) {
-  float f = __fmul_rn(t, m.dt_inv);
-  long long fr = (long long)f;
-  if (m.reference_compat) {
-    long long hi = (long long)m.total_steps - 1;
-    fr = fr < 0 ? 0 : (fr > hi ? hi : fr);
-    long long idx = fr + (long long)m.clip_start[id];
-    return (int)(idx > hi ? hi : idx);  // the reference would raise IndexError here
+constexpr int TN_CHAR = 0, TN_TAR = 1, TN_H0 = 9, TN_H1 = 10, TN_SIMG = 11, TN_D0 = 12, TN_D1 = 13, TN_REF = 14, TN_SLOTS = 15;
+constexpr int OFF_TN = ROWS * LROW;                // [15][6] tangent/normal vectors
+constexpr int OFF_TP = OFF_TN + TN_SLOTS * 6;      // [8][3] target position observations
+constexpr int OFF_ZERO = OFF_TP + ADDHIP_MAX_TAR_STEPS * 3;
+constexpr int WORK = (OFF_ZERO + 1 + 3) / 4 * 4;   // floats per wave (16-byte multiple)
+constexpr int MAP_MAX = 512;                       // obs_stride + 2*disc_stride must fit
+
+enum { K_SKIP = 0, K_POSE = 1, K_VEL = 2, K_SIM = 3, K_HIST = 4 };
+
+// MotionLib.get_precomputed_motion_step index (anim/motion_lib.py:322-326): fp32 multiply by round(1/dt), truncate
+// toward zero, clamp, add the clip offset.  Bit-exact: explicit round-to-nearest multiply, no contraction; the float is
+// clamped to the int range first, which cannot change the clamped integer result.
+__device__ __forceinline__ int step_index(float t, float dt_inv, int total_steps, int clip_start, int clip_steps, int compat) {
+  float f = __fmul_rn(t, dt_inv);
+  f = fminf(fmaxf(f, -1.0f), 2.0e9f);
+  int fr = (int)f;  // truncation toward zero
+  if (compat) {
+    const int hi = total_steps - 1;
+    fr = min(max(fr, 0), hi);
+    return min(fr + clip_start, hi);  // (the reference would raise IndexError past the table end)
   }
-  long long hi = (long long)m.clip_steps[id] - 1;
-  fr = fr < 0 ? 0 : (fr > hi ? hi : fr);
-  return (int)(fr + (long long)m.clip_start[id]);
+  fr = min(max(fr, 0), clip_steps - 1);
+  return fr + clip_start;
 }
 
+__device__ __forceinline__ float group_sum16(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -50,223 +68,292 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ Quat row_quat(const float* r) { return Quat{r[3], r[4], r[5], r[6]}; }
-
-// one element of compute_add_obs (add_observation.py:653-717 with compute_char_obs :422-459 and
-// compute_tar_obs :578-650; vel/phase observations are not part of this build's HIP path)
-__device__ __forceinline__ float obs_elem(const addhip_task_t& t, const float (*rows)[PW], int o) {
+// ---- index maps: LDS source of every output element ------------------------------------------------------------
+// compute_add_obs (add_observation.py:653-717 with compute_char_obs :422-459, compute_tar_obs :578-650)
+__device__ __forceinline__ int obs_src(const addhip_task_t& t, int o) {
+  if (o >= t.obs_dim) return OFF_ZERO;
   const int hc = t.root_height_obs ? 1 : 0;
   const int char_dim = hc + 6 + ADDHIP_NUM_DOF;
-  const float* sim = rows[R_SIM];
   if (o < char_dim) {
-    if (hc && o == 0) return sim[2];
-    int c = o - hc;
-    if (c < 6) {
-      Quat q = row_quat(sim);
-      if (!t.global_obs) q = quat_mul(heading_quat_inv(q), q);
-      return tan_norm_elem(q, c);
-    }
-    return sim[7 + c - 6];
+    if (hc && o == 0) return row_off(R_SIM, 2);
+    const int c = o - hc;
+    return c < 6 ? OFF_TN + TN_CHAR * 6 + c : row_off(R_SIM, 7 + c - 6);
   }
   const int pw = hc ? 3 : 2;
   const int tw = pw + 6 + ADDHIP_NUM_DOF;
-  int k = (o - char_dim) / tw;
+  const int k = (o - char_dim) / tw;
   int c = (o - char_dim) - k * tw;
-  const float* tar = rows[R_TAR + k];
-  if (c < pw) {
-    if (c == 2) return tar[2];  // add_observation.py:615-616 absolute height
-    if (t.global_obs) return tar[c] - sim[c];
-    const float* t0 = rows[R_TAR];
-    Vec3 d{tar[0] - t0[0], tar[1] - t0[1], tar[2] - t0[2]};
-    Vec3 r = quat_rotate(heading_quat_inv(row_quat(t0)), d);
-    return c == 0 ? r.x : r.y;
-  }
+  if (c < pw) return OFF_TP + k * 3 + c;
   c -= pw;
-  if (c < 6) {
-    Quat q = row_quat(tar);
-    if (!t.global_obs) q = quat_mul(heading_quat_inv(row_quat(rows[R_TAR])), q);
-    return tan_norm_elem(q, c);
-  }
-  return tar[7 + c - 6];
+  return c < 6 ? OFF_TN + (TN_TAR + k) * 6 + c : row_off(R_TAR + k, 7 + c - 6);
 }
-
-// one element of compute_disc_obs (add_observation.py:462-554) for history rows (r0,r1,r2) oldest..newest
-__device__ __forceinline__ float disc_elem(const addhip_task_t& t, const float* r0, const float* r1, const float* r2, int o) {
+// compute_disc_obs (add_observation.py:462-554); demo=false: history rows, true: clip rows
+__device__ __forceinline__ int disc_src(const addhip_task_t& t, int o, bool demo) {
+  if (o >= t.disc_dim) return OFF_ZERO;
   constexpr int sw = 3 + 6 + ADDHIP_NUM_DOF;  // 38
-  int s = o / sw;
-  int c = o - s * sw;
-  const float* r = s == 0 ? r0 : (s == 1 ? r1 : r2);
-  if (c < 3) return (!t.global_obs && c < 2) ? 0.0f : r[c];
-  if (c < 9) return tan_norm_elem(row_quat(r), c - 3);
-  return r[7 + c - 9];
+  const int s = o / sw, c = o - s * sw;
+  const int row = demo ? (s == 0 ? R_DEMO0 : (s == 1 ? R_DEMO1 : R_REF)) : (s == 0 ? R_H0 : (s == 1 ? R_H1 : R_SIM));
+  const int slot = demo ? (s == 0 ? TN_D0 : (s == 1 ? TN_D1 : TN_REF)) : (s == 0 ? TN_H0 : (s == 1 ? TN_H1 : TN_SIMG));
+  if (c < 3) return (!t.global_obs && c < 2) ? OFF_ZERO : row_off(row, c);
+  if (c < 9) return OFF_TN + slot * 6 + (c - 3);
+  return row_off(row, 7 + c - 9);
+}
+__device__ __forceinline__ void build_maps(const addhip_task_t& t, short* maps) {
+  const int n_obs = t.obs_stride, n_disc = t.disc_stride;
+  for (int i = threadIdx.x; i < n_obs + 2 * n_disc; i += blockDim.x) {
+    int v;
+    if (i < n_obs) v = obs_src(t, i);
+    else if (i < n_obs + n_disc) v = disc_src(t, i - n_obs, false);
+    else v = disc_src(t, i - n_obs - n_disc, true);
+    maps[i] = (short)v;
+  }
 }
 
-struct RowSrc {
-  const float* p[ROWS];
+// ---- per-lane staging role (fixed for the whole kernel): lane l copies floats [9q, 9q+9) of row r = l>>2, q = l&3 ----
+struct Role {
+  int kind;    // K_*
+  float dt;    // time offset of a table row relative to the env's motion time
+  int hslot;   // history slot for K_HIST
+};
+__device__ __forceinline__ Role lane_role(const addhip_task_t& t, int lane, bool fresh, int h0, int h1) {
+  const int r = lane >> 2;
+  Role ro{K_SKIP, 0.0f, 0};
+  if (r == R_SIM) ro.kind = fresh ? K_POSE : K_SIM;
+  else if (r == R_REF) ro.kind = K_POSE;
+  else if (r == R_REFV) ro.kind = K_VEL;
+  else if (r >= R_TAR && r < R_TAR + ADDHIP_MAX_TAR_STEPS) {
+    const int k = r - R_TAR;
+    if (k < t.num_tar_steps) { ro.kind = K_POSE; ro.dt = t.tar_dt[k]; }  // add_observation.py:214-215
+  } else if (r == R_DEMO0 || (r == R_H0 && fresh)) { ro.kind = K_POSE; ro.dt = t.demo_dt[0]; }   // :362-375
+  else if (r == R_DEMO1 || (r == R_H1 && fresh)) { ro.kind = K_POSE; ro.dt = t.demo_dt[1]; }
+  else if (r == R_H0) { ro.kind = K_HIST; ro.hslot = h0; }
+  else if (r == R_H1) { ro.kind = K_HIST; ro.hslot = h1; }
+  return ro;
+}
+
+struct Tables {  // the motion-table fields the per-env code needs
+  const float* pose; const float* vel; const int* clip_start; const int* clip_steps;
+  int total_steps, compat; float dt_inv;
 };
 
-// which global row feeds LDS row r (fresh=1: state just (re)initialised from the clip)
-__device__ __forceinline__ const float* row_ptr(const addhip_motion_t& m, const addhip_task_t& t, const addhip_env_t& e,
-                                                int env, int r, int id, float tm, int head_old0, int head_old1, bool fresh) {
-  if (r == R_REF || (fresh && r == R_SIM)) return m.pose + (size_t)step_index(m, id, tm) * PW;
-  if (r == R_REFV || (fresh && r == R_SIMV)) return m.vel + (size_t)step_index(m, id, tm) * PW;
-  if (r == R_SIM) return e.sim_pose + (size_t)env * PW;
-  if (r == R_SIMV) return e.sim_vel + (size_t)env * PW;
-  if (r >= R_TAR && r < R_TAR + ADDHIP_MAX_TAR_STEPS) {
-    int k = r - R_TAR;
-    if (k >= t.num_tar_steps) k = 0;
-    return m.pose + (size_t)step_index(m, id, __fadd_rn(tm, t.tar_dt[k])) * PW;  // add_observation.py:214-215
+__device__ __forceinline__ void stage_rows(float* w, const Role& ro, const Tables& tb, const float* sim_pose, const float* hist,
+                                           int env, int cstart, int csteps, float tm, int lane) {
+  if (ro.kind == K_SKIP) return;
+  const int q = lane & 3;
+  size_t off;
+  const float* base;
+  if (ro.kind == K_SIM) { base = sim_pose; off = (size_t)env * PW; }
+  else if (ro.kind == K_HIST) { base = hist; off = ((size_t)env * ADDHIP_HIST + ro.hslot) * PW; }
+  else {
+    const int idx = step_index(__fadd_rn(tm, ro.dt), tb.dt_inv, tb.total_steps, cstart, csteps, tb.compat);
+    base = ro.kind == K_POSE ? tb.pose : tb.vel;
+    off = (size_t)idx * PW;
   }
-  if (r == R_DEMO0 || (fresh && r == R_H0)) return m.pose + (size_t)step_index(m, id, __fadd_rn(tm, t.demo_dt[0])) * PW;
-  if (r == R_DEMO1 || (fresh && r == R_H1)) return m.pose + (size_t)step_index(m, id, __fadd_rn(tm, t.demo_dt[1])) * PW;
-  if (r == R_H0) return e.hist + ((size_t)env * ADDHIP_HIST + head_old0) * PW;
-  return e.hist + ((size_t)env * ADDHIP_HIST + head_old1) * PW;
-}
-
-__device__ __forceinline__ void stage_rows(float (*rows)[PW], const addhip_motion_t& m, const addhip_task_t& t,
-                                           const addhip_env_t& e, int env, int id, float tm, int h0, int h1, bool fresh, int lane) {
+  const float* src = base + off + q * 9;
+  // nine dword loads (this granularity is only 4-byte aligned); the backend merges them into 16+16+4 byte loads
+  float v[9];
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    int item = lane + 64 * p;
-    if (item < ROWS * 9) {
-      int r = item / 9, part = item - r * 9;
-      const float4* src = reinterpret_cast<const float4*>(row_ptr(m, t, e, env, r, id, tm, h0, h1, fresh));
-      float4 v = src[part];
-      *reinterpret_cast<float4*>(&rows[r][part * 4]) = v;
+  for (int i = 0; i < 9; ++i) v[i] = src[i];
+  float* dst = w + (lane >> 2) * LROW + q * 12;
+  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  dst[8] = v[8];
+}
+
+__device__ __forceinline__ Quat lds_quat(const float* w, int r) {
+  return Quat{w[row_off(r, 3)], w[row_off(r, 4)], w[row_off(r, 5)], w[row_off(r, 6)]};
+}
+
+// per-env arithmetic, once: lane s < 15 -> tangent+normal (torch_util.py:231-242) of quaternion slot s;
+// lanes 16.. -> target position observations (add_observation.py:589-618)
+template <bool GLOBAL>
+__device__ __forceinline__ void derive(const addhip_task_t& t, float* w, int lane) {
+  if (lane < TN_SLOTS) {
+    const int slot = lane;
+    int r;
+    bool local = false;
+    if (slot == TN_CHAR) { r = R_SIM; local = !GLOBAL; }
+    else if (slot < TN_TAR + ADDHIP_MAX_TAR_STEPS) { r = R_TAR + (slot - TN_TAR); local = !GLOBAL; }
+    else r = slot == TN_H0 ? R_H0 : slot == TN_H1 ? R_H1 : slot == TN_SIMG ? R_SIM : slot == TN_D0 ? R_DEMO0 : slot == TN_D1 ? R_DEMO1 : R_REF;
+    Quat q = lds_quat(w, r);
+    if (local) q = quat_mul(heading_quat_inv(lds_quat(w, slot == TN_CHAR ? R_SIM : R_TAR)), q);
+    const Vec3 tan = quat_rotate(q, Vec3{1.0f, 0.0f, 0.0f}), nrm = quat_rotate(q, Vec3{0.0f, 0.0f, 1.0f});
+    float* d = w + OFF_TN + slot * 6;
+    d[0] = tan.x; d[1] = tan.y; d[2] = tan.z; d[3] = nrm.x; d[4] = nrm.y; d[5] = nrm.z;
+  } else if (lane >= 16 && lane < 16 + t.num_tar_steps * 3) {
+    const int i = lane - 16, k = i / 3, c = i - k * 3;
+    const int r = R_TAR + k;
+    float v;
+    if (c == 2) v = w[row_off(r, 2)];  // add_observation.py:615-616 absolute height
+    else if (GLOBAL) v = w[row_off(r, c)] - w[row_off(R_SIM, c)];
+    else {
+      Vec3 d{w[row_off(r, 0)] - w[row_off(R_TAR, 0)], w[row_off(r, 1)] - w[row_off(R_TAR, 1)], w[row_off(r, 2)] - w[row_off(R_TAR, 2)]};
+      const Vec3 rr = quat_rotate(heading_quat_inv(lds_quat(w, R_TAR)), d);
+      v = c == 0 ? rr.x : rr.y;
     }
+    w[OFF_TP + i] = v;
+  } else if (lane == 63) {
+    w[OFF_ZERO] = 0.0f;
   }
 }
 
-__device__ __forceinline__ void emit_obs(const addhip_task_t& t, const float (*rows)[PW], int env, int lane,
-                                         float* obs, float* obs2, float* disc, float* demo) {
-  if (obs || obs2) {
-    for (int o = lane; o < t.obs_stride; o += 64) {
-      float v = o < t.obs_dim ? obs_elem(t, rows, o) : 0.0f;
-      if (obs) obs[(size_t)env * t.obs_stride + o] = v;
-      if (obs2) obs2[(size_t)env * t.obs_stride + o] = v;
-    }
-  }
-  if (disc) {
-    for (int o = lane; o < t.disc_stride; o += 64)
-      disc[(size_t)env * t.disc_stride + o] = o < t.disc_dim ? disc_elem(t, rows[R_H0], rows[R_H1], rows[R_SIM], o) : 0.0f;
-  }
-  if (demo) {
-    for (int o = lane; o < t.disc_stride; o += 64)
-      demo[(size_t)env * t.disc_stride + o] = o < t.disc_dim ? disc_elem(t, rows[R_DEMO0], rows[R_DEMO1], rows[R_REF], o) : 0.0f;
-  }
+__device__ __forceinline__ void emit(const float* w, const short* map, int n, float* out, int lane) {
+  for (int o = lane; o < n; o += 64) out[o] = w[map[o]];
 }
 
-__global__ __launch_bounds__(64 * WAVES) void env_step_kernel(addhip_motion_t m, addhip_task_t t, addhip_env_t e,
-                                                              addhip_step_out_t o, int head) {
-  __shared__ __attribute__((aligned(16))) float lds[WAVES][ROWS][PW];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float(*rows)[PW] = lds[w];
-  const int groups = (e.num_envs + WAVES - 1) / WAVES;
-  const int h0 = (head + 1) % ADDHIP_HIST, h1 = (head + 2) % ADDHIP_HIST;
+struct ObsArgs {
+  Tables tb;
+  const float* sim_pose; const float* time; const float* time_off; const int* motion_id; float* hist;
+  float* ref_pose; float* ref_vel;
+  float* obs; float* obs2; float* disc; float* demo;
+  int num_envs, head;
+};
+
+template <bool GLOBAL>
+__global__ __launch_bounds__(64 * WAVES) void env_obs_kernel(addhip_task_t t, ObsArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[WAVES][WORK];
+  __shared__ short maps[MAP_MAX];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* w = lds[wv];
+  build_maps(t, maps);
+  const int h0 = (a.head + 1) % ADDHIP_HIST, h1 = (a.head + 2) % ADDHIP_HIST;
+  const Role ro = lane_role(t, lane, false, h0, h1);
+  const int n_obs = t.obs_stride, n_disc = t.disc_stride;
+  const int groups = (a.num_envs + WAVES - 1) / WAVES;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
-    const int env = g * WAVES + w;
-    const bool valid = env < e.num_envs;
-    float time_new = 0.0f, tm = 0.0f;
-    int id = 0;
+    const int env = g * WAVES + wv;
+    const bool valid = env < a.num_envs;
     if (valid) {
-      time_new = __fadd_rn(e.time[env], t.dt);            // env.py:155
-      id = e.motion_id[env];
-      tm = __fadd_rn(time_new, e.time_off[env]);          // add_observation.py:352-354
-      stage_rows(rows, m, t, e, env, id, tm, h0, h1, false, lane);
+      const float time_new = __fadd_rn(a.time[env], t.dt);     // env.py:155 (written back by env_reward_kernel)
+      const int id = a.motion_id[env];
+      const float tm = __fadd_rn(time_new, a.time_off[env]);   // add_observation.py:352-354
+      stage_rows(w, ro, a.tb, a.sim_pose, a.hist, env, a.tb.clip_start[id], a.tb.clip_steps[id], tm, lane);
     }
     __syncthreads();
+    if (valid) derive<GLOBAL>(t, w, lane);
+    __syncthreads();
     if (valid) {
-      emit_obs(t, rows, env, lane, o.obs, o.obs_next_in, o.disc_obs, o.disc_demo);
-      // history push (circular_buffer.py:17-20) and reference state (add_observation.py:163-174)
+      if (a.obs) emit(w, maps, n_obs, a.obs + (size_t)env * n_obs, lane);
+      if (a.obs2) emit(w, maps, n_obs, a.obs2 + (size_t)env * n_obs, lane);
+      if (a.disc) emit(w, maps + n_obs, n_disc, a.disc + (size_t)env * n_disc, lane);
+      if (a.demo) emit(w, maps + n_obs + n_disc, n_disc, a.demo + (size_t)env * n_disc, lane);
       if (lane < PW) {
-        e.hist[((size_t)env * ADDHIP_HIST + head) * PW + lane] = rows[R_SIM][lane];
-        if (e.ref_pose) e.ref_pose[(size_t)env * PW + lane] = rows[R_REF][lane];
-        if (e.ref_vel) e.ref_vel[(size_t)env * PW + lane] = rows[R_REFV][lane];
-      }
-      // ---- reward (add_reward.py:103-177), joint weights are all 1 (add_reward.py:31-34)
-      float pe = 0.0f, ve = 0.0f;
-      if (lane < ADDHIP_NUM_DOF) {
-        float d = rows[R_REF][7 + lane] - rows[R_SIM][7 + lane];
-        pe = d * d;
-        float dv = rows[R_REFV][6 + lane] - rows[R_SIMV][6 + lane];
-        ve = dv * dv;
-      }
-      pe = wave_sum(pe);
-      ve = wave_sum(ve);
-      const float* sim = rows[R_SIM];
-      const float* ref = rows[R_REF];
-      const bool track_root = (t.num_tar_steps > 0) && t.global_obs;  // add_observation.py:349-350
-      float dx = ref[0] - sim[0], dy = ref[1] - sim[1], dz = ref[2] - sim[2];
-      float root_err_full = dx * dx + dy * dy + dz * dz;
-      float rx = track_root ? dx : 0.0f, ry = track_root ? dy : 0.0f, rz = t.root_height_obs ? dz : 0.0f;
-      float root_pos_err = rx * rx + ry * ry + rz * rz;
-      Quat q_sim = row_quat(sim), q_ref = row_quat(ref);
-      Vec3 v_sim{rows[R_SIMV][0], rows[R_SIMV][1], rows[R_SIMV][2]}, w_sim{rows[R_SIMV][3], rows[R_SIMV][4], rows[R_SIMV][5]};
-      Vec3 v_ref{rows[R_REFV][0], rows[R_REFV][1], rows[R_REFV][2]}, w_ref{rows[R_REFV][3], rows[R_REFV][4], rows[R_REFV][5]};
-      if (!track_root) {  // convert_to_local_root (add_reward.py:91-101)
-        Quat hs = heading_quat_inv(q_sim), hr = heading_quat_inv(q_ref);
-        v_sim = quat_rotate(hs, v_sim); w_sim = quat_rotate(hs, w_sim); q_sim = quat_mul(hs, q_sim);
-        v_ref = quat_rotate(hr, v_ref); w_ref = quat_rotate(hr, w_ref); q_ref = quat_mul(hr, q_ref);
-      }
-      float rot_err = quat_diff_angle(q_sim, q_ref);
-      rot_err *= rot_err;
-      float vx = v_ref.x - v_sim.x, vy = v_ref.y - v_sim.y, vz = v_ref.z - v_sim.z;
-      float root_vel_err = vx * vx + vy * vy + vz * vz;
-      float ax = w_ref.x - w_sim.x, ay = w_ref.y - w_sim.y, az = w_ref.z - w_sim.z;
-      float root_ang_err = ax * ax + ay * ay + az * az;
-      float r = t.pose_w * expf(-t.pose_scale * pe) + t.vel_w * expf(-t.vel_scale * ve) +
-                t.root_pose_w * expf(-t.root_pose_scale * (root_pos_err + 0.1f * rot_err)) +
-                t.root_vel_w * expf(-t.root_vel_scale * (root_vel_err + 0.1f * root_ang_err));
-      // ---- done (add_done.py:96-147)
-      if (lane == 0) {
-        int done = ADDHIP_DONE_NULL;
-        if (time_new >= t.max_episode_length) done = ADDHIP_DONE_TIME;
-        if (tm >= m.clip_len[id] && m.clip_loop[id] != 1) done = ADDHIP_DONE_SUCC;
-        if (t.enable_early_termination) {
-          bool failed = e.contact ? (e.contact[env] != 0) : false;
-          if (t.pose_termination) {
-            bool pose_fail = (pe / (float)ADDHIP_NUM_DOF) > t.pose_termination_dist;
-            if (track_root) pose_fail = pose_fail || (root_err_full > t.pose_termination_dist);
-            failed = failed || pose_fail;
-          }
-          if (failed && time_new > 0.0f) done = ADDHIP_DONE_FAIL;
-        }
-        e.time[env] = time_new;
-        e.done[env] = done;
-        if (o.done) o.done[env] = done;
-        if (o.reward) o.reward[env] = r;
-        if (o.motion_id_rec) o.motion_id_rec[env] = id;
-        if (o.motion_time_rec) o.motion_time_rec[env] = tm;
-        if (e.ret_acc) {  // ReturnTracker.update (base_agent.py:596-621)
-          float ra = e.ret_acc[env] + r;
-          int la = e.len_acc[env] + 1;
-          if (done != ADDHIP_DONE_NULL) {
-            if (o.ep_stats) {
-              atomicAdd(&o.ep_stats[0], ra);
-              atomicAdd(&o.ep_stats[1], (float)la);
-              atomicAdd(&o.ep_stats[2], 1.0f);
-            }
-            ra = 0.0f;
-            la = 0;
-          }
-          e.ret_acc[env] = ra;
-          e.len_acc[env] = la;
-        }
+        // history push (circular_buffer.py:17-20) and reference state (add_observation.py:163-174)
+        a.hist[((size_t)env * ADDHIP_HIST + a.head) * PW + lane] = w[row_off(R_SIM, lane)];
+        a.ref_pose[(size_t)env * PW + lane] = w[row_off(R_REF, lane)];
+        a.ref_vel[(size_t)env * PW + lane] = w[row_off(R_REFV, lane)];
       }
     }
     __syncthreads();
+  }
+}
+
+// ---- reward (add_reward.py:103-177), done (add_done.py:96-147), return tracker (base_agent.py:596-621) ---------
+struct RewardArgs {
+  const float* sim_pose; const float* sim_vel; const float* ref_pose; const float* ref_vel;
+  float* time; const float* time_off; const int* motion_id; int* done; const unsigned char* contact;
+  const float* clip_len; const int* clip_loop;
+  float* ret_acc; int* len_acc;
+  float* reward; int* done_rec; int* motion_id_rec; float* motion_time_rec; float* ep_stats;
+  int num_envs;
+};
+
+template <bool GLOBAL>
+__global__ __launch_bounds__(256) void env_reward_kernel(addhip_task_t t, RewardArgs a) {
+  const int l = threadIdx.x & 15;
+  const int env = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const bool valid = env < a.num_envs;
+  const int e = valid ? env : a.num_envs - 1;
+  const float* sp = a.sim_pose + (size_t)e * PW;
+  const float* sv = a.sim_vel + (size_t)e * PW;
+  const float* rp = a.ref_pose + (size_t)e * PW;
+  const float* rv = a.ref_vel + (size_t)e * PW;
+  // joint weights are all 1 (add_reward.py:31-34); lanes cover dofs l and l+16
+  float pe = 0.0f, ve = 0.0f;
+  {
+    float d = rp[7 + l] - sp[7 + l];
+    pe = d * d;
+    float dv = rv[6 + l] - sv[6 + l];
+    ve = dv * dv;
+    if (l + 16 < ADDHIP_NUM_DOF) {
+      d = rp[7 + 16 + l] - sp[7 + 16 + l];
+      pe += d * d;
+      dv = rv[6 + 16 + l] - sv[6 + 16 + l];
+      ve += dv * dv;
+    }
+  }
+  pe = group_sum16(pe);
+  ve = group_sum16(ve);
+  if (l != 0 || !valid) return;
+  const bool track_root = (t.num_tar_steps > 0) && GLOBAL;  // add_observation.py:349-350
+  const float dx = rp[0] - sp[0], dy = rp[1] - sp[1], dz = rp[2] - sp[2];
+  const float root_err_full = dx * dx + dy * dy + dz * dz;
+  const float rx = track_root ? dx : 0.0f, ry = track_root ? dy : 0.0f, rz = t.root_height_obs ? dz : 0.0f;
+  const float root_pos_err = rx * rx + ry * ry + rz * rz;
+  Quat q_sim{sp[3], sp[4], sp[5], sp[6]}, q_ref{rp[3], rp[4], rp[5], rp[6]};
+  Vec3 v_sim{sv[0], sv[1], sv[2]}, w_sim{sv[3], sv[4], sv[5]}, v_ref{rv[0], rv[1], rv[2]}, w_ref{rv[3], rv[4], rv[5]};
+  if (!track_root) {  // convert_to_local_root (add_reward.py:91-101)
+    const Quat hs = heading_quat_inv(q_sim), hr = heading_quat_inv(q_ref);
+    v_sim = quat_rotate(hs, v_sim); w_sim = quat_rotate(hs, w_sim); q_sim = quat_mul(hs, q_sim);
+    v_ref = quat_rotate(hr, v_ref); w_ref = quat_rotate(hr, w_ref); q_ref = quat_mul(hr, q_ref);
+  }
+  float rot_err = quat_diff_angle(q_sim, q_ref);
+  rot_err *= rot_err;
+  const float vx = v_ref.x - v_sim.x, vy = v_ref.y - v_sim.y, vz = v_ref.z - v_sim.z;
+  const float root_vel_err = vx * vx + vy * vy + vz * vz;
+  const float ax = w_ref.x - w_sim.x, ay = w_ref.y - w_sim.y, az = w_ref.z - w_sim.z;
+  const float root_ang_err = ax * ax + ay * ay + az * az;
+  const float r = t.pose_w * expf(-t.pose_scale * pe) + t.vel_w * expf(-t.vel_scale * ve) +
+                  t.root_pose_w * expf(-t.root_pose_scale * (root_pos_err + 0.1f * rot_err)) +
+                  t.root_vel_w * expf(-t.root_vel_scale * (root_vel_err + 0.1f * root_ang_err));
+  const float time_new = __fadd_rn(a.time[env], t.dt);
+  const int id = a.motion_id[env];
+  const float tm = __fadd_rn(time_new, a.time_off[env]);
+  int done = ADDHIP_DONE_NULL;
+  if (time_new >= t.max_episode_length) done = ADDHIP_DONE_TIME;
+  if (tm >= a.clip_len[id] && a.clip_loop[id] != 1) done = ADDHIP_DONE_SUCC;
+  if (t.enable_early_termination) {
+    bool failed = a.contact ? (a.contact[env] != 0) : false;
+    if (t.pose_termination) {
+      bool pose_fail = (pe / (float)ADDHIP_NUM_DOF) > t.pose_termination_dist;
+      if (track_root) pose_fail = pose_fail || (root_err_full > t.pose_termination_dist);
+      failed = failed || pose_fail;
+    }
+    if (failed && time_new > 0.0f) done = ADDHIP_DONE_FAIL;
+  }
+  a.time[env] = time_new;
+  a.done[env] = done;
+  if (a.done_rec) a.done_rec[env] = done;
+  if (a.reward) a.reward[env] = r;
+  if (a.motion_id_rec) a.motion_id_rec[env] = id;
+  if (a.motion_time_rec) a.motion_time_rec[env] = tm;
+  if (a.ret_acc) {
+    float ra = a.ret_acc[env] + r;
+    int la = a.len_acc[env] + 1;
+    if (done != ADDHIP_DONE_NULL) {
+      if (a.ep_stats) {
+        atomicAdd(&a.ep_stats[0], ra);
+        atomicAdd(&a.ep_stats[1], (float)la);
+        atomicAdd(&a.ep_stats[2], 1.0f);
+      }
+      ra = 0.0f;
+      la = 0;
+    }
+    a.ret_acc[env] = ra;
+    a.len_acc[env] = la;
   }
 }
 
 // ---- reset phase 1: clip draw (MotionLib.sample_motions, motion_lib.py:35-39) + batch temperature
-__global__ void reset_draw_kernel(addhip_motion_t m, addhip_env_t e, addhip_sampler_t s, const float* u_clip, int reset_all) {
-  int env = blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= e.num_envs) return;
-  if (!reset_all && e.done[env] == ADDHIP_DONE_NULL) return;
-  float u = u_clip[env];
+__global__ void reset_draw_kernel(int num_envs, int num_clips, const int* done, int* motion_id, addhip_sampler_t s, const float* u_clip,
+                                  int reset_all) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= num_envs) return;
+  if (!reset_all && done[env] == ADDHIP_DONE_NULL) return;
+  const float u = u_clip[env];
   int id = 0;
-  while (id < m.num_clips - 1 && !(u < s.clip_cdf[id])) ++id;
-  e.motion_id[env] = id;
+  while (id < num_clips - 1 && !(u < s.clip_cdf[id])) ++id;
+  motion_id[env] = id;
   if (s.temperature <= 0.0f) {
     float mx = 0.0f;  // errors are >= 0
     for (int k = 0; k < s.num_segments; ++k) mx = fmaxf(mx, s.errors[id * s.num_segments + k]);
@@ -276,7 +363,7 @@ __global__ void reset_draw_kernel(addhip_motion_t m, addhip_env_t e, addhip_samp
 
 // c10::div_floor_floating, the arithmetic behind `time // dt` (sampler.py:88)
 __device__ __forceinline__ float floor_div_f32(float a, float b) {
-  float mod = fmodf(a, b);
+  const float mod = fmodf(a, b);
   float div = __fdiv_rn(__fsub_rn(a, mod), b);
   if (mod != 0.0f && ((b < 0.0f) != (mod < 0.0f))) div = __fsub_rn(div, 1.0f);
   if (div != 0.0f) {
@@ -287,67 +374,82 @@ __device__ __forceinline__ float floor_div_f32(float a, float b) {
   return copysignf(0.0f, __fdiv_rn(a, b));
 }
 
+struct ResetArgs {
+  Tables tb;
+  float* sim_pose; float* sim_vel; float* time; float* time_off; const int* motion_id; float* hist; int* done;
+  float* ref_pose; float* ref_vel;
+  const float* u_seg; const float* u_jit;
+  float* obs; float* disc; float* demo;
+  int num_envs, head, reset_all;
+};
+
 // ---- reset phase 2: start time, state from the clip, history refill, observations
-__global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_motion_t m, addhip_task_t t, addhip_env_t e, addhip_sampler_t s,
-                                                               const float* u_seg, const float* u_jit, float* obs_out,
-                                                               float* disc_out, float* demo_out, int reset_all, int head) {
-  __shared__ __attribute__((aligned(16))) float lds[WAVES][ROWS][PW];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float(*rows)[PW] = lds[w];
-  const int groups = (e.num_envs + WAVES - 1) / WAVES;
+template <bool GLOBAL>
+__global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_task_t t, addhip_sampler_t s, ResetArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[WAVES][WORK];
+  __shared__ short maps[MAP_MAX];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* w = lds[wv];
+  build_maps(t, maps);
+  const Role ro = lane_role(t, lane, true, 0, 0);
+  const int n_obs = t.obs_stride, n_disc = t.disc_stride;
+  const int groups = (a.num_envs + WAVES - 1) / WAVES;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
-    const int env = g * WAVES + w;
-    const bool active = env < e.num_envs && (reset_all || e.done[env] != ADDHIP_DONE_NULL);
-    int id = 0;
+    const int env = g * WAVES + wv;
+    const bool active = env < a.num_envs && (a.reset_all || a.done[env] != ADDHIP_DONE_NULL);
     float off = 0.0f;
     if (active) {
-      id = e.motion_id[env];
+      const int id = a.motion_id[env];
       if (s.rand_reset) {
         // AdaptiveSegmentSampler.get_probs + multinomial by inverse CDF (sampler.py:57-80)
         const int S = s.num_segments;
-        float temp = s.temperature > 0.0f ? s.temperature : __fadd_rn(__uint_as_float(*s.temp_bits), 1e-6f);
-        float z = lane < S ? s.errors[id * S + lane] / temp : -INFINITY;
-        float zmax = wave_max(z);
-        float ez = lane < S ? expf(z - zmax) : 0.0f;
-        float p = ez / wave_sum(ez);
+        const float temp = s.temperature > 0.0f ? s.temperature : __fadd_rn(__uint_as_float(*s.temp_bits), 1e-6f);
+        const float z = lane < S ? s.errors[id * S + lane] / temp : -INFINITY;
+        const float zmax = wave_max(z);
+        const float ez = lane < S ? expf(z - zmax) : 0.0f;
+        const float p = ez / wave_sum(ez);
         float cdf = p;  // inclusive scan over the first S lanes
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-          float up = __shfl_up(cdf, d, 64);
+          const float up = __shfl_up(cdf, d, 64);
           if (lane >= d) cdf += up;
         }
-        float u = u_seg[env];
-        unsigned long long below = __ballot(lane < S && !(u < cdf));
-        int seg = __popcll(below);
+        const float u = a.u_seg[env];
+        int seg = __popcll(__ballot(lane < S && !(u < cdf)));
         if (seg > S - 1) seg = S - 1;
-        float ss = s.seg_size[id];
-        float tt = __fmul_rn((float)seg, ss);                 // sampler.py:81-82
-        tt = __fadd_rn(tt, __fmul_rn(u_jit[env], ss));        // :84-85
-        tt = __fmul_rn(floor_div_f32(tt, t.dt), t.dt);        // :88
-        off = fmaxf(tt, s.min_start_time);                    // :91
+        const float ss = s.seg_size[id];
+        float tt = __fmul_rn((float)seg, ss);                   // sampler.py:81-82
+        tt = __fadd_rn(tt, __fmul_rn(a.u_jit[env], ss));        // :84-85
+        tt = __fmul_rn(floor_div_f32(tt, t.dt), t.dt);          // :88
+        off = fmaxf(tt, s.min_start_time);                      // :91
       }
       // time_buf = 0 (env.py:161) -> motion time == offset
-      stage_rows(rows, m, t, e, env, id, off, 0, 0, true, lane);
+      stage_rows(w, ro, a.tb, nullptr, nullptr, env, a.tb.clip_start[id], a.tb.clip_steps[id], off, lane);
     }
     __syncthreads();
+    if (active) derive<GLOBAL>(t, w, lane);
+    __syncthreads();
     if (active) {
-      emit_obs(t, rows, env, lane, obs_out, nullptr, disc_out, demo_out);
+      if (a.obs) emit(w, maps, n_obs, a.obs + (size_t)env * n_obs, lane);
+      if (a.disc) emit(w, maps + n_obs, n_disc, a.disc + (size_t)env * n_disc, lane);
+      if (a.demo) emit(w, maps + n_obs + n_disc, n_disc, a.demo + (size_t)env * n_disc, lane);
       if (lane < PW) {
+        const float pose = w[row_off(R_REF, lane)], vel = w[row_off(R_REFV, lane)];
         // set_qpos / set_dofs_velocity payload (add_observation.py:314-331) straight into the simulator state
-        e.sim_pose[(size_t)env * PW + lane] = rows[R_REF][lane];
-        e.sim_vel[(size_t)env * PW + lane] = rows[R_REFV][lane];
-        if (e.ref_pose) e.ref_pose[(size_t)env * PW + lane] = rows[R_REF][lane];
-        if (e.ref_vel) e.ref_vel[(size_t)env * PW + lane] = rows[R_REFV][lane];
+        a.sim_pose[(size_t)env * PW + lane] = pose;
+        a.sim_vel[(size_t)env * PW + lane] = vel;
+        if (a.ref_pose) a.ref_pose[(size_t)env * PW + lane] = pose;
+        if (a.ref_vel) a.ref_vel[(size_t)env * PW + lane] = vel;
         // CircularBuffer.fill (circular_buffer.py:22-29): get_all() order = demo frames t-2dt, t-dt, t
-        float* hb = e.hist + (size_t)env * ADDHIP_HIST * PW;
-        hb[((head + 0) % ADDHIP_HIST) * PW + lane] = rows[R_DEMO0][lane];
-        hb[((head + 1) % ADDHIP_HIST) * PW + lane] = rows[R_DEMO1][lane];
-        hb[((head + 2) % ADDHIP_HIST) * PW + lane] = rows[R_REF][lane];
+        float* hb = a.hist + (size_t)env * ADDHIP_HIST * PW;
+        hb[((a.head + 0) % ADDHIP_HIST) * PW + lane] = w[row_off(R_DEMO0, lane)];
+        hb[((a.head + 1) % ADDHIP_HIST) * PW + lane] = w[row_off(R_DEMO1, lane)];
+        hb[((a.head + 2) % ADDHIP_HIST) * PW + lane] = pose;
       }
       if (lane == 0) {
-        e.time[env] = 0.0f;
-        e.time_off[env] = off;
-        e.done[env] = ADDHIP_DONE_NULL;  // add_done.py:92-93
+        a.time[env] = 0.0f;
+        a.time_off[env] = off;
+        a.done[env] = ADDHIP_DONE_NULL;  // add_done.py:92-93
       }
     }
     __syncthreads();
@@ -355,10 +457,11 @@ __global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_motion_t m
 }
 
 __global__ void lookup_kernel(addhip_motion_t m, const int* ids, const float* times, int count, int* idx_out, float* pose_out, float* vel_out) {
-  int q = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-  int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (q >= count) return;
-  int idx = step_index(m, ids[q], times[q]);
+  const int id = ids[q];
+  const int idx = step_index(times[q], m.dt_inv, m.total_steps, m.clip_start[id], m.clip_steps[id], m.reference_compat);
   if (lane == 0 && idx_out) idx_out[q] = idx;
   if (lane < PW) {
     if (pose_out) pose_out[(size_t)q * PW + lane] = m.pose[(size_t)idx * PW + lane];
@@ -367,11 +470,11 @@ __global__ void lookup_kernel(addhip_motion_t m, const int* ids, const float* ti
 }
 
 __global__ void kin_engine_step_kernel(float* sim_pose, float* sim_vel, const float* target, int tstride, int n, float lag, float dt) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * ADDHIP_NUM_DOF) return;
-  int env = i / ADDHIP_NUM_DOF, j = i - env * ADDHIP_NUM_DOF;
-  float q = sim_pose[(size_t)env * PW + 7 + j];
-  float qn = __fadd_rn(q, __fmul_rn(lag, __fsub_rn(target[(size_t)env * tstride + j], q)));
+  const int env = i / ADDHIP_NUM_DOF, j = i - env * ADDHIP_NUM_DOF;
+  const float q = sim_pose[(size_t)env * PW + 7 + j];
+  const float qn = __fadd_rn(q, __fmul_rn(lag, __fsub_rn(target[(size_t)env * tstride + j], q)));
   sim_vel[(size_t)env * PW + 6 + j] = __fdiv_rn(__fsub_rn(qn, q), dt);
   sim_pose[(size_t)env * PW + 7 + j] = qn;
 }
@@ -381,6 +484,7 @@ int check_common(const addhip_motion_t* m, const addhip_task_t* t, const addhip_
   ADDHIP_REQUIRE(e->num_envs > 0, "num_envs must be > 0");
   ADDHIP_REQUIRE(m->pose && m->vel && m->clip_start && m->clip_len && m->clip_loop && m->clip_steps, "motion tables missing");
   ADDHIP_REQUIRE(m->total_steps > 0 && m->num_clips > 0, "empty motion library");
+  ADDHIP_REQUIRE((long long)e->num_envs * ADDHIP_HIST * PW < (1ll << 31), "env count too large for 32-bit row offsets");
   ADDHIP_REQUIRE(t->num_tar_steps >= 0 && t->num_tar_steps <= ADDHIP_MAX_TAR_STEPS, "num_tar_steps out of range");
   ADDHIP_REQUIRE(t->demo_dt[ADDHIP_HIST - 1] == 0.0f, "demo_dt[last] must be 0 (newest demo frame == reference frame)");
   const int hc = t->root_height_obs ? 1 : 0;
@@ -388,15 +492,18 @@ int check_common(const addhip_motion_t* m, const addhip_task_t* t, const addhip_
   ADDHIP_REQUIRE(t->obs_dim == want, "obs_dim %d does not match the task flags (expected %d)", t->obs_dim, want);
   ADDHIP_REQUIRE(t->disc_dim == ADDHIP_HIST * (9 + ADDHIP_NUM_DOF), "disc_dim must be %d", ADDHIP_HIST * (9 + ADDHIP_NUM_DOF));
   ADDHIP_REQUIRE(t->obs_stride >= t->obs_dim && t->disc_stride >= t->disc_dim, "strides smaller than dims");
-  ADDHIP_REQUIRE(e->sim_pose && e->sim_vel && e->time && e->time_off && e->motion_id && e->hist && e->done, "env state pointers missing");
-  ADDHIP_REQUIRE(aligned16(m->pose) && aligned16(m->vel) && aligned16(e->sim_pose) && aligned16(e->sim_vel) && aligned16(e->hist),
-                 "row buffers must be 16-byte aligned");
+  ADDHIP_REQUIRE(t->obs_stride + 2 * t->disc_stride <= MAP_MAX, "obs_stride + 2*disc_stride must be <= %d", MAP_MAX);
+  ADDHIP_REQUIRE(e->sim_pose && e->sim_vel && e->time && e->time_off && e->motion_id && e->hist && e->done && e->ref_pose && e->ref_vel,
+                 "env state pointers missing");
   return 0;
 }
 
+inline Tables tables_of(const addhip_motion_t* m) {
+  return Tables{m->pose, m->vel, m->clip_start, m->clip_steps, m->total_steps, m->reference_compat, m->dt_inv};
+}
 inline int env_grid(int num_envs) {
-  int groups = (num_envs + WAVES - 1) / WAVES;
-  return groups < 2048 ? groups : 2048;
+  const int groups = (num_envs + WAVES - 1) / WAVES;
+  return groups < 4096 ? groups : 4096;
 }
 
 }  // namespace
@@ -406,8 +513,19 @@ extern "C" int addhip_env_step(const addhip_motion_t* m, const addhip_task_t* t,
   if (int rc = check_common(m, t, e)) return rc;
   ADDHIP_REQUIRE(o, "null outputs");
   ADDHIP_REQUIRE(head >= 0 && head < ADDHIP_HIST, "head out of range");
-  hipLaunchKernelGGL(env_step_kernel, dim3(env_grid(e->num_envs)), dim3(64 * WAVES), 0, (hipStream_t)stream, *m, *t, *e, *o, head);
-  return check_launch("env_step_kernel");
+  hipStream_t st = (hipStream_t)stream;
+  ObsArgs a{tables_of(m), e->sim_pose, e->time, e->time_off, e->motion_id, e->hist, e->ref_pose, e->ref_vel,
+            o->obs, o->obs_next_in, o->disc_obs, o->disc_demo, e->num_envs, head};
+  if (t->global_obs) hipLaunchKernelGGL(env_obs_kernel<true>, dim3(env_grid(e->num_envs)), dim3(64 * WAVES), 0, st, *t, a);
+  else hipLaunchKernelGGL(env_obs_kernel<false>, dim3(env_grid(e->num_envs)), dim3(64 * WAVES), 0, st, *t, a);
+  if (int rc = check_launch("env_obs_kernel")) return rc;
+  RewardArgs r{e->sim_pose, e->sim_vel, e->ref_pose, e->ref_vel, e->time, e->time_off, e->motion_id, e->done, e->contact,
+               m->clip_len, m->clip_loop, e->ret_acc, e->len_acc, o->reward, o->done, o->motion_id_rec, o->motion_time_rec, o->ep_stats,
+               e->num_envs};
+  const int blocks = (e->num_envs * 16 + 255) / 256;
+  if (t->global_obs) hipLaunchKernelGGL(env_reward_kernel<true>, dim3(blocks), dim3(256), 0, st, *t, r);
+  else hipLaunchKernelGGL(env_reward_kernel<false>, dim3(blocks), dim3(256), 0, st, *t, r);
+  return check_launch("env_reward_kernel");
 }
 
 extern "C" int addhip_env_reset(const addhip_motion_t* m, const addhip_task_t* t, const addhip_env_t* e,
@@ -421,10 +539,13 @@ extern "C" int addhip_env_reset(const addhip_motion_t* m, const addhip_task_t* t
   ADDHIP_REQUIRE(head >= 0 && head < ADDHIP_HIST, "head out of range");
   hipStream_t st = (hipStream_t)stream;
   ADDHIP_HIP(hipMemsetAsync(s->temp_bits, 0, sizeof(uint32_t), st));
-  hipLaunchKernelGGL(reset_draw_kernel, dim3((e->num_envs + 255) / 256), dim3(256), 0, st, *m, *e, *s, u_clip, reset_all);
+  hipLaunchKernelGGL(reset_draw_kernel, dim3((e->num_envs + 255) / 256), dim3(256), 0, st, e->num_envs, m->num_clips, e->done, e->motion_id, *s,
+                     u_clip, reset_all);
   if (int rc = check_launch("reset_draw_kernel")) return rc;
-  hipLaunchKernelGGL(env_reset_kernel, dim3(env_grid(e->num_envs)), dim3(64 * WAVES), 0, st, *m, *t, *e, *s, u_seg, u_jit, obs_out,
-                     disc_obs_out, disc_demo_out, reset_all, head);
+  ResetArgs a{tables_of(m), e->sim_pose, e->sim_vel, e->time, e->time_off, e->motion_id, e->hist, e->done, e->ref_pose, e->ref_vel,
+              u_seg, u_jit, obs_out, disc_obs_out, disc_demo_out, e->num_envs, head, reset_all};
+  if (t->global_obs) hipLaunchKernelGGL(env_reset_kernel<true>, dim3(env_grid(e->num_envs)), dim3(64 * WAVES), 0, st, *t, *s, a);
+  else hipLaunchKernelGGL(env_reset_kernel<false>, dim3(env_grid(e->num_envs)), dim3(64 * WAVES), 0, st, *t, *s, a);
   return check_launch("env_reset_kernel");
 }
 
@@ -438,7 +559,7 @@ extern "C" int addhip_motion_lookup(const addhip_motion_t* m, const int32_t* ids
 extern "C" int addhip_kin_engine_step(float* sim_pose, float* sim_vel, const float* target, int32_t target_stride, int32_t num_envs,
                                       float lag, float dt, void* stream) {
   ADDHIP_REQUIRE(sim_pose && sim_vel && target && num_envs > 0 && target_stride >= ADDHIP_NUM_DOF, "bad engine-step arguments");
-  int n = num_envs * ADDHIP_NUM_DOF;
+  const int n = num_envs * ADDHIP_NUM_DOF;
   hipLaunchKernelGGL(kin_engine_step_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sim_pose, sim_vel, target,
                      target_stride, num_envs, lag, dt);
   return check_launch("kin_engine_step_kernel");
