@@ -66,7 +66,21 @@ def time_gemms(agent, reps=3):
     return dict(launches=len(calls), flops=flops, ms=ms)
 
 
+def env_step_at_scale(num_envs=65536):
+    """The fused env step alone at a size where it is not launch-latency bound (same kernels, same task config)."""
+    import add_gym_amd  # noqa: F401
+    from add_gym_amd.config import load_config
+    from add_gym_amd.learning.add_agent import ADDAgent
+
+    cfg = load_config("train", [f"engine.num_envs={num_envs}", "agent.steps_per_iter=2", "agent.batch_size=1", "task.motion_file=synthetic:1x3600"])
+    ag = ADDAgent(cfg)
+    ag.reset_all_envs()
+    ag._init_train()
+    return time_env_step(ag, reps=50)
+
+
 def time_env_step(agent, reps=20):
+    """Average duration of addhip_env_step (env_obs_kernel + env_reward_kernel), HIP events on the launch stream."""
     import torch
     import add_gym_amd._lib as L
 
@@ -196,8 +210,17 @@ def main():
                            "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"]}
         ms = time_env_step(agent)
         gbs = ENV_STEP_BYTES * agent.N / (ms * 1e-3) / 1e9
-        out["roofline_env_step"] = {"bound": "hbm", "kernel": "env_step_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "us_per_launch": ms * 1e3, "envs": agent.N}
+        out["roofline_env_step"] = {"bound": "hbm", "kernel": "env_obs_kernel + env_reward_kernel (addhip_env_step)", "achieved": gbs,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "us_per_launch": ms * 1e3,
+                                    "envs": agent.N, "note": "launch-latency scale at this env count; see roofline_env_step_65536"}
+        if world == 1:
+            big = 65536
+            ms2 = env_step_at_scale(big)
+            gbs2 = ENV_STEP_BYTES * big / (ms2 * 1e-3) / 1e9
+            # PMC traffic per launch pair at 65536 envs (profiles/r01_env_step_pmc.md): WRITE_SIZE 225.3 MB + 2 x FETCH_SIZE 72.9 MB
+            out["roofline_env_step_65536"] = {"bound": "hbm", "kernel": "env_obs_kernel + env_reward_kernel (addhip_env_step)", "achieved": gbs2,
+                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs2 / HBM_PEAK_GBS, "traffic": 371.2e6,
+                                              "us_per_launch": ms2 * 1e3, "envs": big}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_envs, agent.T)
         print(json.dumps(out), flush=True)
