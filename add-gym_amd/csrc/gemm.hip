@@ -15,7 +15,6 @@
 // Replaces: torch.nn.Linear forward/backward inside PPOModel.eval_actor/eval_critic
 // (ppo_model.py:13-21), ADDModel.eval_disc (add_model.py:12-15) and their autograd.
 #include "common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -99,7 +98,7 @@ constexpr int EPI_RUNTIME = -1;  // epilogue chosen from the descriptor at run t
 
 // EPI: compile-time epilogue (ADDHIP_EPI_*) or EPI_RUNTIME; NORM: fused (a-mean)/std on A
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int BK, int EPI, bool NORM>
-__global__ __launch_bounds__(256, (BK == 16 && BM * BN == 128 * 128) ? 4 : 1) void gemm_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
   static_assert(WM * WN == 4, "4 wavefronts");
   static_assert(!NORM || AKC, "fused normalisation needs a k-contiguous A");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
@@ -301,8 +300,6 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   // keep >= ~1 block per CU on the skinny rollout shapes
   const long long tiles128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
   if (tiles128 < 256) return launch_cfg<64, 128, 2, 2, 16>(g, st);
-  static const int bk16 = getenv("ADDHIP_BK16") ? 1 : 0;
-  if (bk16) return launch_cfg<128, 128, 2, 2, 16>(g, st);
   return launch_cfg<128, 128, 2, 2, 32>(g, st);
 }
 

@@ -11,10 +11,10 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters)
   const int li = lane & 31, lh = lane >> 5;
   f32x16 acc[2][2];
   for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
-  for (int i = threadIdx.x; i < 2 * 2 * 128 * 36; i += 256) lds[i] = (float)(i & 7) * 0.125f;
+  for (int i = threadIdx.x; i < 2 * 2 * 128 * 36; i += 256) lds[i] = in[(blockIdx.x * 977 + i) & 0xfffff];
   __syncthreads();
   float4 fa[2], fb[2];
-  fa[0] = fa[1] = fb[0] = fb[1] = make_float4(lane * 0.01f, 0.5f, 0.25f, 1.f);
+  fa[0] = fa[1] = fb[0] = fb[1] = make_float4(in[lane], in[lane + 64], in[lane + 128], in[lane + 192]);
   float4 g0 = make_float4(0, 0, 0, 0);
   const float4* gin = reinterpret_cast<const float4*>(in) + (size_t)blockIdx.x * 4096 + threadIdx.x;
   for (int it = 0; it < iters; ++it) {
@@ -76,7 +76,7 @@ int main() {
   float *out, *in;
   hipMalloc(&out, 4096 * 256 * 4);
   hipMalloc(&in, (size_t)4096 * 4096 * 16 + (1 << 24));
-  hipMemset(in, 0, (size_t)4096 * 4096 * 16 + (1 << 24));
+  { size_t n = ((size_t)4096 * 4096 * 16 + (1 << 24)) / 4; float* h = (float*)malloc(n * 4); unsigned x = 12345; bool zero = getenv("ZERO") != nullptr; for (size_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; h[i] = zero ? 0.f : ((int)(x >> 8) - (1 << 23)) * (1.0f / (1 << 23)); } hipMemcpy(in, h, n * 4, hipMemcpyHostToDevice); free(h); }
   for (int blocks : {512, 1024}) {
     run<0>("mfma only (regs)", blocks, 32, out, in);
     run<1>("+ LDS fragment reads", blocks, 32, out, in);
