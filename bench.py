@@ -162,7 +162,9 @@ def main():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     distributed = world > 1
     if distributed:
-        dist.init_process_group(backend="nccl")  # RCCL
+        # "nccl" is RCCL on ROCm.  ADDHIP_DIST_BACKEND=gloo exists only to rehearse the multi-rank plumbing on a box with
+        # fewer GPUs than ranks (several ranks then share a device); it is never the measured configuration.
+        dist.init_process_group(backend=os.environ.get("ADDHIP_DIST_BACKEND", "nccl"))
     import add_gym_amd  # noqa: F401
     from add_gym_amd.config import load_config
     from add_gym_amd.learning.add_agent import ADDAgent
@@ -196,7 +198,8 @@ def main():
         "metric": "env-steps/sec (rollout+update), G1 imitation, 4096 envs/GPU",
         "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic (generated G1 clip, random-init weights, kinematic stand-in simulator)",
+        "data": "synthetic (generated G1 clip, random-init weights, kinematic stand-in simulator)"
+                + ("" if not distributed or dist.get_backend() == "nccl" else " [REHEARSAL: %s backend, ranks share GPUs]" % dist.get_backend()),
         "config": {"workload": "G1 walk-like synthetic motion, num_envs=%d/GPU, fp32 PPO + ADD discriminator (BASELINE configs[1])" % a.envs,
                    "envs_per_gpu": a.envs, "steps_per_iter": agent.T, "update_epochs": agent._update_epochs, "minibatch_rows": agent.Mb,
                    "params": agent.calc_num_params(), "parallelism": "dp%d (envs sharded, gradient all-reduce)" % world},
