@@ -209,7 +209,9 @@ def main():
         g = time_gemms(agent)
         tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all GEMM launches of one optimiser step)",
-                           "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                           "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                           # PMC, profiles/r01_gemm_pmc.md: (WRITE_SIZE 1207.7 MB + 2 x FETCH_SIZE 2465.1 MB) / 30 launches of one optimiser step
+                           "traffic": (1207.7e6 + 2 * 2465.1e6) / 30,
                            "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"]}
         ms = time_env_step(agent)
         gbs = ENV_STEP_BYTES * agent.N / (ms * 1e-3) / 1e9

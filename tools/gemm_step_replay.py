@@ -1,0 +1,18 @@
+"""Replays only the GEMM launches of one optimiser step (N=4096 envs -> 16384-row minibatch) three times, for PMC passes."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, add_gym_amd
+from add_gym_amd.config import load_config
+from add_gym_amd.learning.add_agent import ADDAgent
+ag = ADDAgent(load_config("train", ["engine.num_envs=4096"]))
+for w in ag._W.values():
+    if w.dtype == torch.float32: w.normal_()
+for r in (ag._run_actor, ag._run_critic, ag._run_disc):
+    for t in r.h + r.dz: t.normal_()
+st = torch.cuda.current_stream().cuda_stream
+calls = [(fn, args) for name, fn, args in ag._update_plan.calls if name == "addhip_gemm_f32"]
+print("gemm launches per step:", len(calls))
+for _ in range(3):
+    for fn, args in calls:
+        assert fn(*args, st) == 0
+torch.cuda.synchronize()
