@@ -31,12 +31,13 @@ class TaskT(C.Structure):
                 ("enable_early_termination", C.c_int32), ("pose_termination", C.c_int32), ("pose_termination_dist", C.c_float),
                 ("pose_w", C.c_float), ("vel_w", C.c_float), ("root_pose_w", C.c_float), ("root_vel_w", C.c_float),
                 ("pose_scale", C.c_float), ("vel_scale", C.c_float), ("root_pose_scale", C.c_float), ("root_vel_scale", C.c_float),
-                ("obs_dim", C.c_int32), ("obs_stride", C.c_int32), ("disc_dim", C.c_int32), ("disc_stride", C.c_int32)]
+                ("obs_dim", C.c_int32), ("obs_stride", C.c_int32), ("disc_dim", C.c_int32), ("disc_stride", C.c_int32),
+                ("enable_vel_obs", C.c_int32), ("enable_phase_obs", C.c_int32), ("num_phase_encoding", C.c_int32)]
 
 
 class EnvT(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("sim_pose", f32p), ("sim_vel", f32p), ("time", f32p), ("time_off", f32p), ("motion_id", f32p),
-                ("hist", f32p), ("done", f32p), ("contact", f32p), ("ref_pose", f32p), ("ref_vel", f32p), ("ret_acc", f32p), ("len_acc", f32p)]
+                ("hist", f32p), ("hist_vel", f32p), ("done", f32p), ("contact", f32p), ("ref_pose", f32p), ("ref_vel", f32p), ("ret_acc", f32p), ("len_acc", f32p)]
 
 
 class StepOutT(C.Structure):

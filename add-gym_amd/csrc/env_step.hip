@@ -20,21 +20,30 @@ using namespace addhip;
 namespace {
 
 constexpr int PW = ADDHIP_POSE_W;  // 36 floats per global row
-constexpr int ROWS = 16;
 constexpr int WAVES = 4;
-constexpr int R_SIM = 0, R_REF = 2, R_REFV = 3, R_TAR = 4, R_DEMO0 = 12, R_DEMO1 = 13, R_H0 = 14, R_H1 = 15;
+// LDS rows: 16 staged in pass 0, 4 more (velocity history / demo velocity rows) in pass 1 when vel observations are on
+constexpr int R_SIM = 0, R_SIMV = 1, R_REF = 2, R_REFV = 3, R_TAR = 4, R_DEMO0 = 12, R_DEMO1 = 13, R_H0 = 14, R_H1 = 15;
+constexpr int R_D0V = 16, R_D1V = 17, R_H0V = 18, R_H1V = 19;
+constexpr int rows_of(bool vel) { return vel ? 20 : 16; }
+
+// wave-private work area: derived values first, then the staged rows
+constexpr int TN_CHAR = 0, TN_TAR = 1, TN_H0 = 9, TN_H1 = 10, TN_SIMG = 11, TN_D0 = 12, TN_D1 = 13, TN_REF = 14, TN_SLOTS = 15;
+constexpr int OFF_TN = 0;                          // [15][6] tangent/normal vectors
+constexpr int OFF_TP = OFF_TN + TN_SLOTS * 6;      // [8][3] target position observations
+// root velocity / angular velocity observations (heading-local when !global_obs) of 6 (rotation, velocity) row pairs
+constexpr int TV_SIM = 0, TV_H0 = 1, TV_H1 = 2, TV_D0 = 3, TV_D1 = 4, TV_REF = 5, TV_SLOTS = 6;
+constexpr int OFF_TV = OFF_TP + ADDHIP_MAX_TAR_STEPS * 3;   // [6][6]
+constexpr int MAX_PHASE_ENC = 8;
+constexpr int OFF_PH = OFF_TV + TV_SLOTS * 6;               // phase, sin[P], cos[P]
+constexpr int OFF_ZERO = OFF_PH + 1 + 2 * MAX_PHASE_ENC;
+constexpr int OFF_ROWS = (OFF_ZERO + 1 + 3) / 4 * 4;        // 16-byte aligned
 // LDS image of a row: 4 chunks of 9 floats padded to 12 so that each lane's chunk is 16-byte aligned
 constexpr int LROW = 48;
-__device__ __forceinline__ int row_off(int r, int c) { return r * LROW + (c / 9) * 12 + (c % 9); }
+__device__ __forceinline__ constexpr int row_off(int r, int c) { return OFF_ROWS + r * LROW + (c / 9) * 12 + (c % 9); }
+constexpr int work_of(bool vel) { return OFF_ROWS + rows_of(vel) * LROW; }   // floats per wave
+constexpr int map_of(bool vel, bool phase) { return vel ? 1024 : (phase ? 640 : 512); }  // obs_stride + 2*disc_stride must fit
 
-constexpr int TN_CHAR = 0, TN_TAR = 1, TN_H0 = 9, TN_H1 = 10, TN_SIMG = 11, TN_D0 = 12, TN_D1 = 13, TN_REF = 14, TN_SLOTS = 15;
-constexpr int OFF_TN = ROWS * LROW;                // [15][6] tangent/normal vectors
-constexpr int OFF_TP = OFF_TN + TN_SLOTS * 6;      // [8][3] target position observations
-constexpr int OFF_ZERO = OFF_TP + ADDHIP_MAX_TAR_STEPS * 3;
-constexpr int WORK = (OFF_ZERO + 1 + 3) / 4 * 4;   // floats per wave (16-byte multiple)
-constexpr int MAP_MAX = 512;                       // obs_stride + 2*disc_stride must fit
-
-enum { K_SKIP = 0, K_POSE = 1, K_VEL = 2, K_SIM = 3, K_HIST = 4 };
+enum { K_SKIP = 0, K_POSE = 1, K_VEL = 2, K_SIM = 3, K_HIST = 4, K_SIMV = 5, K_HISTV = 6 };
 
 // MotionLib.get_precomputed_motion_step index (anim/motion_lib.py:322-326): fp32 multiply by round(1/dt), truncate
 // toward zero, clamp, add the clip offset.  Bit-exact: explicit round-to-nearest multiply, no contraction; the float is
@@ -73,16 +82,27 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ int obs_src(const addhip_task_t& t, int o) {
   if (o >= t.obs_dim) return OFF_ZERO;
   const int hc = t.root_height_obs ? 1 : 0;
-  const int char_dim = hc + 6 + ADDHIP_NUM_DOF;
+  const int vw = t.enable_vel_obs ? 6 + ADDHIP_NUM_DOF : 0;
+  const int char_dim = hc + 6 + ADDHIP_NUM_DOF + vw;
   if (o < char_dim) {
     if (hc && o == 0) return row_off(R_SIM, 2);
-    const int c = o - hc;
-    return c < 6 ? OFF_TN + TN_CHAR * 6 + c : row_off(R_SIM, 7 + c - 6);
+    int c = o - hc;
+    if (c < 6) return OFF_TN + TN_CHAR * 6 + c;
+    c -= 6;
+    if (c < ADDHIP_NUM_DOF) return row_off(R_SIM, 7 + c);
+    c -= ADDHIP_NUM_DOF;  // root_vel, root_ang_vel, dof_vel (add_observation.py:445-452)
+    return c < 6 ? OFF_TV + TV_SIM * 6 + c : row_off(R_SIMV, 6 + c - 6);
+  }
+  const int ph_dim = t.enable_phase_obs ? 1 + 2 * t.num_phase_encoding : 0;  // add_observation.py:557-575
+  if (o < char_dim + ph_dim) {
+    const int i = o - char_dim;  // phase | sin terms | cos terms; OFF_PH holds them with stride MAX_PHASE_ENC
+    if (i == 0) return OFF_PH;
+    return i <= t.num_phase_encoding ? OFF_PH + i : OFF_PH + MAX_PHASE_ENC + (i - t.num_phase_encoding);
   }
   const int pw = hc ? 3 : 2;
   const int tw = pw + 6 + ADDHIP_NUM_DOF;
-  const int k = (o - char_dim) / tw;
-  int c = (o - char_dim) - k * tw;
+  const int k = (o - char_dim - ph_dim) / tw;
+  int c = (o - char_dim - ph_dim) - k * tw;
   if (c < pw) return OFF_TP + k * 3 + c;
   c -= pw;
   return c < 6 ? OFF_TN + (TN_TAR + k) * 6 + c : row_off(R_TAR + k, 7 + c - 6);
@@ -90,13 +110,19 @@ __device__ __forceinline__ int obs_src(const addhip_task_t& t, int o) {
 // compute_disc_obs (add_observation.py:462-554); demo=false: history rows, true: clip rows
 __device__ __forceinline__ int disc_src(const addhip_task_t& t, int o, bool demo) {
   if (o >= t.disc_dim) return OFF_ZERO;
-  constexpr int sw = 3 + 6 + ADDHIP_NUM_DOF;  // 38
+  constexpr int pw = 3 + 6 + ADDHIP_NUM_DOF;  // 38
+  const int sw = pw + (t.enable_vel_obs ? 6 + ADDHIP_NUM_DOF : 0);
   const int s = o / sw, c = o - s * sw;
   const int row = demo ? (s == 0 ? R_DEMO0 : (s == 1 ? R_DEMO1 : R_REF)) : (s == 0 ? R_H0 : (s == 1 ? R_H1 : R_SIM));
   const int slot = demo ? (s == 0 ? TN_D0 : (s == 1 ? TN_D1 : TN_REF)) : (s == 0 ? TN_H0 : (s == 1 ? TN_H1 : TN_SIMG));
   if (c < 3) return (!t.global_obs && c < 2) ? OFF_ZERO : row_off(row, c);
   if (c < 9) return OFF_TN + slot * 6 + (c - 3);
-  return row_off(row, 7 + c - 9);
+  if (c < pw) return row_off(row, 7 + c - 9);
+  // compute_vel_obs (add_observation.py:502-517)
+  const int cv = c - pw;
+  const int vrow = demo ? (s == 0 ? R_D0V : (s == 1 ? R_D1V : R_REFV)) : (s == 0 ? R_H0V : (s == 1 ? R_H1V : R_SIMV));
+  const int vslot = demo ? (s == 0 ? TV_D0 : (s == 1 ? TV_D1 : TV_REF)) : (s == 0 ? TV_H0 : (s == 1 ? TV_H1 : TV_SIM));
+  return cv < 6 ? OFF_TV + vslot * 6 + cv : row_off(vrow, 6 + cv - 6);
 }
 __device__ __forceinline__ void build_maps(const addhip_task_t& t, short* maps) {
   const int n_obs = t.obs_stride, n_disc = t.disc_stride;
@@ -110,25 +136,12 @@ __device__ __forceinline__ void build_maps(const addhip_task_t& t, short* maps) 
 }
 
 // ---- per-lane staging role (fixed for the whole kernel): lane l copies floats [9q, 9q+9) of row r = l>>2, q = l&3 ----
-struct Role {
-  int kind;    // K_*
-  float dt;    // time offset of a table row relative to the env's motion time
-  int hslot;   // history slot for K_HIST
-};
-__device__ __forceinline__ Role lane_role(const addhip_task_t& t, int lane, bool fresh, int h0, int h1) {
-  const int r = lane >> 2;
-  Role ro{K_SKIP, 0.0f, 0};
-  if (r == R_SIM) ro.kind = fresh ? K_POSE : K_SIM;
-  else if (r == R_REF) ro.kind = K_POSE;
-  else if (r == R_REFV) ro.kind = K_VEL;
-  else if (r >= R_TAR && r < R_TAR + ADDHIP_MAX_TAR_STEPS) {
-    const int k = r - R_TAR;
-    if (k < t.num_tar_steps) { ro.kind = K_POSE; ro.dt = t.tar_dt[k]; }  // add_observation.py:214-215
-  } else if (r == R_DEMO0 || (r == R_H0 && fresh)) { ro.kind = K_POSE; ro.dt = t.demo_dt[0]; }   // :362-375
-  else if (r == R_DEMO1 || (r == R_H1 && fresh)) { ro.kind = K_POSE; ro.dt = t.demo_dt[1]; }
-  else if (r == R_H0) { ro.kind = K_HIST; ro.hslot = h0; }
-  else if (r == R_H1) { ro.kind = K_HIST; ro.hslot = h1; }
-  return ro;
+// t.tar_dt[k] without dynamic indexing of the by-value kernel argument (which would be copied to scratch)
+__device__ __forceinline__ float tar_dt_at(const addhip_task_t& t, int k) {
+  float v = t.tar_dt[0];
+#pragma unroll
+  for (int i = 1; i < ADDHIP_MAX_TAR_STEPS; ++i) v = k == i ? t.tar_dt[i] : v;
+  return v;
 }
 
 struct Tables {  // the motion-table fields the per-env code needs
@@ -136,25 +149,69 @@ struct Tables {  // the motion-table fields the per-env code needs
   int total_steps, compat; float dt_inv;
 };
 
-__device__ __forceinline__ void stage_rows(float* w, const Role& ro, const Tables& tb, const float* sim_pose, const float* hist,
-                                           int env, int cstart, int csteps, float tm, int lane) {
-  if (ro.kind == K_SKIP) return;
-  const int q = lane & 3;
-  size_t off;
+struct EnvPtrs { const float* sim_pose; const float* sim_vel; const float* hist; const float* hist_vel; };
+
+// What a lane copies is fixed for the whole kernel, so the source is resolved once: a base pointer (already advanced to
+// the lane's 9-float chunk and, for history rows, to its ring slot) plus a per-env row multiplier.
+struct Role {
+  int kind;           // ROLE_SKIP, ROLE_TABLE (row = motion-table step index) or ROLE_ENV (row = env)
+  float dt;           // time offset of a table row relative to the env's motion time
   const float* base;
-  if (ro.kind == K_SIM) { base = sim_pose; off = (size_t)env * PW; }
-  else if (ro.kind == K_HIST) { base = hist; off = ((size_t)env * ADDHIP_HIST + ro.hslot) * PW; }
-  else {
-    const int idx = step_index(__fadd_rn(tm, ro.dt), tb.dt_inv, tb.total_steps, cstart, csteps, tb.compat);
-    base = ro.kind == K_POSE ? tb.pose : tb.vel;
-    off = (size_t)idx * PW;
+  int mul;            // floats per row index
+};
+enum { ROLE_SKIP = 0, ROLE_TABLE = 1, ROLE_ENV = 2 };
+
+// FRESH (reset): every row comes from the clip tables, the env pointers are never touched
+template <bool VEL, bool FRESH>
+__device__ __forceinline__ Role lane_role(const addhip_task_t& t, const Tables& tb, const EnvPtrs& ep, int lane, int pass, int h0, int h1) {
+  constexpr bool fresh = FRESH;
+  const int r = pass * 16 + (lane >> 2), q = lane & 3;
+  int kind = K_SKIP, hslot = 0;
+  float dt = 0.0f;
+  if (r == R_SIM) kind = fresh ? K_POSE : K_SIM;
+  else if (r == R_REF) kind = K_POSE;
+  else if (r == R_REFV) kind = K_VEL;
+  else if (r >= R_TAR && r < R_TAR + ADDHIP_MAX_TAR_STEPS) {
+    const int k = r - R_TAR;
+    if (k < t.num_tar_steps) { kind = K_POSE; dt = tar_dt_at(t, k); }  // add_observation.py:214-215
+  } else if (r == R_DEMO0 || (r == R_H0 && fresh)) { kind = K_POSE; dt = t.demo_dt[0]; }   // :362-375
+  else if (r == R_DEMO1 || (r == R_H1 && fresh)) { kind = K_POSE; dt = t.demo_dt[1]; }
+  else if (r == R_H0) { kind = K_HIST; hslot = h0; }
+  else if (r == R_H1) { kind = K_HIST; hslot = h1; }
+  else if (VEL) {
+    if (r == R_SIMV) kind = fresh ? K_VEL : K_SIMV;
+    else if (r == R_D0V || (r == R_H0V && fresh)) { kind = K_VEL; dt = t.demo_dt[0]; }
+    else if (r == R_D1V || (r == R_H1V && fresh)) { kind = K_VEL; dt = t.demo_dt[1]; }
+    else if (r == R_H0V) { kind = K_HISTV; hslot = h0; }
+    else if (r == R_H1V) { kind = K_HISTV; hslot = h1; }
   }
-  const float* src = base + off + q * 9;
+  Role ro{ROLE_SKIP, dt, nullptr, PW};
+  if (kind == K_SKIP) return ro;
+  if (FRESH || kind == K_POSE || kind == K_VEL) {
+    ro.kind = ROLE_TABLE;
+    ro.base = (kind == K_POSE ? tb.pose : tb.vel) + q * 9;
+  } else if (kind == K_SIM || (VEL && kind == K_SIMV)) {
+    ro.kind = ROLE_ENV;
+    ro.base = (kind == K_SIM ? ep.sim_pose : ep.sim_vel) + q * 9;
+  } else {
+    ro.kind = ROLE_ENV;
+    ro.base = ((VEL && kind == K_HISTV) ? ep.hist_vel : ep.hist) + hslot * PW + q * 9;
+    ro.mul = ADDHIP_HIST * PW;
+  }
+  return ro;
+}
+
+__device__ __forceinline__ void stage_rows(float* w, const Role& ro, const Tables& tb, int pass, int env, int cstart, int csteps,
+                                           float tm, int lane) {
+  if (ro.kind == ROLE_SKIP) return;
+  int row = env;
+  if (ro.kind == ROLE_TABLE) row = step_index(__fadd_rn(tm, ro.dt), tb.dt_inv, tb.total_steps, cstart, csteps, tb.compat);
+  const float* src = ro.base + (size_t)(unsigned)(row * ro.mul);  // < 2^31 floats (check_common)
   // nine dword loads (this granularity is only 4-byte aligned); the backend merges them into 16+16+4 byte loads
   float v[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) v[i] = src[i];
-  float* dst = w + (lane >> 2) * LROW + q * 12;
+  float* dst = w + OFF_ROWS + (pass * 16 + (lane >> 2)) * LROW + (lane & 3) * 12;
   *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
   *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
   dst[8] = v[8];
@@ -166,8 +223,8 @@ __device__ __forceinline__ Quat lds_quat(const float* w, int r) {
 
 // per-env arithmetic, once: lane s < 15 -> tangent+normal (torch_util.py:231-242) of quaternion slot s;
 // lanes 16.. -> target position observations (add_observation.py:589-618)
-template <bool GLOBAL>
-__device__ __forceinline__ void derive(const addhip_task_t& t, float* w, int lane) {
+template <bool GLOBAL, bool VEL, bool PHASE>
+__device__ __forceinline__ void derive(const addhip_task_t& t, float* w, int lane, float phase) {
   if (lane < TN_SLOTS) {
     const int slot = lane;
     int r;
@@ -192,6 +249,32 @@ __device__ __forceinline__ void derive(const addhip_task_t& t, float* w, int lan
       v = c == 0 ? rr.x : rr.y;
     }
     w[OFF_TP + i] = v;
+  } else if (lane >= 40 && lane < 40 + TV_SLOTS) {
+    if (VEL) {  // compute_char_obs / compute_vel_obs velocity terms (add_observation.py:445-452, 502-517)
+      const int s = lane - 40;
+      const int rr = s == TV_SIM ? R_SIM : s == TV_H0 ? R_H0 : s == TV_H1 ? R_H1 : s == TV_D0 ? R_DEMO0 : s == TV_D1 ? R_DEMO1 : R_REF;
+      const int rv = s == TV_SIM ? R_SIMV : s == TV_H0 ? R_H0V : s == TV_H1 ? R_H1V : s == TV_D0 ? R_D0V : s == TV_D1 ? R_D1V : R_REFV;
+      Vec3 v{w[row_off(rv, 0)], w[row_off(rv, 1)], w[row_off(rv, 2)]}, a{w[row_off(rv, 3)], w[row_off(rv, 4)], w[row_off(rv, 5)]};
+      if (!GLOBAL) {
+        const Quat h = heading_quat_inv(lds_quat(w, rr));
+        v = quat_rotate(h, v);
+        a = quat_rotate(h, a);
+      }
+      float* d = w + OFF_TV + s * 6;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = a.x; d[4] = a.y; d[5] = a.z;
+    }
+  } else if (lane >= 46 && lane < 47 + 2 * MAX_PHASE_ENC) {
+    if (PHASE) {  // compute_phase_obs (add_observation.py:557-575)
+      const int i = lane - 46;
+      if (i == 0) w[OFF_PH] = phase;
+      else {
+        const int e = (i - 1) % MAX_PHASE_ENC;
+        if (e < t.num_phase_encoding) {
+          const float val = __fmul_rn(phase, __fmul_rn(6.2831855f, (float)(1 << e)));  // 2*pi*2^e in fp32
+          w[OFF_PH + i] = i <= MAX_PHASE_ENC ? sinf(val) : cosf(val);
+        }
+      }
+    }
   } else if (lane == 63) {
     w[OFF_ZERO] = 0.0f;
   }
@@ -203,34 +286,42 @@ __device__ __forceinline__ void emit(const float* w, const short* map, int n, fl
 
 struct ObsArgs {
   Tables tb;
-  const float* sim_pose; const float* time; const float* time_off; const int* motion_id; float* hist;
+  const float* sim_pose; const float* sim_vel; const float* time; const float* time_off; const int* motion_id; float* hist; float* hist_vel;
+  const float* clip_len;
   float* ref_pose; float* ref_vel;
   float* obs; float* obs2; float* disc; float* demo;
   int num_envs, head;
 };
 
-template <bool GLOBAL>
+template <bool GLOBAL, bool VEL, bool PHASE>
 __global__ __launch_bounds__(64 * WAVES) void env_obs_kernel(addhip_task_t t, ObsArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[WAVES][WORK];
-  __shared__ short maps[MAP_MAX];
+  __shared__ __attribute__((aligned(16))) float lds[WAVES][work_of(VEL)];
+  __shared__ short maps[map_of(VEL, PHASE)];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* w = lds[wv];
   build_maps(t, maps);
   const int h0 = (a.head + 1) % ADDHIP_HIST, h1 = (a.head + 2) % ADDHIP_HIST;
-  const Role ro = lane_role(t, lane, false, h0, h1);
+  const EnvPtrs ep{a.sim_pose, a.sim_vel, a.hist, a.hist_vel};
+  const Role ro = lane_role<VEL, false>(t, a.tb, ep, lane, 0, h0, h1);
+  Role ro1{ROLE_SKIP, 0.0f, nullptr, PW};
+  if (VEL) ro1 = lane_role<VEL, false>(t, a.tb, ep, lane, 1, h0, h1);
   const int n_obs = t.obs_stride, n_disc = t.disc_stride;
   const int groups = (a.num_envs + WAVES - 1) / WAVES;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int env = g * WAVES + wv;
     const bool valid = env < a.num_envs;
+    float phase = 0.0f;
     if (valid) {
       const float time_new = __fadd_rn(a.time[env], t.dt);     // env.py:155 (written back by env_reward_kernel)
       const int id = a.motion_id[env];
       const float tm = __fadd_rn(time_new, a.time_off[env]);   // add_observation.py:352-354
-      stage_rows(w, ro, a.tb, a.sim_pose, a.hist, env, a.tb.clip_start[id], a.tb.clip_steps[id], tm, lane);
+      const int cstart = a.tb.clip_start[id], csteps = a.tb.clip_steps[id];
+      stage_rows(w, ro, a.tb, 0, env, cstart, csteps, tm, lane);
+      if (VEL) stage_rows(w, ro1, a.tb, 1, env, cstart, csteps, tm, lane);
+      if (PHASE) phase = fminf(fmaxf(__fdiv_rn(tm, a.clip_len[id]), 0.0f), 1.0f);  // motion_lib.py:361-372 (CLAMP clips)
     }
     __syncthreads();
-    if (valid) derive<GLOBAL>(t, w, lane);
+    if (valid) derive<GLOBAL, VEL, PHASE>(t, w, lane, phase);
     __syncthreads();
     if (valid) {
       if (a.obs) emit(w, maps, n_obs, a.obs + (size_t)env * n_obs, lane);
@@ -240,6 +331,7 @@ __global__ __launch_bounds__(64 * WAVES) void env_obs_kernel(addhip_task_t t, Ob
       if (lane < PW) {
         // history push (circular_buffer.py:17-20) and reference state (add_observation.py:163-174)
         a.hist[((size_t)env * ADDHIP_HIST + a.head) * PW + lane] = w[row_off(R_SIM, lane)];
+        if (VEL) a.hist_vel[((size_t)env * ADDHIP_HIST + a.head) * PW + lane] = w[row_off(R_SIMV, lane)];
         a.ref_pose[(size_t)env * PW + lane] = w[row_off(R_REF, lane)];
         a.ref_vel[(size_t)env * PW + lane] = w[row_off(R_REFV, lane)];
       }
@@ -376,7 +468,8 @@ __device__ __forceinline__ float floor_div_f32(float a, float b) {
 
 struct ResetArgs {
   Tables tb;
-  float* sim_pose; float* sim_vel; float* time; float* time_off; const int* motion_id; float* hist; int* done;
+  const float* clip_len;
+  float* sim_pose; float* sim_vel; float* time; float* time_off; const int* motion_id; float* hist; float* hist_vel; int* done;
   float* ref_pose; float* ref_vel;
   const float* u_seg; const float* u_jit;
   float* obs; float* disc; float* demo;
@@ -384,20 +477,23 @@ struct ResetArgs {
 };
 
 // ---- reset phase 2: start time, state from the clip, history refill, observations
-template <bool GLOBAL>
+template <bool GLOBAL, bool VEL, bool PHASE>
 __global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_task_t t, addhip_sampler_t s, ResetArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[WAVES][WORK];
-  __shared__ short maps[MAP_MAX];
+  __shared__ __attribute__((aligned(16))) float lds[WAVES][work_of(VEL)];
+  __shared__ short maps[map_of(VEL, PHASE)];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* w = lds[wv];
   build_maps(t, maps);
-  const Role ro = lane_role(t, lane, true, 0, 0);
+  const EnvPtrs ep{nullptr, nullptr, nullptr, nullptr};
+  const Role ro = lane_role<VEL, true>(t, a.tb, ep, lane, 0, 0, 0);
+  Role ro1{ROLE_SKIP, 0.0f, nullptr, PW};
+  if (VEL) ro1 = lane_role<VEL, true>(t, a.tb, ep, lane, 1, 0, 0);
   const int n_obs = t.obs_stride, n_disc = t.disc_stride;
   const int groups = (a.num_envs + WAVES - 1) / WAVES;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int env = g * WAVES + wv;
     const bool active = env < a.num_envs && (a.reset_all || a.done[env] != ADDHIP_DONE_NULL);
-    float off = 0.0f;
+    float off = 0.0f, phase = 0.0f;
     if (active) {
       const int id = a.motion_id[env];
       if (s.rand_reset) {
@@ -424,10 +520,13 @@ __global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_task_t t, 
         off = fmaxf(tt, s.min_start_time);                      // :91
       }
       // time_buf = 0 (env.py:161) -> motion time == offset
-      stage_rows(w, ro, a.tb, nullptr, nullptr, env, a.tb.clip_start[id], a.tb.clip_steps[id], off, lane);
+      const int cstart = a.tb.clip_start[id], csteps = a.tb.clip_steps[id];
+      stage_rows(w, ro, a.tb, 0, env, cstart, csteps, off, lane);
+      if (VEL) stage_rows(w, ro1, a.tb, 1, env, cstart, csteps, off, lane);
+      if (PHASE) phase = fminf(fmaxf(__fdiv_rn(off, a.clip_len[id]), 0.0f), 1.0f);
     }
     __syncthreads();
-    if (active) derive<GLOBAL>(t, w, lane);
+    if (active) derive<GLOBAL, VEL, PHASE>(t, w, lane, phase);
     __syncthreads();
     if (active) {
       if (a.obs) emit(w, maps, n_obs, a.obs + (size_t)env * n_obs, lane);
@@ -445,6 +544,12 @@ __global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_task_t t, 
         hb[((a.head + 0) % ADDHIP_HIST) * PW + lane] = w[row_off(R_DEMO0, lane)];
         hb[((a.head + 1) % ADDHIP_HIST) * PW + lane] = w[row_off(R_DEMO1, lane)];
         hb[((a.head + 2) % ADDHIP_HIST) * PW + lane] = pose;
+        if (VEL) {
+          float* hv = a.hist_vel + (size_t)env * ADDHIP_HIST * PW;
+          hv[((a.head + 0) % ADDHIP_HIST) * PW + lane] = w[row_off(R_D0V, lane)];
+          hv[((a.head + 1) % ADDHIP_HIST) * PW + lane] = w[row_off(R_D1V, lane)];
+          hv[((a.head + 2) % ADDHIP_HIST) * PW + lane] = vel;
+        }
       }
       if (lane == 0) {
         a.time[env] = 0.0f;
@@ -484,15 +589,21 @@ int check_common(const addhip_motion_t* m, const addhip_task_t* t, const addhip_
   ADDHIP_REQUIRE(e->num_envs > 0, "num_envs must be > 0");
   ADDHIP_REQUIRE(m->pose && m->vel && m->clip_start && m->clip_len && m->clip_loop && m->clip_steps, "motion tables missing");
   ADDHIP_REQUIRE(m->total_steps > 0 && m->num_clips > 0, "empty motion library");
+  ADDHIP_REQUIRE((long long)m->total_steps * PW < (1ll << 31), "motion table too large for 32-bit row offsets");
   ADDHIP_REQUIRE((long long)e->num_envs * ADDHIP_HIST * PW < (1ll << 31), "env count too large for 32-bit row offsets");
   ADDHIP_REQUIRE(t->num_tar_steps >= 0 && t->num_tar_steps <= ADDHIP_MAX_TAR_STEPS, "num_tar_steps out of range");
   ADDHIP_REQUIRE(t->demo_dt[ADDHIP_HIST - 1] == 0.0f, "demo_dt[last] must be 0 (newest demo frame == reference frame)");
   const int hc = t->root_height_obs ? 1 : 0;
-  const int want = hc + 6 + ADDHIP_NUM_DOF + t->num_tar_steps * ((hc ? 3 : 2) + 6 + ADDHIP_NUM_DOF);
+  const int vw = t->enable_vel_obs ? 6 + ADDHIP_NUM_DOF : 0;
+  ADDHIP_REQUIRE(t->num_phase_encoding >= 0 && t->num_phase_encoding <= MAX_PHASE_ENC, "num_phase_encoding must be in 0..%d", MAX_PHASE_ENC);
+  const int want = hc + 6 + ADDHIP_NUM_DOF + vw + (t->enable_phase_obs ? 1 + 2 * t->num_phase_encoding : 0) +
+                   t->num_tar_steps * ((hc ? 3 : 2) + 6 + ADDHIP_NUM_DOF);
   ADDHIP_REQUIRE(t->obs_dim == want, "obs_dim %d does not match the task flags (expected %d)", t->obs_dim, want);
-  ADDHIP_REQUIRE(t->disc_dim == ADDHIP_HIST * (9 + ADDHIP_NUM_DOF), "disc_dim must be %d", ADDHIP_HIST * (9 + ADDHIP_NUM_DOF));
+  ADDHIP_REQUIRE(t->disc_dim == ADDHIP_HIST * (9 + ADDHIP_NUM_DOF + vw), "disc_dim must be %d", ADDHIP_HIST * (9 + ADDHIP_NUM_DOF + vw));
+  ADDHIP_REQUIRE(!t->enable_vel_obs || e->hist_vel, "hist_vel is required when enable_vel_obs is set");
   ADDHIP_REQUIRE(t->obs_stride >= t->obs_dim && t->disc_stride >= t->disc_dim, "strides smaller than dims");
-  ADDHIP_REQUIRE(t->obs_stride + 2 * t->disc_stride <= MAP_MAX, "obs_stride + 2*disc_stride must be <= %d", MAP_MAX);
+  const int map_max = map_of(t->enable_vel_obs != 0, t->enable_phase_obs != 0);
+  ADDHIP_REQUIRE(t->obs_stride + 2 * t->disc_stride <= map_max, "obs_stride + 2*disc_stride must be <= %d", map_max);
   ADDHIP_REQUIRE(e->sim_pose && e->sim_vel && e->time && e->time_off && e->motion_id && e->hist && e->done && e->ref_pose && e->ref_vel,
                  "env state pointers missing");
   return 0;
@@ -514,10 +625,22 @@ extern "C" int addhip_env_step(const addhip_motion_t* m, const addhip_task_t* t,
   ADDHIP_REQUIRE(o, "null outputs");
   ADDHIP_REQUIRE(head >= 0 && head < ADDHIP_HIST, "head out of range");
   hipStream_t st = (hipStream_t)stream;
-  ObsArgs a{tables_of(m), e->sim_pose, e->time, e->time_off, e->motion_id, e->hist, e->ref_pose, e->ref_vel,
+  ObsArgs a{tables_of(m), e->sim_pose, e->sim_vel, e->time, e->time_off, e->motion_id, e->hist, e->hist_vel, m->clip_len, e->ref_pose, e->ref_vel,
             o->obs, o->obs_next_in, o->disc_obs, o->disc_demo, e->num_envs, head};
-  if (t->global_obs) hipLaunchKernelGGL(env_obs_kernel<true>, dim3(env_grid(e->num_envs)), dim3(64 * WAVES), 0, st, *t, a);
-  else hipLaunchKernelGGL(env_obs_kernel<false>, dim3(env_grid(e->num_envs)), dim3(64 * WAVES), 0, st, *t, a);
+  const dim3 grid(env_grid(e->num_envs)), block(64 * WAVES);
+  const int variant = (t->global_obs ? 4 : 0) | (t->enable_vel_obs ? 2 : 0) | (t->enable_phase_obs ? 1 : 0);
+#define ADDHIP_OBS(G, V, P) hipLaunchKernelGGL((env_obs_kernel<G, V, P>), grid, block, 0, st, *t, a)
+  switch (variant) {
+    case 0: ADDHIP_OBS(false, false, false); break;
+    case 1: ADDHIP_OBS(false, false, true); break;
+    case 2: ADDHIP_OBS(false, true, false); break;
+    case 3: ADDHIP_OBS(false, true, true); break;
+    case 4: ADDHIP_OBS(true, false, false); break;
+    case 5: ADDHIP_OBS(true, false, true); break;
+    case 6: ADDHIP_OBS(true, true, false); break;
+    default: ADDHIP_OBS(true, true, true); break;
+  }
+#undef ADDHIP_OBS
   if (int rc = check_launch("env_obs_kernel")) return rc;
   RewardArgs r{e->sim_pose, e->sim_vel, e->ref_pose, e->ref_vel, e->time, e->time_off, e->motion_id, e->done, e->contact,
                m->clip_len, m->clip_loop, e->ret_acc, e->len_acc, o->reward, o->done, o->motion_id_rec, o->motion_time_rec, o->ep_stats,
@@ -542,10 +665,22 @@ extern "C" int addhip_env_reset(const addhip_motion_t* m, const addhip_task_t* t
   hipLaunchKernelGGL(reset_draw_kernel, dim3((e->num_envs + 255) / 256), dim3(256), 0, st, e->num_envs, m->num_clips, e->done, e->motion_id, *s,
                      u_clip, reset_all);
   if (int rc = check_launch("reset_draw_kernel")) return rc;
-  ResetArgs a{tables_of(m), e->sim_pose, e->sim_vel, e->time, e->time_off, e->motion_id, e->hist, e->done, e->ref_pose, e->ref_vel,
+  ResetArgs a{tables_of(m), m->clip_len, e->sim_pose, e->sim_vel, e->time, e->time_off, e->motion_id, e->hist, e->hist_vel, e->done, e->ref_pose, e->ref_vel,
               u_seg, u_jit, obs_out, disc_obs_out, disc_demo_out, e->num_envs, head, reset_all};
-  if (t->global_obs) hipLaunchKernelGGL(env_reset_kernel<true>, dim3(env_grid(e->num_envs)), dim3(64 * WAVES), 0, st, *t, *s, a);
-  else hipLaunchKernelGGL(env_reset_kernel<false>, dim3(env_grid(e->num_envs)), dim3(64 * WAVES), 0, st, *t, *s, a);
+  const dim3 grid(env_grid(e->num_envs)), block(64 * WAVES);
+  const int variant = (t->global_obs ? 4 : 0) | (t->enable_vel_obs ? 2 : 0) | (t->enable_phase_obs ? 1 : 0);
+#define ADDHIP_RESET(G, V, P) hipLaunchKernelGGL((env_reset_kernel<G, V, P>), grid, block, 0, st, *t, *s, a)
+  switch (variant) {
+    case 0: ADDHIP_RESET(false, false, false); break;
+    case 1: ADDHIP_RESET(false, false, true); break;
+    case 2: ADDHIP_RESET(false, true, false); break;
+    case 3: ADDHIP_RESET(false, true, true); break;
+    case 4: ADDHIP_RESET(true, false, false); break;
+    case 5: ADDHIP_RESET(true, false, true); break;
+    case 6: ADDHIP_RESET(true, true, false); break;
+    default: ADDHIP_RESET(true, true, true); break;
+  }
+#undef ADDHIP_RESET
   return check_launch("env_reset_kernel");
 }
 

@@ -107,11 +107,14 @@ __global__ __launch_bounds__(256) void disc_prep_kernel(const float* dobs, const
   float* sh_abs = sh + 2 * cells;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 2 * cells; i += 256) sh[i] = 0.f;
-  float a0 = 0.f, a1 = 0.f;  // |diff| partials for columns lane, lane+64
+  float a[4] = {0.f, 0.f, 0.f, 0.f};  // |diff| partials for columns lane + 64k
   __syncthreads();
   for (long long row = (long long)blockIdx.x * 4 + w; row < rows; row += (long long)gridDim.x * 4) {
     float err = 0.f;
-    for (int c = lane, k = 0; c < stride; c += 64, ++k) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lane + 64 * k;
+      if (c >= stride) break;
       float v = 0.f;
       if (c < dim) {
         float ag = dobs[row * stride + c], de = ddemo[row * stride + c];
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void disc_prep_kernel(const float* dobs, const
         float e = ag - de;
         err += e * e;
         v = d / fmaxf(mean_abs[c], min_diff);
-        if (k == 0) a0 += fabsf(d); else a1 += fabsf(d);
+        a[k] += fabsf(d);
       }
       if (norm_diff) norm_diff[row * stride + c] = v;
     }
@@ -134,8 +137,9 @@ __global__ __launch_bounds__(256) void disc_prep_kernel(const float* dobs, const
     }
   }
   if (abs_sum) {
-    sh_abs[w * stride + lane] = a0;
-    if (lane + 64 < stride) sh_abs[w * stride + lane + 64] = a1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lane + 64 * k < stride) sh_abs[w * stride + lane + 64 * k] = a[k];
   }
   __syncthreads();
   if (abs_sum)
@@ -553,7 +557,7 @@ extern "C" int addhip_actor_sample(const float* mean, int32_t ld_mean, const flo
 extern "C" int addhip_disc_prep(const float* disc_obs, const float* disc_demo, int32_t stride, int32_t dim, int64_t rows, const float* mean_abs,
                                  float min_diff, float* norm_diff, const int32_t* motion_id, const float* motion_time, const addhip_sampler_t* s,
                                  int32_t num_clips, float* abs_sum, void* stream) {
-  ADDHIP_REQUIRE(disc_obs && disc_demo && mean_abs && rows > 0 && dim <= stride && stride <= 128, "disc_prep: bad arguments");
+  ADDHIP_REQUIRE(disc_obs && disc_demo && mean_abs && rows > 0 && dim <= stride && stride <= 256, "disc_prep: bad arguments (stride <= 256)");
   addhip_sampler_t ss;
   memset(&ss, 0, sizeof(ss));
   int cells = 0;

@@ -7,12 +7,17 @@ from . import _lib as L
 F = np.float32
 
 
+VEL_W = 35  # root_vel 3 + root_ang_vel 3 + dof_vel 29
+
+
 def obs_dims(task):
-    """(obs_dim, disc_dim) for the flags the HIP path implements (add_observation.py:231-274, 520-554)."""
+    """(obs_dim, disc_dim) (add_observation.py:231-274, 422-459, 520-575)."""
     hc = 1 if task.get("root_height_obs", False) else 0
     k = len(task.get("tar_obs_steps", [1])) if task.get("enable_tar_obs", False) else 0
-    obs_dim = hc + 6 + L.NUM_DOF + k * ((3 if hc else 2) + 6 + L.NUM_DOF)
-    return obs_dim, L.HIST * L.DISC_STEP_W
+    vel = VEL_W if task.get("enable_vel_obs", False) else 0
+    phase = (1 + 2 * int(task.get("num_phase_encoding", 0))) if task.get("enable_phase_obs", True) else 0
+    obs_dim = hc + 6 + L.NUM_DOF + vel + phase + k * ((3 if hc else 2) + 6 + L.NUM_DOF)
+    return obs_dim, L.HIST * (L.DISC_STEP_W + vel)
 
 
 def pad4(n):
@@ -22,10 +27,8 @@ def pad4(n):
 def check_supported(task):
     """The HIP path covers the observation flags of configs/task/pose.yaml plus the global/height toggles.
     Anything else fails loudly instead of silently computing something different."""
-    if task.get("enable_vel_obs", False):
-        raise NotImplementedError("task.enable_vel_obs=True is not implemented in the HIP hot path yet")
-    if task.get("enable_phase_obs", True):
-        raise NotImplementedError("task.enable_phase_obs=True is not implemented in the HIP hot path yet (pose.yaml sets it False)")
+    if task.get("enable_phase_obs", True) and int(task.get("num_phase_encoding", 0)) > 8:
+        raise NotImplementedError("task.num_phase_encoding must be <= 8")
     if task.get("num_disc_obs_steps", L.HIST) != L.HIST:
         raise NotImplementedError("task.num_disc_obs_steps must be 3")
     if task.get("visualize_ref_char", False):
@@ -60,6 +63,9 @@ def make_task(task, dt, max_episode_length=None):
     t.root_pose_w, t.root_vel_w = float(task["reward_root_pose_w"]), float(task["reward_root_vel_w"])
     t.pose_scale, t.vel_scale = float(task["reward_pose_scale"]), float(task["reward_vel_scale"])
     t.root_pose_scale, t.root_vel_scale = float(task["reward_root_pose_scale"]), float(task["reward_root_vel_scale"])
+    t.enable_vel_obs = int(bool(task.get("enable_vel_obs", False)))
+    t.enable_phase_obs = int(bool(task.get("enable_phase_obs", True)))
+    t.num_phase_encoding = int(task.get("num_phase_encoding", 0))
     t.obs_dim, t.disc_dim = obs_dims(task)
     t.obs_stride, t.disc_stride = pad4(t.obs_dim), pad4(t.disc_dim)
     return t

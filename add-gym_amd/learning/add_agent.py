@@ -89,11 +89,11 @@ class ADDAgent:
             allowed = [ent.get_link(name=nm).idx for nm in names]
             self._noncontact_ids = torch.tensor([l.idx for l in ent.links if l.idx not in allowed], dtype=torch.long, device=dev)
         self._S = S = dict(sim_pose=sim_pose, sim_vel=sim_vel, contact=contact, time=env.time_buf, time_off=z(N), motion_id=z(N, dt=torch.int32),
-                           hist=z(N, L.HIST, L.POSE_W), done=z(N, dt=torch.int32), ref_pose=z(N, L.POSE_W), ref_vel=z(N, L.POSE_W),
+                           hist=z(N, L.HIST, L.POSE_W), hist_vel=z(N, L.HIST, L.POSE_W) if tk.enable_vel_obs else None, done=z(N, dt=torch.int32), ref_pose=z(N, L.POSE_W), ref_vel=z(N, L.POSE_W),
                            ret_acc=z(N), len_acc=z(N, dt=torch.int32), ret_acc_test=z(N), len_acc_test=z(N, dt=torch.int32))
-        self._env_c = L.EnvT(N, *[L.ptr(S[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "done", "contact",
+        self._env_c = L.EnvT(N, *[L.ptr(S[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "hist_vel", "done", "contact",
                                                          "ref_pose", "ref_vel", "ret_acc", "len_acc")])
-        self._env_c_test = L.EnvT(N, *[L.ptr(S[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "done", "contact",
+        self._env_c_test = L.EnvT(N, *[L.ptr(S[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "hist_vel", "done", "contact",
                                                               "ref_pose", "ref_vel", "ret_acc_test", "len_acc_test")])
         self._head = 0  # ring slot that receives the next state (circular_buffer.py:8)
 

@@ -66,6 +66,9 @@ typedef struct {
   float pose_w, vel_w, root_pose_w, root_vel_w;
   float pose_scale, vel_scale, root_pose_scale, root_vel_scale;
   int32_t obs_dim, obs_stride, disc_dim, disc_stride;
+  int32_t enable_vel_obs;         /* root vel / ang vel / dof vel in the policy and discriminator observations */
+  int32_t enable_phase_obs;       /* motion phase (+ 2*num_phase_encoding positional terms) in the policy observation */
+  int32_t num_phase_encoding;     /* <= 8 */
 } addhip_task_t;
 
 /* ---- per-env state between the engine boundary and the agent ---- */
@@ -77,6 +80,7 @@ typedef struct {
   float* time_off;      /* [N] ADDObservation._motion_time_offsets */
   int32_t* motion_id;   /* [N] ADDObservation._motion_ids */
   float* hist;          /* [N,3,36] pose history ring (util/circular_buffer.py), one shared head */
+  float* hist_vel;      /* [N,3,36] velocity history ring; required iff task.enable_vel_obs, else NULL */
   int32_t* done;        /* [N] ADDDone.done_buf */
   const uint8_t* contact; /* [N] non-foot ground contact flag (robot.py:221-231) or NULL */
   float* ref_pose;      /* [N,36] ADDObservation.ref_* */

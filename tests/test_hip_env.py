@@ -32,14 +32,14 @@ def T(x, dtype=None):
     return torch.tensor(np.ascontiguousarray(x), dtype=dtype, device="cuda")
 
 
-def make_env(L, n, pose, vel, time, off, ids, hist, contact=None):
+def make_env(L, n, pose, vel, time, off, ids, hist, contact=None, hist_vel=None):
     import torch
 
     st = dict(sim_pose=T(pose), sim_vel=T(vel), time=T(time, torch.float32), time_off=T(off, torch.float32), motion_id=T(ids, torch.int32),
-              hist=T(hist), done=torch.zeros(n, dtype=torch.int32, device="cuda"),
+              hist=T(hist), hist_vel=None if hist_vel is None else T(hist_vel), done=torch.zeros(n, dtype=torch.int32, device="cuda"),
               contact=None if contact is None else T(contact.astype(np.uint8)), ref_pose=torch.zeros(n, 36, device="cuda"),
               ref_vel=torch.zeros(n, 36, device="cuda"), ret_acc=torch.zeros(n, device="cuda"), len_acc=torch.zeros(n, dtype=torch.int32, device="cuda"))
-    c = L.EnvT(n, *[L.ptr(st[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "done", "contact", "ref_pose", "ref_vel", "ret_acc", "len_acc")])
+    c = L.EnvT(n, *[L.ptr(st[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "hist_vel", "done", "contact", "ref_pose", "ref_vel", "ret_acc", "len_acc")])
     return st, c
 
 
@@ -58,8 +58,15 @@ def fixture_hist(v, prefix=""):
     return np.concatenate([v[prefix + "hist_root_pos"], v[prefix + "hist_root_rot"], v[prefix + "hist_dof_pos"]], axis=-1).astype(F)
 
 
+def fixture_hist_vel(v, prefix=""):
+    z = np.zeros(v[prefix + "hist_root_vel"].shape[:-1] + (1,), F)
+    return np.concatenate([v[prefix + "hist_root_vel"], v[prefix + "hist_root_ang_vel"], v[prefix + "hist_dof_vel"], z], axis=-1).astype(F)
+
+
 VARIANTS = {"default": {}, "local": dict(global_obs=False), "noheight": dict(root_height_obs=False),
-            "local_noheight": dict(global_obs=False, root_height_obs=False)}
+            "local_noheight": dict(global_obs=False, root_height_obs=False),
+            "vel_phase": dict(enable_vel_obs=True, enable_phase_obs=True, num_phase_encoding=4),
+            "local_vel": dict(global_obs=False, enable_vel_obs=True)}
 
 
 @pytest.mark.parametrize("vname", list(VARIANTS))
@@ -75,17 +82,23 @@ def test_env_step_matches_reference(vname):
     pose = pack_pose(v["root_pos"], v["root_rot"], v["dof_pos"])
     vel = pack_vel(v["root_vel"], v["root_ang_vel"], v["dof_vel"])
     head = int(v["hist_head"])
-    st, env = make_env(L, n, pose, vel, v["time"], v["time_off"], v["motion_ids"], fixture_hist(v), v["contact"])
+    with_vel = bool(task.enable_vel_obs)
+    st, env = make_env(L, n, pose, vel, v["time"], v["time_off"], v["motion_ids"], fixture_hist(v), v["contact"],
+                       fixture_hist_vel(v) if with_vel else None)
     o, out = make_out(L, n, task)
     L.call("addhip_env_step", mot.c, task, env, out, head, L.current_stream())
     torch.cuda.synchronize()
     obs = o["obs"].cpu().numpy()
+    dd = task.disc_dim
+    assert v["obs"].shape[1] == task.obs_dim and v["disc_obs"].shape[1] == dd
     assert obs.shape[1] == task.obs_stride and np.all(obs[:, task.obs_dim:] == 0)
     np.testing.assert_allclose(obs[:, :task.obs_dim], v["obs"], rtol=0, atol=ATOL)
     assert np.array_equal(o["obs2"].cpu().numpy(), obs)
-    np.testing.assert_allclose(o["disc"].cpu().numpy()[:, :114], v["disc_obs"], rtol=0, atol=ATOL)
-    np.testing.assert_allclose(o["demo"].cpu().numpy()[:, :114], v["disc_obs_demo"], rtol=0, atol=ATOL)
-    assert np.all(o["disc"].cpu().numpy()[:, 114:] == 0)
+    np.testing.assert_allclose(o["disc"].cpu().numpy()[:, :dd], v["disc_obs"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(o["demo"].cpu().numpy()[:, :dd], v["disc_obs_demo"], rtol=0, atol=ATOL)
+    assert np.all(o["disc"].cpu().numpy()[:, dd:] == 0)
+    if with_vel:
+        assert np.array_equal(st["hist_vel"].cpu().numpy()[:, head], vel)
     np.testing.assert_allclose(o["reward"].cpu().numpy(), v["reward"], rtol=0, atol=ATOL)
     # bit-exact: flags, clock, reference rows (pure gathers), recorded motion times
     assert np.array_equal(o["done"].cpu().numpy(), v["done"])
