@@ -107,7 +107,11 @@ typedef struct {
  * _update_ref_motion + _update_disc_hist (add_observation.py:163-207); compute_add_obs /
  * compute_disc_obs x2 (add_observation.py:231-306, 356-419, 422-717); compute_reward
  * (add_reward.py:103-177); compute_done (add_done.py:96-147); ReturnTracker.update
- * (base_agent.py:596-621).  `head` = ring slot that receives the new state. */
+ * (base_agent.py:596-621).  `head` = ring slot that receives the new state.
+ * Two launches: observations + ring push + reference rows, then reward / done / return tracker.
+ * task.enable_vel_obs adds the velocity terms of compute_char_obs / compute_vel_obs
+ * (add_observation.py:445-452, 502-517; needs e->hist_vel); task.enable_phase_obs adds
+ * compute_phase_obs (:557-575). */
 int addhip_env_step(const addhip_motion_t* m, const addhip_task_t* t, const addhip_env_t* e,
                     const addhip_step_out_t* o, int32_t head, void* stream);
 

@@ -330,3 +330,26 @@ def test_multi_clip_library_and_corrected_offsets():
             idx = lib.step_index(ag._S["motion_id"], t).cpu().numpy()
             start, cnt = lib._step_start.numpy(), lib._step_counts.numpy()
             assert np.all((idx >= start[ids]) & (idx < start[ids] + cnt[ids]))
+
+
+def test_velocity_and_phase_observations_train_end_to_end():
+    """task.enable_vel_obs / enable_phase_obs widen obs to 308 and disc obs to 219 columns; the whole iteration
+    (rollout, velocity history ring, discriminator, update) runs on those widths.  Per-element parity of the wider
+    rows is pinned in test_hip_env (golden variants vel_phase / local_vel)."""
+    import torch
+    import add_gym_amd.learning.add_agent as A
+
+    cfg = make_cfg(128, steps_per_iter=8)
+    cfg["task"].update(motion_file="synthetic:2x240", enable_vel_obs=True, enable_phase_obs=True, num_phase_encoding=4)
+    ag = A.ADDAgent(cfg)
+    assert (ag._task.obs_dim, ag._task.disc_dim) == (264 + 35 + 9, 3 * (38 + 35))
+    ag.reset_all_envs()
+    ag._init_train()
+    info = ag._train_iter()
+    torch.cuda.synchronize()
+    assert all(np.isfinite(v) for v in info.values())
+    # the velocity ring's newest slot holds the simulator velocities of the last step
+    # (for envs reset at the end of the step: the clip velocities the reset wrote to both places)
+    hv = ag._S["hist_vel"]
+    assert torch.isfinite(hv).all() and float(hv.abs().sum()) > 0
+    assert torch.equal(hv[:, (ag._head - 1) % 3], ag._S["sim_vel"])
