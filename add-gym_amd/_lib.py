@@ -41,7 +41,7 @@ class EnvT(C.Structure):
 
 
 class StepOutT(C.Structure):
-    _fields_ = [("obs", f32p), ("obs_next_in", f32p), ("disc_obs", f32p), ("disc_demo", f32p), ("reward", f32p), ("done", f32p),
+    _fields_ = [("obs", f32p), ("obs_next_in", f32p), ("obs_timeout", f32p), ("disc_obs", f32p), ("disc_demo", f32p), ("reward", f32p), ("done", f32p),
                 ("motion_id_rec", f32p), ("motion_time_rec", f32p), ("ep_stats", f32p)]
 
 
@@ -86,7 +86,7 @@ SIGNATURES = {
     "addhip_sampler_update": [P(SamplerT), i32, vp],
     "addhip_disc_reward": [vp, vp, i64, f32, f32, f32, vp, vp],
     "addhip_head_gemv": [vp, i32, i32, i64, vp, vp, vp, vp],
-    "addhip_td_lambda_adv": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
+    "addhip_td_lambda_adv": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
     "addhip_norm_accum": [vp, i64, i32, i32, vp, vp, vp],
     "addhip_norm_merge": [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
     "addhip_diffnorm_merge": [vp, vp, vp, i64, i32, vp],

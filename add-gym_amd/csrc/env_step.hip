@@ -178,26 +178,23 @@ __device__ __forceinline__ Role lane_role(const addhip_task_t& t, const Tables& 
   else if (r == R_DEMO1 || (r == R_H1 && fresh)) { kind = K_POSE; dt = t.demo_dt[1]; }
   else if (r == R_H0) { kind = K_HIST; hslot = h0; }
   else if (r == R_H1) { kind = K_HIST; hslot = h1; }
+  else if (r == R_SIMV) { if (VEL || !FRESH) kind = fresh ? K_VEL : K_SIMV; }  // the step's reward reads it too
   else if (VEL) {
-    if (r == R_SIMV) kind = fresh ? K_VEL : K_SIMV;
-    else if (r == R_D0V || (r == R_H0V && fresh)) { kind = K_VEL; dt = t.demo_dt[0]; }
+    if (r == R_D0V || (r == R_H0V && fresh)) { kind = K_VEL; dt = t.demo_dt[0]; }
     else if (r == R_D1V || (r == R_H1V && fresh)) { kind = K_VEL; dt = t.demo_dt[1]; }
     else if (r == R_H0V) { kind = K_HISTV; hslot = h0; }
     else if (r == R_H1V) { kind = K_HISTV; hslot = h1; }
   }
   Role ro{ROLE_SKIP, dt, nullptr, PW};
   if (kind == K_SKIP) return ro;
-  if (FRESH || kind == K_POSE || kind == K_VEL) {
-    ro.kind = ROLE_TABLE;
-    ro.base = (kind == K_POSE ? tb.pose : tb.vel) + q * 9;
-  } else if (kind == K_SIM || (VEL && kind == K_SIMV)) {
-    ro.kind = ROLE_ENV;
-    ro.base = (kind == K_SIM ? ep.sim_pose : ep.sim_vel) + q * 9;
-  } else {
-    ro.kind = ROLE_ENV;
-    ro.base = ((VEL && kind == K_HISTV) ? ep.hist_vel : ep.hist) + hslot * PW + q * 9;
-    ro.mul = ADDHIP_HIST * PW;
-  }
+  // base pointer by masks, not by a select chain (which the optimiser turns into a pointer table in scratch memory)
+  auto pick = [](bool c, const float* p) -> unsigned long long { return c ? (unsigned long long)p : 0ull; };
+  unsigned long long b = pick(kind == K_POSE, tb.pose) | pick(kind == K_VEL, tb.vel);
+  if (!FRESH) b |= pick(kind == K_SIM, ep.sim_pose) | pick(kind == K_SIMV, ep.sim_vel) | pick(kind == K_HIST, ep.hist) | pick(kind == K_HISTV, ep.hist_vel);
+  const bool table = FRESH || kind == K_POSE || kind == K_VEL, ring = kind == K_HIST || kind == K_HISTV;
+  ro.kind = table ? ROLE_TABLE : ROLE_ENV;
+  ro.base = reinterpret_cast<const float*>(b) + (ring ? hslot * PW : 0) + q * 9;
+  ro.mul = ring ? ADDHIP_HIST * PW : PW;
   return ro;
 }
 
@@ -215,6 +212,24 @@ __device__ __forceinline__ void stage_rows(float* w, const Role& ro, const Table
   *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
   *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
   dst[8] = v[8];
+}
+
+// the two halves of stage_rows, so that the loads of the next env can be in flight while the current one is emitted
+struct RowRegs { float v[9]; };
+__device__ __forceinline__ void load_rows(RowRegs& rr, const Role& ro, const Tables& tb, int env, int cstart, int csteps, float tm) {
+  if (ro.kind == ROLE_SKIP) return;
+  int row = env;
+  if (ro.kind == ROLE_TABLE) row = step_index(__fadd_rn(tm, ro.dt), tb.dt_inv, tb.total_steps, cstart, csteps, tb.compat);
+  const float* src = ro.base + (size_t)(unsigned)(row * ro.mul);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) rr.v[i] = src[i];
+}
+__device__ __forceinline__ void store_rows(float* w, const RowRegs& rr, const Role& ro, int pass, int lane) {
+  if (ro.kind == ROLE_SKIP) return;
+  float* dst = w + OFF_ROWS + (pass * 16 + (lane >> 2)) * LROW + (lane & 3) * 12;
+  *reinterpret_cast<float4*>(dst) = make_float4(rr.v[0], rr.v[1], rr.v[2], rr.v[3]);
+  *reinterpret_cast<float4*>(dst + 4) = make_float4(rr.v[4], rr.v[5], rr.v[6], rr.v[7]);
+  dst[8] = rr.v[8];
 }
 
 __device__ __forceinline__ Quat lds_quat(const float* w, int r) {
@@ -280,110 +295,71 @@ __device__ __forceinline__ void derive(const addhip_task_t& t, float* w, int lan
   }
 }
 
+// n is a multiple of 4 and rows are 16-byte aligned: one 16-byte store per lane per pass
 __device__ __forceinline__ void emit(const float* w, const short* map, int n, float* out, int lane) {
-  for (int o = lane; o < n; o += 64) out[o] = w[map[o]];
-}
-
-struct ObsArgs {
-  Tables tb;
-  const float* sim_pose; const float* sim_vel; const float* time; const float* time_off; const int* motion_id; float* hist; float* hist_vel;
-  const float* clip_len;
-  float* ref_pose; float* ref_vel;
-  float* obs; float* obs2; float* disc; float* demo;
-  int num_envs, head;
-};
-
-template <bool GLOBAL, bool VEL, bool PHASE>
-__global__ __launch_bounds__(64 * WAVES) void env_obs_kernel(addhip_task_t t, ObsArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[WAVES][work_of(VEL)];
-  __shared__ short maps[map_of(VEL, PHASE)];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float* w = lds[wv];
-  build_maps(t, maps);
-  const int h0 = (a.head + 1) % ADDHIP_HIST, h1 = (a.head + 2) % ADDHIP_HIST;
-  const EnvPtrs ep{a.sim_pose, a.sim_vel, a.hist, a.hist_vel};
-  const Role ro = lane_role<VEL, false>(t, a.tb, ep, lane, 0, h0, h1);
-  Role ro1{ROLE_SKIP, 0.0f, nullptr, PW};
-  if (VEL) ro1 = lane_role<VEL, false>(t, a.tb, ep, lane, 1, h0, h1);
-  const int n_obs = t.obs_stride, n_disc = t.disc_stride;
-  const int groups = (a.num_envs + WAVES - 1) / WAVES;
-  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
-    const int env = g * WAVES + wv;
-    const bool valid = env < a.num_envs;
-    float phase = 0.0f;
-    if (valid) {
-      const float time_new = __fadd_rn(a.time[env], t.dt);     // env.py:155 (written back by env_reward_kernel)
-      const int id = a.motion_id[env];
-      const float tm = __fadd_rn(time_new, a.time_off[env]);   // add_observation.py:352-354
-      const int cstart = a.tb.clip_start[id], csteps = a.tb.clip_steps[id];
-      stage_rows(w, ro, a.tb, 0, env, cstart, csteps, tm, lane);
-      if (VEL) stage_rows(w, ro1, a.tb, 1, env, cstart, csteps, tm, lane);
-      if (PHASE) phase = fminf(fmaxf(__fdiv_rn(tm, a.clip_len[id]), 0.0f), 1.0f);  // motion_lib.py:361-372 (CLAMP clips)
-    }
-    __syncthreads();
-    if (valid) derive<GLOBAL, VEL, PHASE>(t, w, lane, phase);
-    __syncthreads();
-    if (valid) {
-      if (a.obs) emit(w, maps, n_obs, a.obs + (size_t)env * n_obs, lane);
-      if (a.obs2) emit(w, maps, n_obs, a.obs2 + (size_t)env * n_obs, lane);
-      if (a.disc) emit(w, maps + n_obs, n_disc, a.disc + (size_t)env * n_disc, lane);
-      if (a.demo) emit(w, maps + n_obs + n_disc, n_disc, a.demo + (size_t)env * n_disc, lane);
-      if (lane < PW) {
-        // history push (circular_buffer.py:17-20) and reference state (add_observation.py:163-174)
-        a.hist[((size_t)env * ADDHIP_HIST + a.head) * PW + lane] = w[row_off(R_SIM, lane)];
-        if (VEL) a.hist_vel[((size_t)env * ADDHIP_HIST + a.head) * PW + lane] = w[row_off(R_SIMV, lane)];
-        a.ref_pose[(size_t)env * PW + lane] = w[row_off(R_REF, lane)];
-        a.ref_vel[(size_t)env * PW + lane] = w[row_off(R_REFV, lane)];
-      }
-    }
-    __syncthreads();
+  for (int o = lane * 4; o < n; o += 256) {
+    const short4 m = *reinterpret_cast<const short4*>(map + o);
+    *reinterpret_cast<float4*>(out + o) = make_float4(w[m.x], w[m.y], w[m.z], w[m.w]);
   }
 }
+
+// wave-private LDS hand-off: DS operations of one wave execute in program order, so only the compiler must be kept
+// from moving accesses across the phase boundary
+__device__ __forceinline__ void wave_sync() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
+struct StepArgs {
+  Tables tb;
+  const float* sim_pose; const float* sim_vel; float* time; const float* time_off; const int* motion_id; float* hist; float* hist_vel;
+  const float* clip_len; const int* clip_loop;
+  int* done; const unsigned char* contact; float* ret_acc; int* len_acc;
+  float* ref_pose; float* ref_vel;
+  float* obs; float* obs2; float* obs_timeout; float* disc; float* demo;
+  float* reward; int* done_rec; int* motion_id_rec; float* motion_time_rec; float* ep_stats;
+  int num_envs, head, envs_per_wave;
+};
 
 // ---- reward (add_reward.py:103-177), done (add_done.py:96-147), return tracker (base_agent.py:596-621) ---------
-struct RewardArgs {
-  const float* sim_pose; const float* sim_vel; const float* ref_pose; const float* ref_vel;
-  float* time; const float* time_off; const int* motion_id; int* done; const unsigned char* contact;
-  const float* clip_len; const int* clip_loop;
-  float* ret_acc; int* len_acc;
-  float* reward; int* done_rec; int* motion_id_rec; float* motion_time_rec; float* ep_stats;
-  int num_envs;
-};
+// Per env the wave leaves 31 values in an LDS slot: the 26 root values of simulator and reference (sim pos3 quat4 |
+// ref pos3 quat4 | sim vel3 ang3 | ref vel3 ang3), the two dof error sums, the clocks and the clip id.  Once per
+// group of up to SLOT_MAX consecutive envs, ONE LANE PER ENV does the scalar part (quaternion angle, four exp, flags,
+// tracker): its ~300 instructions are paid once per group instead of once per env, and its loads / stores of the
+// per-env scalars are coalesced.
+constexpr int SLOT_MAX = 16, SLOT_W = 33;  // odd stride: conflict-free lane-per-slot reads
+enum { S_PE = 26, S_VE = 27, S_TIME = 28, S_TM = 29, S_ID = 30 };
 
+// LDS source of root value j (0..25) in the staged rows
+__device__ __forceinline__ int root_src(int j) {
+  if (j < 7) return row_off(R_SIM, j);
+  if (j < 14) return row_off(R_REF, j - 7);
+  if (j < 20) return row_off(R_SIMV, j - 14);
+  return row_off(R_REFV, j - 20);
+}
+
+// returns the wave-wide mask of lanes (= envs of the group) that finished with DONE_TIME
 template <bool GLOBAL>
-__global__ __launch_bounds__(256) void env_reward_kernel(addhip_task_t t, RewardArgs a) {
-  const int l = threadIdx.x & 15;
-  const int env = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const bool valid = env < a.num_envs;
-  const int e = valid ? env : a.num_envs - 1;
-  const float* sp = a.sim_pose + (size_t)e * PW;
-  const float* sv = a.sim_vel + (size_t)e * PW;
-  const float* rp = a.ref_pose + (size_t)e * PW;
-  const float* rv = a.ref_vel + (size_t)e * PW;
-  // joint weights are all 1 (add_reward.py:31-34); lanes cover dofs l and l+16
-  float pe = 0.0f, ve = 0.0f;
-  {
-    float d = rp[7 + l] - sp[7 + l];
-    pe = d * d;
-    float dv = rv[6 + l] - sv[6 + l];
-    ve = dv * dv;
-    if (l + 16 < ADDHIP_NUM_DOF) {
-      d = rp[7 + 16 + l] - sp[7 + 16 + l];
-      pe += d * d;
-      dv = rv[6 + 16 + l] - sv[6 + 16 + l];
-      ve += dv * dv;
-    }
-  }
-  pe = group_sum16(pe);
-  ve = group_sum16(ve);
-  if (l != 0 || !valid) return;
+__device__ __forceinline__ unsigned long long reward_done_group(const addhip_task_t& t, const StepArgs& a, const float* slots, int first_env,
+                                                                int count, int lane) {
+  const bool valid = lane < count;
+  const int env = first_env + (valid ? lane : 0);
+  const float* rt = slots + (valid ? lane : 0) * SLOT_W;
+  const bool contact = a.contact ? (a.contact[env] != 0) : false;
+  const float ret_old = a.ret_acc ? a.ret_acc[env] : 0.0f;
+  const int len_old = a.ret_acc ? a.len_acc[env] : 0;
+  const int id = __float_as_int(rt[S_ID]);
+  const float clip_len = a.clip_len[id];
+  const int clip_loop = a.clip_loop[id];
+  const float pe = rt[S_PE], ve = rt[S_VE], time_new = rt[S_TIME], tm = rt[S_TM];
+  const float dx = rt[7] - rt[0], dy = rt[8] - rt[1], dz = rt[9] - rt[2];
+  Quat q_sim{rt[3], rt[4], rt[5], rt[6]}, q_ref{rt[10], rt[11], rt[12], rt[13]};
+  Vec3 v_sim{rt[14], rt[15], rt[16]}, w_sim{rt[17], rt[18], rt[19]}, v_ref{rt[20], rt[21], rt[22]}, w_ref{rt[23], rt[24], rt[25]};
   const bool track_root = (t.num_tar_steps > 0) && GLOBAL;  // add_observation.py:349-350
-  const float dx = rp[0] - sp[0], dy = rp[1] - sp[1], dz = rp[2] - sp[2];
   const float root_err_full = dx * dx + dy * dy + dz * dz;
   const float rx = track_root ? dx : 0.0f, ry = track_root ? dy : 0.0f, rz = t.root_height_obs ? dz : 0.0f;
   const float root_pos_err = rx * rx + ry * ry + rz * rz;
-  Quat q_sim{sp[3], sp[4], sp[5], sp[6]}, q_ref{rp[3], rp[4], rp[5], rp[6]};
-  Vec3 v_sim{sv[0], sv[1], sv[2]}, w_sim{sv[3], sv[4], sv[5]}, v_ref{rv[0], rv[1], rv[2]}, w_ref{rv[3], rv[4], rv[5]};
   if (!track_root) {  // convert_to_local_root (add_reward.py:91-101)
     const Quat hs = heading_quat_inv(q_sim), hr = heading_quat_inv(q_ref);
     v_sim = quat_rotate(hs, v_sim); w_sim = quat_rotate(hs, w_sim); q_sim = quat_mul(hs, q_sim);
@@ -398,14 +374,11 @@ __global__ __launch_bounds__(256) void env_reward_kernel(addhip_task_t t, Reward
   const float r = t.pose_w * expf(-t.pose_scale * pe) + t.vel_w * expf(-t.vel_scale * ve) +
                   t.root_pose_w * expf(-t.root_pose_scale * (root_pos_err + 0.1f * rot_err)) +
                   t.root_vel_w * expf(-t.root_vel_scale * (root_vel_err + 0.1f * root_ang_err));
-  const float time_new = __fadd_rn(a.time[env], t.dt);
-  const int id = a.motion_id[env];
-  const float tm = __fadd_rn(time_new, a.time_off[env]);
   int done = ADDHIP_DONE_NULL;
   if (time_new >= t.max_episode_length) done = ADDHIP_DONE_TIME;
-  if (tm >= a.clip_len[id] && a.clip_loop[id] != 1) done = ADDHIP_DONE_SUCC;
+  if (tm >= clip_len && clip_loop != 1) done = ADDHIP_DONE_SUCC;
   if (t.enable_early_termination) {
-    bool failed = a.contact ? (a.contact[env] != 0) : false;
+    bool failed = contact;
     if (t.pose_termination) {
       bool pose_fail = (pe / (float)ADDHIP_NUM_DOF) > t.pose_termination_dist;
       if (track_root) pose_fail = pose_fail || (root_err_full > t.pose_termination_dist);
@@ -413,26 +386,131 @@ __global__ __launch_bounds__(256) void env_reward_kernel(addhip_task_t t, Reward
     }
     if (failed && time_new > 0.0f) done = ADDHIP_DONE_FAIL;
   }
-  a.time[env] = time_new;
-  a.done[env] = done;
-  if (a.done_rec) a.done_rec[env] = done;
-  if (a.reward) a.reward[env] = r;
-  if (a.motion_id_rec) a.motion_id_rec[env] = id;
-  if (a.motion_time_rec) a.motion_time_rec[env] = tm;
+  if (valid) {
+    a.time[env] = time_new;
+    a.done[env] = done;
+    if (a.done_rec) a.done_rec[env] = done;
+    if (a.reward) a.reward[env] = r;
+    if (a.motion_id_rec) a.motion_id_rec[env] = id;
+    if (a.motion_time_rec) a.motion_time_rec[env] = tm;
+  }
   if (a.ret_acc) {
-    float ra = a.ret_acc[env] + r;
-    int la = a.len_acc[env] + 1;
-    if (done != ADDHIP_DONE_NULL) {
-      if (a.ep_stats) {
-        atomicAdd(&a.ep_stats[0], ra);
-        atomicAdd(&a.ep_stats[1], (float)la);
-        atomicAdd(&a.ep_stats[2], 1.0f);
+    const float ra = ret_old + r;
+    const int la = len_old + 1;
+    const bool finished = valid && done != ADDHIP_DONE_NULL;
+    if (a.ep_stats && __ballot(finished)) {  // one atomic triple per group, not per finished episode
+      const float s_ret = wave_sum(finished ? ra : 0.0f), s_len = wave_sum(finished ? (float)la : 0.0f), s_cnt = wave_sum(finished ? 1.0f : 0.0f);
+      if (lane == 0) {
+        atomicAdd(&a.ep_stats[0], s_ret);
+        atomicAdd(&a.ep_stats[1], s_len);
+        atomicAdd(&a.ep_stats[2], s_cnt);
       }
-      ra = 0.0f;
-      la = 0;
     }
-    a.ret_acc[env] = ra;
-    a.len_acc[env] = la;
+    if (valid) {
+      a.ret_acc[env] = finished ? 0.0f : ra;
+      a.len_acc[env] = finished ? 0 : la;
+    }
+  }
+  return __ballot(valid && done == ADDHIP_DONE_TIME);
+}
+
+template <bool GLOBAL, bool VEL, bool PHASE>
+__global__ __launch_bounds__(64 * WAVES) void env_step_kernel(addhip_task_t t, StepArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[WAVES][work_of(VEL)];
+  __shared__ float slot_mem[WAVES][SLOT_MAX * SLOT_W];
+  __shared__ short maps[map_of(VEL, PHASE)];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* w = lds[wv];
+  float* slots = slot_mem[wv];
+  build_maps(t, maps);
+  const int h0 = (a.head + 1) % ADDHIP_HIST, h1 = (a.head + 2) % ADDHIP_HIST;
+  const EnvPtrs ep{a.sim_pose, a.sim_vel, a.hist, a.hist_vel};
+  const Role ro = lane_role<VEL, false>(t, a.tb, ep, lane, 0, h0, h1);
+  Role ro1{ROLE_SKIP, 0.0f, nullptr, PW};
+  if (VEL) ro1 = lane_role<VEL, false>(t, a.tb, ep, lane, 1, h0, h1);
+  const int n_obs = t.obs_stride, n_disc = t.disc_stride;
+  // loop-invariant LDS offsets of this lane's reward inputs: lanes 0-28 dof positions, 32-60 dof velocities; lanes
+  // 0-25 also copy one root value each
+  const int hl = lane & 31;
+  const bool dof_lane = hl < ADDHIP_NUM_DOF;
+  const int dof_a = lane < 32 ? row_off(R_REF, 7 + (dof_lane ? hl : 0)) : row_off(R_REFV, 6 + (dof_lane ? hl : 0));
+  const int dof_b = lane < 32 ? row_off(R_SIM, 7 + (dof_lane ? hl : 0)) : row_off(R_SIMV, 6 + (dof_lane ? hl : 0));
+  const int root_off = root_src(lane < 26 ? lane : 0);
+  __syncthreads();  // maps; from here on the waves of a workgroup run independently
+  // a wave owns ONE group of envs_per_wave consecutive envs (no outer loop: the scalar phase after the env loop then
+  // starts from an empty register file instead of having its constants hoisted across the loop)
+  {
+    const int first = (blockIdx.x * WAVES + wv) * a.envs_per_wave;
+    const int count = min(a.envs_per_wave, a.num_envs - first);
+    if (count <= 0) return;
+    // per-env scalars of the whole group, lane k <-> env first+k: two dependent loads per GROUP instead of per env
+    const int mine = first + min(lane, count - 1);
+    const float g_time = __fadd_rn(a.time[mine], t.dt);       // env.py:155
+    const int g_id = a.motion_id[mine];
+    const float g_tm = __fadd_rn(g_time, a.time_off[mine]);   // add_observation.py:352-354
+    const int g_cstart = a.tb.clip_start[g_id], g_csteps = a.tb.clip_steps[g_id];
+    float g_phase = 0.0f;
+    if (PHASE) g_phase = fminf(fmaxf(__fdiv_rn(g_tm, a.clip_len[g_id]), 0.0f), 1.0f);  // motion_lib.py:361-372 (CLAMP clips)
+    RowRegs r0, r1;
+    load_rows(r0, ro, a.tb, first, __builtin_amdgcn_readlane(g_cstart, 0), __builtin_amdgcn_readlane(g_csteps, 0),
+              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_tm), 0)));
+    if (VEL) load_rows(r1, ro1, a.tb, first, __builtin_amdgcn_readlane(g_cstart, 0), __builtin_amdgcn_readlane(g_csteps, 0),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_tm), 0)));
+    for (int k = 0; k < count; ++k) {
+      const int env = first + k;
+      const float time_new = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_time), k));
+      const float tm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_tm), k));
+      const int id = __builtin_amdgcn_readlane(g_id, k);
+      const float phase = PHASE ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_phase), k)) : 0.0f;
+      store_rows(w, r0, ro, 0, lane);
+      if (VEL) store_rows(w, r1, ro1, 1, lane);
+      wave_sync();
+      if (k + 1 < count) {  // next env's rows: in flight during derive + emit of this one
+        const int cs = __builtin_amdgcn_readlane(g_cstart, k + 1), cn = __builtin_amdgcn_readlane(g_csteps, k + 1);
+        const float tn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_tm), k + 1));
+        load_rows(r0, ro, a.tb, env + 1, cs, cn, tn);
+        if (VEL) load_rows(r1, ro1, a.tb, env + 1, cs, cn, tn);
+      }
+      derive<GLOBAL, VEL, PHASE>(t, w, lane, phase);
+      {  // reward inputs of this env -> slot k
+        float* sl = slots + k * SLOT_W;
+        float sq = 0.0f;
+        if (dof_lane) { const float d = w[dof_a] - w[dof_b]; sq = d * d; }  // joint weights are all 1 (add_reward.py:31-34)
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        if (lane < 26) sl[lane] = w[root_off];
+        if (lane == 0) { sl[S_PE] = sq; sl[S_TIME] = time_new; sl[S_TM] = tm; sl[S_ID] = __int_as_float(id); }
+        if (lane == 32) sl[S_VE] = sq;
+      }
+      wave_sync();
+      if (a.obs) emit(w, maps, n_obs, a.obs + (size_t)env * n_obs, lane);
+      if (a.obs2) emit(w, maps, n_obs, a.obs2 + (size_t)env * n_obs, lane);
+      if (a.disc) emit(w, maps + n_obs, n_disc, a.disc + (size_t)env * n_disc, lane);
+      if (a.demo) emit(w, maps + n_obs + n_disc, n_disc, a.demo + (size_t)env * n_disc, lane);
+      if (lane < PW) {
+        // history push (circular_buffer.py:17-20) and, optionally, the reference state (add_observation.py:163-174)
+        a.hist[((size_t)env * ADDHIP_HIST + a.head) * PW + lane] = w[row_off(R_SIM, lane)];
+        if (VEL) a.hist_vel[((size_t)env * ADDHIP_HIST + a.head) * PW + lane] = w[row_off(R_SIMV, lane)];
+        if (a.ref_pose) a.ref_pose[(size_t)env * PW + lane] = w[row_off(R_REF, lane)];
+        if (a.ref_vel) a.ref_vel[(size_t)env * PW + lane] = w[row_off(R_REFV, lane)];
+      }
+      wave_sync();
+    }
+    unsigned long long timed_out = reward_done_group<GLOBAL>(t, a, slots, first, count, lane);
+    if (timed_out && a.obs_timeout && a.obs) {
+      // rare (once per max_episode_length per env): keep the pre-reset obs row of these envs for the critic's
+      // next-value (ppo_agent.py:117-133); the reset kernel is about to overwrite it in the obs slot.  The rows were
+      // stored by this wave above: make them visible to its own loads first.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      while (timed_out) {
+        const int k = __ffsll((long long)timed_out) - 1;
+        timed_out &= timed_out - 1;
+        const float* src = a.obs + (size_t)(first + k) * n_obs;
+        float* dst = a.obs_timeout + (size_t)(first + k) * n_obs;
+        for (int o = lane; o < n_obs; o += 64) dst[o] = __builtin_nontemporal_load(src + o);
+      }
+    }
   }
 }
 
@@ -489,12 +567,11 @@ __global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_task_t t, 
   Role ro1{ROLE_SKIP, 0.0f, nullptr, PW};
   if (VEL) ro1 = lane_role<VEL, true>(t, a.tb, ep, lane, 1, 0, 0);
   const int n_obs = t.obs_stride, n_disc = t.disc_stride;
-  const int groups = (a.num_envs + WAVES - 1) / WAVES;
-  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
-    const int env = g * WAVES + wv;
-    const bool active = env < a.num_envs && (a.reset_all || a.done[env] != ADDHIP_DONE_NULL);
+  __syncthreads();  // maps
+  for (int env = blockIdx.x * WAVES + wv; env < a.num_envs; env += gridDim.x * WAVES) {
+    if (!a.reset_all && a.done[env] == ADDHIP_DONE_NULL) continue;  // wave-uniform
     float off = 0.0f, phase = 0.0f;
-    if (active) {
+    {
       const int id = a.motion_id[env];
       if (s.rand_reset) {
         // AdaptiveSegmentSampler.get_probs + multinomial by inverse CDF (sampler.py:57-80)
@@ -525,10 +602,10 @@ __global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_task_t t, 
       if (VEL) stage_rows(w, ro1, a.tb, 1, env, cstart, csteps, off, lane);
       if (PHASE) phase = fminf(fmaxf(__fdiv_rn(off, a.clip_len[id]), 0.0f), 1.0f);
     }
-    __syncthreads();
-    if (active) derive<GLOBAL, VEL, PHASE>(t, w, lane, phase);
-    __syncthreads();
-    if (active) {
+    wave_sync();
+    derive<GLOBAL, VEL, PHASE>(t, w, lane, phase);
+    wave_sync();
+    {
       if (a.obs) emit(w, maps, n_obs, a.obs + (size_t)env * n_obs, lane);
       if (a.disc) emit(w, maps + n_obs, n_disc, a.disc + (size_t)env * n_disc, lane);
       if (a.demo) emit(w, maps + n_obs + n_disc, n_disc, a.demo + (size_t)env * n_disc, lane);
@@ -557,7 +634,7 @@ __global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_task_t t, 
         a.done[env] = ADDHIP_DONE_NULL;  // add_done.py:92-93
       }
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -604,8 +681,8 @@ int check_common(const addhip_motion_t* m, const addhip_task_t* t, const addhip_
   ADDHIP_REQUIRE(t->obs_stride >= t->obs_dim && t->disc_stride >= t->disc_dim, "strides smaller than dims");
   const int map_max = map_of(t->enable_vel_obs != 0, t->enable_phase_obs != 0);
   ADDHIP_REQUIRE(t->obs_stride + 2 * t->disc_stride <= map_max, "obs_stride + 2*disc_stride must be <= %d", map_max);
-  ADDHIP_REQUIRE(e->sim_pose && e->sim_vel && e->time && e->time_off && e->motion_id && e->hist && e->done && e->ref_pose && e->ref_vel,
-                 "env state pointers missing");
+  ADDHIP_REQUIRE(e->sim_pose && e->sim_vel && e->time && e->time_off && e->motion_id && e->hist && e->done, "env state pointers missing");
+  ADDHIP_REQUIRE(!e->ret_acc || e->len_acc, "ret_acc needs len_acc");
   return 0;
 }
 
@@ -623,32 +700,32 @@ extern "C" int addhip_env_step(const addhip_motion_t* m, const addhip_task_t* t,
                                const addhip_step_out_t* o, int32_t head, void* stream) {
   if (int rc = check_common(m, t, e)) return rc;
   ADDHIP_REQUIRE(o, "null outputs");
+  ADDHIP_REQUIRE(!o->obs_timeout || o->obs, "obs_timeout needs obs");
   ADDHIP_REQUIRE(head >= 0 && head < ADDHIP_HIST, "head out of range");
   hipStream_t st = (hipStream_t)stream;
-  ObsArgs a{tables_of(m), e->sim_pose, e->sim_vel, e->time, e->time_off, e->motion_id, e->hist, e->hist_vel, m->clip_len, e->ref_pose, e->ref_vel,
-            o->obs, o->obs_next_in, o->disc_obs, o->disc_demo, e->num_envs, head};
-  const dim3 grid(env_grid(e->num_envs)), block(64 * WAVES);
+  // envs per wave: enough waves to fill the chip (256 CUs x ~24 resident waves) first, then amortise the per-group part
+  int epw = e->num_envs / 8192;
+  epw = epw < 1 ? 1 : (epw > SLOT_MAX ? SLOT_MAX : epw);
+  StepArgs a{tables_of(m), e->sim_pose, e->sim_vel, e->time, e->time_off, e->motion_id, e->hist, e->hist_vel, m->clip_len, m->clip_loop,
+             e->done, e->contact, e->ret_acc, e->len_acc, e->ref_pose, e->ref_vel, o->obs, o->obs_next_in, o->obs_timeout, o->disc_obs, o->disc_demo,
+             o->reward, o->done, o->motion_id_rec, o->motion_time_rec, o->ep_stats, e->num_envs, head, epw};
+  const int groups = (e->num_envs + epw - 1) / epw;
+  const int blocks = (groups + WAVES - 1) / WAVES;
+  const dim3 grid(blocks), block(64 * WAVES);
   const int variant = (t->global_obs ? 4 : 0) | (t->enable_vel_obs ? 2 : 0) | (t->enable_phase_obs ? 1 : 0);
-#define ADDHIP_OBS(G, V, P) hipLaunchKernelGGL((env_obs_kernel<G, V, P>), grid, block, 0, st, *t, a)
+#define ADDHIP_STEP(G, V, P) hipLaunchKernelGGL((env_step_kernel<G, V, P>), grid, block, 0, st, *t, a)
   switch (variant) {
-    case 0: ADDHIP_OBS(false, false, false); break;
-    case 1: ADDHIP_OBS(false, false, true); break;
-    case 2: ADDHIP_OBS(false, true, false); break;
-    case 3: ADDHIP_OBS(false, true, true); break;
-    case 4: ADDHIP_OBS(true, false, false); break;
-    case 5: ADDHIP_OBS(true, false, true); break;
-    case 6: ADDHIP_OBS(true, true, false); break;
-    default: ADDHIP_OBS(true, true, true); break;
+    case 0: ADDHIP_STEP(false, false, false); break;
+    case 1: ADDHIP_STEP(false, false, true); break;
+    case 2: ADDHIP_STEP(false, true, false); break;
+    case 3: ADDHIP_STEP(false, true, true); break;
+    case 4: ADDHIP_STEP(true, false, false); break;
+    case 5: ADDHIP_STEP(true, false, true); break;
+    case 6: ADDHIP_STEP(true, true, false); break;
+    default: ADDHIP_STEP(true, true, true); break;
   }
-#undef ADDHIP_OBS
-  if (int rc = check_launch("env_obs_kernel")) return rc;
-  RewardArgs r{e->sim_pose, e->sim_vel, e->ref_pose, e->ref_vel, e->time, e->time_off, e->motion_id, e->done, e->contact,
-               m->clip_len, m->clip_loop, e->ret_acc, e->len_acc, o->reward, o->done, o->motion_id_rec, o->motion_time_rec, o->ep_stats,
-               e->num_envs};
-  const int blocks = (e->num_envs * 16 + 255) / 256;
-  if (t->global_obs) hipLaunchKernelGGL(env_reward_kernel<true>, dim3(blocks), dim3(256), 0, st, *t, r);
-  else hipLaunchKernelGGL(env_reward_kernel<false>, dim3(blocks), dim3(256), 0, st, *t, r);
-  return check_launch("env_reward_kernel");
+#undef ADDHIP_STEP
+  return check_launch("env_step_kernel");
 }
 
 extern "C" int addhip_env_reset(const addhip_motion_t* m, const addhip_task_t* t, const addhip_env_t* e,

@@ -196,9 +196,9 @@ __global__ __launch_bounds__(256) void head_gemv_kernel(const float* H, int ld, 
 }
 
 // ------------------------------------------------------------------ TD(lambda) + advantage
-__global__ __launch_bounds__(256) void td_lambda_kernel(const float* reward, float* next_vals, const float* vals, const int* done,
-                                                        const float* rand_mask, int T, int N, float discount, float lam, float succ_val,
-                                                        float fail_val, float* tar_val, float* adv, double* partial) {
+__global__ __launch_bounds__(256) void td_lambda_kernel(const float* reward, const float* next_vals, const float* timeout_vals, const float* vals,
+                                                        const int* done, const float* rand_mask, int T, int N, float discount, float lam,
+                                                        float succ_val, float fail_val, float* tar_val, float* adv, double* partial) {
   __shared__ double shd[3][4];
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   double s1 = 0.0, s2 = 0.0, cnt = 0.0;
@@ -208,9 +208,9 @@ __global__ __launch_bounds__(256) void td_lambda_kernel(const float* reward, flo
       const size_t i = (size_t)t * N + n;
       const int d = done[i];
       float nv = next_vals[i];
+      if (d == ADDHIP_DONE_TIME && timeout_vals) nv = timeout_vals[n];  // V(true next obs); next_vals row holds the reset obs
       if (d == ADDHIP_DONE_SUCC) nv = succ_val;  // ppo_agent.py:127-133
       if (d == ADDHIP_DONE_FAIL) nv = fail_val;
-      next_vals[i] = nv;
       float ret;
       if (t == T - 1) {
         ret = __fadd_rn(reward[i], __fmul_rn(discount, nv));  // base_agent.py:632-633
@@ -594,17 +594,17 @@ extern "C" int addhip_head_gemv(const float* H, int32_t ld, int32_t K, int64_t r
   return addhip::check_launch("head_gemv_kernel");
 }
 
-extern "C" int addhip_td_lambda_adv(const float* reward, float* next_vals, const float* vals, const int32_t* done, const float* rand_mask, int32_t T,
-                                    int32_t N, float discount, float td_lambda, float succ_val, float fail_val, float adv_clip, float* tar_val,
-                                    float* adv, float* scratch, float* stats_out, void* stream) {
+extern "C" int addhip_td_lambda_adv(const float* reward, const float* next_vals, const float* timeout_vals, const float* vals, const int32_t* done,
+                                    const float* rand_mask, int32_t T, int32_t N, float discount, float td_lambda, float succ_val, float fail_val,
+                                    float adv_clip, float* tar_val, float* adv, float* scratch, float* stats_out, void* stream) {
   ADDHIP_REQUIRE(reward && next_vals && vals && done && rand_mask && tar_val && adv && scratch && stats_out && T > 0 && N > 0,
                  "td_lambda_adv: bad arguments");
   ADDHIP_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7u) == 0, "td_lambda_adv: scratch must be 8-byte aligned");
   int blocks = (N + 255) / 256;
   ADDHIP_REQUIRE(blocks <= 1024, "td_lambda_adv: at most 262144 envs per rank");
   double* partial = reinterpret_cast<double*>(scratch);
-  hipLaunchKernelGGL(td_lambda_kernel, dim3(blocks), dim3(256), 0, ST, reward, next_vals, vals, done, rand_mask, T, N, discount, td_lambda, succ_val,
-                     fail_val, tar_val, adv, partial);
+  hipLaunchKernelGGL(td_lambda_kernel, dim3(blocks), dim3(256), 0, ST, reward, next_vals, timeout_vals, vals, done, rand_mask, T, N, discount, td_lambda,
+                     succ_val, fail_val, tar_val, adv, partial);
   if (int rc = addhip::check_launch("td_lambda_kernel")) return rc;
   hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(64), 0, ST, partial, blocks, stats_out);
   if (int rc = addhip::check_launch("adv_stats_kernel")) return rc;

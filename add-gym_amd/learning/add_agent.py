@@ -10,6 +10,7 @@ ADDAgent._build_train_data/_compute_disc_loss/_step_env/_reset_envs (add_agent.p
 """
 import math
 import os
+import gc
 import time
 
 import numpy as np
@@ -60,6 +61,9 @@ class ADDAgent:
         lib = self._motion_lib
         self._task = make_task(task, env.ctrl_dt, max_episode_length=lib.get_total_length())
         tk = self._task
+        if tk.max_episode_length < T * env.ctrl_dt:
+            # obs_timeout keeps ONE pre-reset row per env and iteration (include/addhip.h: addhip_td_lambda_adv)
+            raise NotImplementedError("task.max_episode_length shorter than one rollout (steps_per_iter * dt) is not supported")
         scfg = task.get("sampler", {}) or {}
         self._num_segments = int(scfg.get("num_segments", 20))
         C = lib.get_num_motions()
@@ -89,7 +93,8 @@ class ADDAgent:
             allowed = [ent.get_link(name=nm).idx for nm in names]
             self._noncontact_ids = torch.tensor([l.idx for l in ent.links if l.idx not in allowed], dtype=torch.long, device=dev)
         self._S = S = dict(sim_pose=sim_pose, sim_vel=sim_vel, contact=contact, time=env.time_buf, time_off=z(N), motion_id=z(N, dt=torch.int32),
-                           hist=z(N, L.HIST, L.POSE_W), hist_vel=z(N, L.HIST, L.POSE_W) if tk.enable_vel_obs else None, done=z(N, dt=torch.int32), ref_pose=z(N, L.POSE_W), ref_vel=z(N, L.POSE_W),
+                           hist=z(N, L.HIST, L.POSE_W), hist_vel=z(N, L.HIST, L.POSE_W) if tk.enable_vel_obs else None, done=z(N, dt=torch.int32),
+                           ref_pose=None, ref_vel=None,  # optional outputs of the step kernel (gathered reference rows); not needed here
                            ret_acc=z(N), len_acc=z(N, dt=torch.int32), ret_acc_test=z(N), len_acc_test=z(N, dt=torch.int32))
         self._env_c = L.EnvT(N, *[L.ptr(S[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "hist_vel", "done", "contact",
                                                          "ref_pose", "ref_vel", "ret_acc", "len_acc")])
@@ -98,9 +103,9 @@ class ADDAgent:
         self._head = 0  # ring slot that receives the next state (circular_buffer.py:8)
 
         # ---- experience buffer (experience_buffer.py; 13 buffers of base/ppo/amp/add agents), obs has T+1 slots
-        self._B = B = dict(obs=z(T + 1, N, OS), next_obs=z(T, N, OS), action=z(T + 1, N, 32), a_logp=z(T + 1, N), rand_mask=z(T + 1, N), reward=z(T, N),
+        self._B = B = dict(obs=z(T + 1, N, OS), obs_timeout=z(N, OS), action=z(T + 1, N, 32), a_logp=z(T + 1, N), rand_mask=z(T + 1, N), reward=z(T, N),
                            done=z(T, N, dt=torch.int32), disc_obs=z(T + 1, N, DS), disc_demo=z(T + 1, N, DS), motion_id=z(T, N, dt=torch.int32),
-                           motion_time=z(T, N), tar_val=z(T, N), adv=z(T, N), next_vals=z(T, N), vals=z(T, N), ep_stats=z(T, 3))
+                           motion_time=z(T, N), tar_val=z(T, N), adv=z(T, N), vals=z(T + 1, N), timeout_vals=z(N), ep_stats=z(T, 3))
         self._total_samples = 0
         self._sample_count = 0
         self._iter = 0
@@ -210,7 +215,7 @@ class ADDAgent:
             self._gemm(p, N, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
             self._act_plans.append(p)
         for t in range(T):
-            self._step_out.append(L.StepOutT(L.ptr(B["next_obs"][t]), L.ptr(B["obs"][t + 1]), L.ptr(B["disc_obs"][t]), L.ptr(B["disc_demo"][t]),
+            self._step_out.append(L.StepOutT(L.ptr(B["obs"][t + 1]), None, L.ptr(B["obs_timeout"]), L.ptr(B["disc_obs"][t]), L.ptr(B["disc_demo"][t]),
                                              L.ptr(B["reward"][t]), L.ptr(B["done"][t]), L.ptr(B["motion_id"][t]), L.ptr(B["motion_time"][t]),
                                              L.ptr(B["ep_stats"][t])))
 
@@ -381,14 +386,22 @@ class ADDAgent:
             L.call("addhip_head_gemv", L.ptr(self._run_disc.h[-1]), hD, hD, rows, m.p("disc", "Wh"), m.p("disc", "bh"), L.ptr(W["logits"]), st)
             L.call("addhip_disc_reward", L.ptr(W["logits"]), L.ptr(B["reward"]) + 4 * r0, rows, self._disc_reward_scale, self._task_reward_weight,
                    self._disc_reward_weight, L.ptr(W["rstats"]), st)
-            for src, dst in ((B["next_obs"], B["next_vals"]), (B["obs"], B["vals"])):
-                self._forward_rows(self._run_critic, L.ptr(src) + 4 * r0 * tk.obs_stride, rows, True)
-                L.call("addhip_head_gemv", L.ptr(self._run_critic.h[-1]), hC, hC, rows, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(dst) + 4 * r0, st)
+        # One critic pass over the T+1 obs slots gives V(obs[t]) and, shifted by one slot, V(next_obs[t]) = V(obs[t+1]) for
+        # every sample whose env was not reset (the reference evaluates next_obs separately, ppo_agent.py:117-126; the
+        # rows are identical, so are the values).  Reset envs: SUCC/FAIL take the terminal values, TIME takes V of the
+        # pre-reset row the step kernel parked in obs_timeout.
+        def critic_rows(src, dst, total):
+            for r0 in range(0, total, chunk):
+                rows = min(chunk, total - r0)
+                self._forward_rows(self._run_critic, src + 4 * r0 * tk.obs_stride, rows, True)
+                L.call("addhip_head_gemv", L.ptr(self._run_critic.h[-1]), hC, hC, rows, m.p("critic", "Wh"), m.p("critic", "bh"), dst + 4 * r0, st)
+        critic_rows(L.ptr(B["obs"]), L.ptr(B["vals"]), (T + 1) * N)
+        critic_rows(L.ptr(B["obs_timeout"]), L.ptr(B["timeout_vals"]), N)
         W["norm_diff"][:self.Mb + 1].zero_()  # row Mb must stay the zero-difference sample for the update plan
         L.call("addhip_sampler_update", self._smp_c, self._num_clips, st)
         succ = self._env.get_reward_succ() / (1.0 - self._discount)  # base_agent.py:472-480
         fail = self._env.get_reward_fail() / (1.0 - self._discount)
-        L.call("addhip_td_lambda_adv", L.ptr(B["reward"]), L.ptr(B["next_vals"]), L.ptr(B["vals"]), L.ptr(B["done"]), L.ptr(B["rand_mask"]), T, N,
+        L.call("addhip_td_lambda_adv", L.ptr(B["reward"]), L.ptr(B["vals"][1:]), L.ptr(B["timeout_vals"]), L.ptr(B["vals"]), L.ptr(B["done"]), L.ptr(B["rand_mask"]), T, N,
                self._discount, self._td_lambda, succ, fail, self._norm_adv_clip, L.ptr(B["tar_val"]), L.ptr(B["adv"]), L.ptr(W["scratch"]),
                L.ptr(W["adv_stats"]), st)
 
@@ -522,6 +535,10 @@ class ADDAgent:
         self._logger = Logger(log_file if self._rank == 0 else None, world=self._world)
         self._init_train()
         test_info = {"mean_return": 0.0, "mean_ep_len": 0.0, "num_eps": 0}
+        # everything built so far is long-lived: take it out of the cyclic GC's view so a full collection (tens of ms with
+        # torch's object graph) cannot land between two kernel launches of the loop
+        gc.collect()
+        gc.freeze()
         while self._sample_count < self._max_samples:
             output_iter = self._iter % self._iters_per_output == 0
             if output_iter:
@@ -557,7 +574,7 @@ class ADDAgent:
         eps_per_env = torch.zeros(self.N, dtype=torch.long, device=self._device)
         min_eps = int(np.ceil(num_episodes / self.N))
         ep = torch.zeros(1, 3, device=self._device)
-        out = L.StepOutT(L.ptr(B["obs"][0]), None, L.ptr(B["disc_obs"][self.T]), L.ptr(B["disc_demo"][self.T]), None, None, None, None, L.ptr(ep))
+        out = L.StepOutT(L.ptr(B["obs"][0]), None, None, L.ptr(B["disc_obs"][self.T]), L.ptr(B["disc_demo"][self.T]), None, None, None, None, L.ptr(ep))
         k = 0
         while True:
             self._decide_action(0, 0, True)

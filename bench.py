@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the fp32 MFMA 
 launch stream) and `cpu_baseline` (the CPU oracle's loop on a bounded sample, N=1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -76,25 +77,32 @@ def env_step_at_scale(num_envs=65536):
     ag = ADDAgent(cfg)
     ag.reset_all_envs()
     ag._init_train()
+    gc.collect()
+    gc.freeze()
     return time_env_step(ag, reps=50)
 
 
-def time_env_step(agent, reps=20):
-    """Average duration of addhip_env_step (env_obs_kernel + env_reward_kernel), HIP events on the launch stream."""
+def time_env_step(agent, reps=50, chunk=10):
+    """Average duration of addhip_env_step (one launch: env_step_kernel), HIP events on the launch stream.  Chunks of 10
+    steps with an untimed reset of every env in between: the simulator is not stepped here, so a longer run would drift
+    into "every env fails every step", which is not the steady state of a rollout."""
     import torch
     import add_gym_amd._lib as L
 
     st = torch.cuda.current_stream()
     out = agent._step_out[0]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(3):
-        L.call("addhip_env_step", agent._motion_lib.c_struct, agent._task, agent._env_c, out, 0, st.cuda_stream)
-    e0.record(st)
-    for _ in range(reps):
-        L.call("addhip_env_step", agent._motion_lib.c_struct, agent._task, agent._env_c, out, 0, st.cuda_stream)
-    e1.record(st)
-    e1.synchronize()
-    return e0.elapsed_time(e1) / reps
+    total = 0.0
+    for c in range(reps // chunk + 1):
+        agent.reset_all_envs()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(chunk):
+            L.call("addhip_env_step", agent._motion_lib.c_struct, agent._task, agent._env_c, out, 0, st.cuda_stream)
+        e1.record(st)
+        e1.synchronize()
+        if c > 0:  # first chunk = warm-up
+            total += e0.elapsed_time(e1)
+    return total / (reps // chunk * chunk)
 
 
 def host_cores():
@@ -173,6 +181,8 @@ def main():
     agent = ADDAgent(cfg, distributed=distributed)
     agent.reset_all_envs()
     agent._init_train()
+    gc.collect()
+    gc.freeze()  # as ADDAgent.train_model does: keep full collections (tens of ms) out of the launch loop
 
     def sync():
         if distributed:
@@ -215,7 +225,7 @@ def main():
                            "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"]}
         ms = time_env_step(agent)
         gbs = ENV_STEP_BYTES * agent.N / (ms * 1e-3) / 1e9
-        out["roofline_env_step"] = {"bound": "hbm", "kernel": "env_obs_kernel + env_reward_kernel (addhip_env_step)", "achieved": gbs,
+        out["roofline_env_step"] = {"bound": "hbm", "kernel": "env_step_kernel (addhip_env_step)", "achieved": gbs,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "us_per_launch": ms * 1e3,
                                     "envs": agent.N, "note": "launch-latency scale at this env count; see roofline_env_step_65536"}
         if world == 1:
@@ -223,7 +233,7 @@ def main():
             ms2 = env_step_at_scale(big)
             gbs2 = ENV_STEP_BYTES * big / (ms2 * 1e-3) / 1e9
             # PMC traffic per launch pair at 65536 envs (profiles/r01_env_step_pmc.md): WRITE_SIZE 225.3 MB + 2 x FETCH_SIZE 72.9 MB
-            out["roofline_env_step_65536"] = {"bound": "hbm", "kernel": "env_obs_kernel + env_reward_kernel (addhip_env_step)", "achieved": gbs2,
+            out["roofline_env_step_65536"] = {"bound": "hbm", "kernel": "env_step_kernel (addhip_env_step)", "achieved": gbs2,
                                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs2 / HBM_PEAK_GBS, "traffic": 371.2e6,
                                               "us_per_launch": ms2 * 1e3, "envs": big}
         if world == 1 and not a.no_cpu_baseline:

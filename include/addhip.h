@@ -93,7 +93,9 @@ typedef struct {
 /* outputs of one env step; any pointer may be NULL to skip that output */
 typedef struct {
   float* obs;         /* [N,obs_stride]  next_obs slot of the experience buffer */
-  float* obs_next_in; /* [N,obs_stride]  obs slot t+1 (same values; overwritten for reset envs) or NULL */
+  float* obs_next_in; /* [N,obs_stride]  optional second copy of the same rows (e.g. a separate next_obs buffer) or NULL */
+  float* obs_timeout; /* [N,obs_stride]  row n receives a copy of the obs row when done[n]==TIME (the one case where
+                         the critic needs the pre-reset next obs, ppo_agent.py:117-133) or NULL */
   float* disc_obs;    /* [N,disc_stride] */
   float* disc_demo;   /* [N,disc_stride] */
   float* reward;      /* [N] */
@@ -203,9 +205,13 @@ int addhip_head_gemv(const float* H, int32_t ld, int32_t K, int64_t rows, const 
                      float* out, void* stream);
 
 /* PPOAgent._build_train_data (ppo_agent.py:111-159) + compute_td_lambda_return (base_agent.py:624-647):
- * next_vals[done in {SUCC,FAIL}] = succ/fail value; reverse scan; adv = ret - vals; then mean/std (unbiased)
- * over samples with rand_mask==1, normalise, clamp.  scratch: [>= 4 + 2*1024] floats. stats_out[0..1]=mean,std */
-int addhip_td_lambda_adv(const float* reward, float* next_vals, const float* vals, const int32_t* done,
+ * next value = succ/fail value where done in {SUCC,FAIL}, else next_vals; reverse scan; adv = ret - vals; then
+ * mean/std (unbiased) over samples with rand_mask==1, normalise, clamp.  next_vals [T,N] is read-only and may alias
+ * vals shifted by one step (V(next_obs[t]) == V(obs[t+1]) wherever no reset happened); timeout_vals [N] (or NULL)
+ * then supplies V(true next obs) for the samples with done==TIME, whose obs[t+1] row already holds the reset obs
+ * (at most one per env per call: requires max_episode_length >= T*dt).
+ * scratch: [>= 4 + 2*1024] floats. stats_out[0..1]=mean,std */
+int addhip_td_lambda_adv(const float* reward, const float* next_vals, const float* timeout_vals, const float* vals, const int32_t* done,
                          const float* rand_mask, int32_t T, int32_t N, float discount, float td_lambda,
                          float succ_val, float fail_val, float adv_clip, float* tar_val, float* adv,
                          float* scratch, float* stats_out, void* stream);

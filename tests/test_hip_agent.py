@@ -205,7 +205,8 @@ def test_one_full_iteration_matches_reference_and_oracle():
     np.testing.assert_allclose(B["reward"].cpu().numpy(), g["buf.reward"], rtol=5e-4, atol=5e-5)
     np.testing.assert_allclose(B["adv"].cpu().numpy(), g["buf.adv"], rtol=5e-3, atol=5e-3)
     np.testing.assert_allclose(B["adv"].cpu().numpy(), orc.buf["adv"], rtol=5e-3, atol=5e-3)
-    for k, key in (("obs", "obs"), ("next_obs", "next_obs"), ("a_logp", "a_logp"), ("tar_val", "tar_val")):
+    # (no next_obs buffer here: V(next_obs[t]) is V(obs[t+1]) except for reset envs -- covered through tar_val / adv)
+    for k, key in (("obs", "obs"), ("a_logp", "a_logp"), ("tar_val", "tar_val")):
         ref = float(g[f"buf.{k}.abs"])
         got = B[key][:Tn].double().abs().sum().item()
         assert abs(got - ref) <= 5e-5 * ref, (k, got, ref)
@@ -323,8 +324,7 @@ def test_multi_clip_library_and_corrected_offsets():
         assert set(np.unique(ids)) == {0, 1, 2}
         assert all(np.isfinite(v) for v in info.values())
         lib = ag._motion_lib
-        # every reference row the kernels touched lies inside the table
-        assert torch.isfinite(ag._S["ref_pose"]).all()
+        assert torch.isfinite(ag._B["obs"]).all() and torch.isfinite(ag._B["disc_demo"]).all()
         if not compat:  # corrected mode: each env's reference row belongs to its own clip
             t = ag._S["time"] + ag._S["time_off"]
             idx = lib.step_index(ag._S["motion_id"], t).cpu().numpy()

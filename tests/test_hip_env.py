@@ -47,10 +47,10 @@ def make_out(L, n, task):
     import torch
 
     o = dict(obs=torch.full((n, task.obs_stride), 7.0, device="cuda"), obs2=torch.full((n, task.obs_stride), 7.0, device="cuda"),
-             disc=torch.full((n, task.disc_stride), 7.0, device="cuda"), demo=torch.full((n, task.disc_stride), 7.0, device="cuda"),
+             tmo=torch.full((n, task.obs_stride), 7.0, device="cuda"), disc=torch.full((n, task.disc_stride), 7.0, device="cuda"), demo=torch.full((n, task.disc_stride), 7.0, device="cuda"),
              reward=torch.zeros(n, device="cuda"), done=torch.zeros(n, dtype=torch.int32, device="cuda"),
              mid=torch.zeros(n, dtype=torch.int32, device="cuda"), mtime=torch.zeros(n, device="cuda"), ep=torch.zeros(3, device="cuda"))
-    c = L.StepOutT(*[L.ptr(o[k]) for k in ("obs", "obs2", "disc", "demo", "reward", "done", "mid", "mtime", "ep")])
+    c = L.StepOutT(*[L.ptr(o[k]) for k in ("obs", "obs2", "tmo", "disc", "demo", "reward", "done", "mid", "mtime", "ep")])
     return o, c
 
 
@@ -103,6 +103,9 @@ def test_env_step_matches_reference(vname):
     # bit-exact: flags, clock, reference rows (pure gathers), recorded motion times
     assert np.array_equal(o["done"].cpu().numpy(), v["done"])
     assert np.array_equal(st["done"].cpu().numpy(), v["done"])
+    # pre-reset obs rows are parked for exactly the envs that ran into the episode time limit
+    tmo, timed = o["tmo"].cpu().numpy(), v["done"] == 3
+    assert timed.sum() > 0 and np.array_equal(tmo[timed], obs[timed]) and np.all(tmo[~timed] == 7.0)
     assert np.array_equal(st["time"].cpu().numpy(), v["time_post"])
     assert np.array_equal(st["ref_pose"].cpu().numpy(), pack_pose(v["ref_root_pos"], v["ref_root_rot"], v["ref_dof_pos"]))
     assert np.array_equal(st["ref_vel"].cpu().numpy()[:, :35], pack_vel(v["ref_root_vel"], v["ref_root_ang_vel"], v["ref_dof_vel"])[:, :35])

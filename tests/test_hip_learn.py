@@ -74,12 +74,48 @@ def test_td_lambda_adv_matches_reference_golden():
     adv = torch.zeros(Tn, n, device="cuda")
     scratch = torch.zeros(4096, dtype=torch.float64, device="cuda")
     stats = torch.zeros(2, device="cuda")
-    L.call("addhip_td_lambda_adv", P(T(g["r"])), L.ptr(nv), P(T(g["vals"])), P(T(g["done"], torch.int32)), P(torch.ones(Tn, n, device="cuda")),
+    L.call("addhip_td_lambda_adv", P(T(g["r"])), L.ptr(nv), None, P(T(g["vals"])), P(T(g["done"], torch.int32)), P(torch.ones(Tn, n, device="cuda")),
            Tn, n, 0.99, 0.95, 0.0, 0.0, 4.0, L.ptr(tar), L.ptr(adv), L.ptr(scratch), L.ptr(stats), L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(tar.cpu().numpy(), g["tar_val"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(stats.cpu().numpy(), [float(g["adv_mean"]), float(g["adv_std"])], rtol=1e-5)
     np.testing.assert_allclose(adv.cpu().numpy(), g["adv"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(nv.cpu().numpy(), g["next_vals"])  # read-only input
+
+
+def test_td_lambda_shifted_values_and_timeout_rows():
+    """The agent's layout: next_vals aliases vals shifted by one slot, and the value of the true next obs of a DONE_TIME
+    sample comes from timeout_vals[env] (its obs[t+1] row already holds the reset obs).  Same returns as the reference
+    recurrence on an explicit next_vals array (oracle restatement of base_agent.py:624-647)."""
+    import torch
+    import add_gym_amd._lib as L
+    from oracle import learn as OL
+
+    g = gload("td_lambda_adv")
+    Tn, n = g["r"].shape
+    rng = np.random.default_rng(5)
+    done = g["done"].copy()
+    for e in range(n):  # at most one DONE_TIME per env and call
+        ts = np.nonzero(done[:, e] == 3)[0]
+        done[ts[:-1], e] = 0
+    assert (done == 3).sum() > 0
+    vals_all = rng.normal(size=(Tn + 1, n)).astype(F)      # V(obs[0..T])
+    tv = rng.normal(size=n).astype(F)                       # V(pre-reset obs) of each env's DONE_TIME sample
+    next_ref = vals_all[1:].copy()
+    tsel = done == 3
+    next_ref[tsel] = np.broadcast_to(tv, (Tn, n))[tsel]
+    next_ref[(done == 1) | (done == 2)] = 0.0
+    want = OL.td_lambda_return(g["r"], next_ref, done, 0.99, 0.95)
+    va = T(vals_all)
+    tar = torch.zeros(Tn, n, device="cuda")
+    adv = torch.zeros(Tn, n, device="cuda")
+    scratch = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    stats = torch.zeros(2, device="cuda")
+    L.call("addhip_td_lambda_adv", P(T(g["r"])), L.ptr(va[1:]), P(T(tv)), L.ptr(va), P(T(done, torch.int32)), P(torch.ones(Tn, n, device="cuda")),
+           Tn, n, 0.99, 0.95, 0.0, 0.0, 4.0, L.ptr(tar), L.ptr(adv), L.ptr(scratch), L.ptr(stats), L.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(tar.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(va.cpu().numpy(), vals_all)
 
 
 def test_normalizers_match_reference_golden():
