@@ -1,15 +1,15 @@
 // Per-env hot path of the rollout: reference-motion frame lookup, history ring, observation /
 // discriminator-observation assembly, imitation reward, done flags, return tracker, masked reset.
 //
-// env_obs_kernel: one wavefront owns one env at a time.  The 16 rows an env needs (simulator pose,
-// reference pose+velocity, up to 8 target frames, 2 older demo frames, 2 older history frames; 144 B each)
-// are fetched in ONE pass -- 4 lanes per row, 36 B per lane -- into a wave-private LDS work area; the few values
-// that need arithmetic (tangent/normal vectors of 15 quaternions, target position offsets) are derived once per
-// env by 15+24 lanes; every output row is then a pure gather from LDS through an index map built once per
-// workgroup, so all global stores are contiguous runs of the obs / disc rows.  HBM-bound by construction:
-// 4.6 KB of algorithmic traffic per env-step; the instruction budget is ~250 wave-instructions per env.
-// env_reward_kernel: 16 lanes per env (reward, done flags, return tracker) on the rows the first kernel left
-// in ref_pose/ref_vel.  env_reset_kernel: masked reset, same staging/derive/emit code on clip rows.
+// env_step_kernel: a wavefront owns a group of 1-16 consecutive envs and handles them one at a time.  The 16 rows an env
+// needs (simulator pose+velocity, reference pose+velocity, up to 8 target frames, 2 older demo frames, 2 older history
+// frames; 144 B each) are fetched in ONE pass -- 4 lanes per row, 36 B per lane -- into a wave-private LDS work area, the
+// next env's rows already in flight; the few values that need arithmetic (tangent/normal vectors of 15 quaternions, target
+// position offsets) are derived once per env by 15+24 lanes; every output row is then a pure gather from LDS through an
+// index map built once per workgroup, stored 16 bytes per lane.  Reward / done / return tracker: the dof error sums of
+// an env come from wave shuffles inside the loop, the scalar part runs after the loop with ONE LANE PER ENV.  HBM-bound by
+// construction: 4.6 KB of algorithmic traffic per env-step.
+// env_reset_kernel: masked reset, same staging/derive/emit code on clip rows.
 //
 // Reference functions restated here: see include/addhip.h at each entry point.
 #include "common.h"
@@ -61,11 +61,6 @@ __device__ __forceinline__ int step_index(float t, float dt_inv, int total_steps
   return fr + clip_start;
 }
 
-__device__ __forceinline__ float group_sum16(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
-  return v;
-}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -232,9 +232,9 @@ def main():
             big = 65536
             ms2 = env_step_at_scale(big)
             gbs2 = ENV_STEP_BYTES * big / (ms2 * 1e-3) / 1e9
-            # PMC traffic per launch pair at 65536 envs (profiles/r01_env_step_pmc.md): WRITE_SIZE 225.3 MB + 2 x FETCH_SIZE 72.9 MB
+            # PMC traffic per launch at 65536 envs (profiles/r01_env_step_pmc.md): WRITE_SIZE 148.4 MB + 2 x FETCH_SIZE 52.3 MB
             out["roofline_env_step_65536"] = {"bound": "hbm", "kernel": "env_step_kernel (addhip_env_step)", "achieved": gbs2,
-                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs2 / HBM_PEAK_GBS, "traffic": 371.2e6,
+                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs2 / HBM_PEAK_GBS, "traffic": 253.0e6,
                                               "us_per_launch": ms2 * 1e3, "envs": big}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_envs, agent.T)
