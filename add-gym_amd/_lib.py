@@ -54,7 +54,7 @@ class GemmT(C.Structure):
     _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("A", f32p), ("lda", C.c_int32), ("a_kcontig", C.c_int32),
                 ("B", f32p), ("ldb", C.c_int32), ("b_kcontig", C.c_int32), ("C", f32p), ("ldc", C.c_int32), ("epilogue", C.c_int32),
                 ("bias", f32p), ("mask", f32p), ("ldmask", C.c_int32), ("a_mean", f32p), ("a_std", f32p), ("split_k", C.c_int32),
-                ("alpha", C.c_float)]
+                ("alpha", C.c_float), ("colsum", f32p)]
 
 
 class GatherT(C.Structure):
@@ -82,6 +82,7 @@ SIGNATURES = {
     "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp],
     "addhip_fill_normal": [vp, i64, u64, u64, vp],
     "addhip_fill_uniform": [vp, i64, u64, u64, vp],
+    "addhip_fill_zero": [vp, i64, vp],
     "addhip_disc_prep": [vp, vp, i32, i32, i64, vp, f32, vp, vp, vp, P(SamplerT), i32, vp, vp],
     "addhip_sampler_update": [P(SamplerT), i32, vp],
     "addhip_disc_reward": [vp, vp, i64, f32, f32, f32, vp, vp],

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
     for (int a = 0; a < FM; ++a) {
       const int rbase = m0 + wm0 + a * 32 + 4 * lh;
       float mk[16];
+      float cs = 0.f;  // MASK: column sum of this lane's 16 stored values (bias gradient)
       if (epi == ADDHIP_EPI_MASK) {  // all 16 mask loads in flight before any use
 #pragma unroll
         for (int x = 0; x < 16; ++x) {
@@ -209,7 +210,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
         float v = g.alpha * acc[a][b][x] + bias;
         if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
         if (epi == ADDHIP_EPI_MASK) v = mk[x] > 0.f ? v : 0.f;
-        if (col_ok && row < g.M) C[(size_t)row * g.ldc + col] = v;
+        if (col_ok && row < g.M) {
+          C[(size_t)row * g.ldc + col] = v;
+          if (epi == ADDHIP_EPI_MASK) cs += v;
+        }
+      }
+      if (epi == ADDHIP_EPI_MASK && g.colsum) {
+        cs += __shfl_xor(cs, 32, 64);  // the two lane halves hold the other rows of the same column
+        if (lh == 0 && col_ok) atomicAdd(&g.colsum[col], cs);
       }
     }
   }
@@ -293,6 +301,7 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_REQUIRE(g.mask, "gemm: mask missing");
   if (g.split_k > 1) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_NONE, "gemm: split-K slabs take no epilogue");
   if (g.a_mean || g.a_std) ADDHIP_REQUIRE(g.a_kcontig && g.a_mean && g.a_std, "gemm: fused normalisation needs a k-contiguous A and both mean/std");
+  if (g.colsum) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && g.split_k <= 1, "gemm: colsum needs the MASK epilogue");
   if (g.alpha == 0.0f) g.alpha = 1.0f;
   hipStream_t st = (hipStream_t)stream;
   if (g.N <= 32) return launch_cfg<128, 32, 4, 1, 16>(g, st);
@@ -311,6 +320,12 @@ extern "C" int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_s
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, slabs, (long long)slab_stride, out,
                      (long long)count, scale, accumulate);
   return addhip::check_launch("slab_reduce_kernel");
+}
+
+extern "C" int addhip_fill_zero(float* p, int64_t count, void* stream) {
+  ADDHIP_REQUIRE(p && count > 0, "fill_zero: bad arguments");
+  ADDHIP_HIP(hipMemsetAsync(p, 0, sizeof(float) * (size_t)count, (hipStream_t)stream));
+  return 0;
 }
 
 extern "C" int addhip_col_sum(const float* X, int32_t M, int32_t N, int32_t ld, float* out, float scale, int32_t accumulate, void* stream) {

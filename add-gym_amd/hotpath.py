@@ -72,6 +72,6 @@ def make_task(task, dt, max_episode_length=None):
 
 
 def gemm(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, epilogue=L.EPI_NONE, bias=None, mask=None, ldmask=0, a_mean=None, a_std=None,
-         split_k=1, alpha=1.0):
+         split_k=1, alpha=1.0, colsum=None):
     """Descriptor for addhip_gemm_f32: C[M,N] = alpha * sum_k A(m,k) B(n,k).  Pointers are raw addresses."""
-    return L.GemmT(M, N, K, A, lda, int(a_kc), B, ldb, int(b_kc), C, ldc, epilogue, bias, mask, ldmask, a_mean, a_std, split_k, alpha)
+    return L.GemmT(M, N, K, A, lda, int(a_kc), B, ldb, int(b_kc), C, ldc, epilogue, bias, mask, ldmask, a_mean, a_std, split_k, alpha, colsum)

@@ -229,10 +229,12 @@ class NetRunner:
                 plan.add("addhip_gemm_f32", g2)
                 total = 2 * s
             plan.add("addhip_slab_reduce", L.ptr(self.slabs), total, slab, m.g(net.name, f"W{i}"), slab, 1.0, 0)
-            plan.add("addhip_col_sum", L.ptr(self.dz[i]), rows, out_d, out_d, m.g(net.name, f"b{i}"), 1.0, 0)
+            if i == n - 1:  # the top layer's dz comes from the loss kernels; the others get their bias gradient from the
+                plan.add("addhip_col_sum", L.ptr(self.dz[i]), rows, out_d, out_d, m.g(net.name, f"b{i}"), 1.0, 0)  # dX GEMM below
             if i > 0:
                 prev_d = net.hidden[i - 1]
+                plan.add("addhip_fill_zero", m.g(net.name, f"b{i - 1}"), prev_d)
                 g3 = gemm(rows, prev_d, out_d, L.ptr(self.dz[i]), out_d, 1, m.p(net.name, f"W{i}"), prev_d, 0, L.ptr(self.dz[i - 1]), prev_d,
-                          L.EPI_MASK, mask=L.ptr(self.h[i - 1]), ldmask=prev_d)
+                          L.EPI_MASK, mask=L.ptr(self.h[i - 1]), ldmask=prev_d, colsum=m.g(net.name, f"b{i - 1}"))
                 plan.hold(g3)
                 plan.add("addhip_gemm_f32", g3)

@@ -166,6 +166,8 @@ typedef struct {
   const float* a_mean; const float* a_std; /* optional fused (a-mean)/std on A when a_kcontig (Normalizer.normalize, normalizer.py:107-110) */
   int32_t split_k;          /* >1: C is [split_k, M, ldc] partial slabs (slab stride M*ldc) */
   float alpha;              /* scale applied to acc before the epilogue */
+  float* colsum;            /* optional, MASK epilogue only: colsum[n] += sum_m C[m,n] (the bias gradient of the layer
+                               whose pre-activation gradient this GEMM produces; atomics, caller zeroes) */
 } addhip_gemm_t;
 int addhip_gemm_f32(const addhip_gemm_t* g, void* stream);
 
@@ -215,6 +217,10 @@ int addhip_td_lambda_adv(const float* reward, const float* next_vals, const floa
                          const float* rand_mask, int32_t T, int32_t N, float discount, float td_lambda,
                          float succ_val, float fail_val, float adv_clip, float* tar_val, float* adv,
                          float* scratch, float* stats_out, void* stream);
+
+/* hipMemsetAsync(p, 0, 4*count): e.g. the flat gradient buffer once per optimiser step (MPOptimizer.step's zero_grad,
+ * mp_optimizer.py:14-16), so that bias gradients can be accumulated by atomics from several kernels */
+int addhip_fill_zero(float* p, int64_t count, void* stream);
 
 /* ---- normalisers ---- */
 /* sum[n] += sum_m x[m,n]; sumsq[n] += sum_m x^2   (Normalizer.record, normalizer.py:25-35) */

@@ -45,8 +45,9 @@ def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, 
     ldc = (N + 3) // 4 * 4
     dC = torch.full((max(split_k, 1), M, ldc), 9.0, device="cuda")
     dbias, dmask, dmean, dstd = T(bias), T(mask), T(mean), T(std)
+    dcs = torch.full((N,), 0.5, device="cuda")  # MASK epilogue also accumulates the column sums (bias gradient) here
     g = gemm(M, N, K, L.ptr(dA), lda, a_kc, L.ptr(dB), ldb, b_kc, L.ptr(dC), ldc, epilogue, L.ptr(dbias), L.ptr(dmask), N,
-             L.ptr(dmean) if norm else None, L.ptr(dstd) if norm else None, split_k, alpha)
+             L.ptr(dmean) if norm else None, L.ptr(dstd) if norm else None, split_k, alpha, L.ptr(dcs) if epilogue == 3 else None)
     L.call("addhip_gemm_f32", g, L.current_stream())
     torch.cuda.synchronize()
     A64 = A.astype(np.float64)
@@ -66,6 +67,10 @@ def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, 
     assert np.all(err <= 4e-7 * scale * max(1.0, abs(alpha)) + 1e-6), (M, N, K, a_kc, b_kc, epilogue, split_k, float(err.max()))
     if ldc > N:
         assert np.all(out[0][:, N:] == 9.0)  # pad columns are never written
+    if epilogue == 3:
+        cs = dcs.cpu().numpy().astype(np.float64) - 0.5
+        cs_scale = np.where(mask > 0, scale, 0).sum(0)
+        assert np.all(np.abs(cs - got.sum(0)) <= 4e-7 * cs_scale + 1e-5), float(np.abs(cs - got.sum(0)).max())
 
 
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
