@@ -54,7 +54,7 @@ class GemmT(C.Structure):
     _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("A", f32p), ("lda", C.c_int32), ("a_kcontig", C.c_int32),
                 ("B", f32p), ("ldb", C.c_int32), ("b_kcontig", C.c_int32), ("C", f32p), ("ldc", C.c_int32), ("epilogue", C.c_int32),
                 ("bias", f32p), ("mask", f32p), ("ldmask", C.c_int32), ("a_mean", f32p), ("a_std", f32p), ("split_k", C.c_int32),
-                ("alpha", C.c_float), ("colsum", f32p)]
+                ("alpha", C.c_float), ("colsum", f32p), ("precision", C.c_int32)]
 
 
 class GatherT(C.Structure):
@@ -66,6 +66,7 @@ class GatherT(C.Structure):
 
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 3
 
 i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
 P = C.POINTER

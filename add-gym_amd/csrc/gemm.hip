@@ -286,6 +286,10 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* X, int M, int
 
 }  // namespace
 
+namespace addhip {
+int gemm_split_dispatch(const addhip_gemm_t& g, int planes, hipStream_t st);  // gemm_split.hip
+}
+
 extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   ADDHIP_REQUIRE(gp, "null gemm descriptor");
   addhip_gemm_t g = *gp;
@@ -302,6 +306,7 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   if (g.split_k > 1) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_NONE, "gemm: split-K slabs take no epilogue");
   if (g.a_mean || g.a_std) ADDHIP_REQUIRE(g.a_kcontig && g.a_mean && g.a_std, "gemm: fused normalisation needs a k-contiguous A and both mean/std");
   if (g.colsum) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && g.split_k <= 1, "gemm: colsum needs the MASK epilogue");
+  ADDHIP_REQUIRE(g.precision == ADDHIP_PREC_F32 || g.precision == ADDHIP_PREC_BF16 || g.precision == ADDHIP_PREC_BF16X3, "gemm: bad precision");
   if (g.alpha == 0.0f) g.alpha = 1.0f;
   hipStream_t st = (hipStream_t)stream;
   if (g.N <= 32) return launch_cfg<128, 32, 4, 1, 16>(g, st);
@@ -309,6 +314,7 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   // keep >= ~1 block per CU on the skinny rollout shapes
   const long long tiles128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
   if (tiles128 < 256) return launch_cfg<64, 128, 2, 2, 16>(g, st);
+  if (g.precision == ADDHIP_PREC_BF16X3 || g.precision == ADDHIP_PREC_BF16) return addhip::gemm_split_dispatch(g, g.precision, st);
   return launch_cfg<128, 128, 2, 2, 32>(g, st);
 }
 

@@ -1,0 +1,344 @@
+// fp32 GEMM through the bf16 matrix cores: every fp32 operand value is split EXACTLY into three bf16 chunks
+// (x = hi + mid + lo, 8 significant bits each, by truncation: no rounding anywhere in the split) and the six products
+// that carry bits above 2^-24 of |a||b| are accumulated in fp32 by v_mfma_f32_32x32x16_bf16:
+//     a*b ~= hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid        (dropped: mid*lo, lo*mid, lo*lo <= 2^-23 |a||b|)
+// A product of two bf16 values is exact in fp32, so the only roundings are those of the fp32 accumulation -- the same
+// ones v_mfma_f32_32x32x2_f32 performs.  The CDNA4 bf16 MFMA rate is 16x its fp32 MFMA rate, so six bf16 MFMAs per
+// k-step are 2.7x cheaper than the fp32 instruction for the same arithmetic (gemm.hip keeps the fp32-MFMA path).
+// PLANES = 1 is the plain bf16 product (operands rounded toward zero to bf16, fp32 accumulate).
+//
+// Same interface, tiling and epilogues as gemm.hip: 128x128 tile, 4 wavefronts of 64x64 (2x2 MFMA accumulators),
+// operands stay fp32 in HBM and are split on their way into LDS.  LDS image of an operand tile: [row][plane][16 k] bf16
+// with a 16-byte pad per row (row stride 112 B = 28 dwords: a ds_read_b128 lane group covers all 64 banks); K advances 16
+// per stage, LDS double-buffered, the next stage prefetched global -> VGPR while the current one feeds the MFMAs.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int EPI_RUNTIME = -1;
+
+template <int PLANES>
+struct Img {
+  static constexpr int RS = PLANES * 32 + 16;  // bytes per row
+  static constexpr int SIZE = 128 * RS;        // bytes per operand tile
+};
+
+// x -> (hi, mid, lo) as fp32 bit patterns whose low 16 bits are zero (i.e. bf16 values), exact
+__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(hi);
+  mid = __float_as_uint(r1) & 0xffff0000u;
+  lo = __float_as_uint(r1 - __uint_as_float(mid));  // <= 8 significant bits: already a bf16 value
+}
+// two bf16 (high halves of a, b) -> one dword, a in the low half
+__device__ __forceinline__ unsigned pack2(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// ---- k-contiguous operand P[r*ld + k]: each thread moves 2 float4 (4 k of one row) per stage --------------------
+// Loads are unconditional (addresses clamped into the K range) and NOTHING is done to the loaded registers until they
+// are written to LDS several stages later (zeroing of the K tail, fused normalisation and the split all happen there):
+// the K loop then has no branch around, and no early use of, a memory instruction, and the compiler keeps the whole
+// register ring in flight across the loop back-edge (counted vmcnt).
+__device__ __forceinline__ void load_kc(float4* reg, const float* __restrict__ P, int ld, int r0, int k0, int R, int kend) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = threadIdx.x + 256 * i;
+    const int row = f >> 2, kq = (f & 3) * 4;
+    const int r = min(r0 + row, R - 1), k = min(k0 + kq, kend - 4);
+    reg[i] = *reinterpret_cast<const float4*>(P + (size_t)r * ld + k);
+  }
+}
+// nmean / nstd: LDS copies of the normaliser vectors, indexed by k - kbeg (NORM only).  One call = one of the thread's two
+// float4 (part i), so that the caller can spread the work between MFMA groups.  GUARD: K tail (k >= kend -> 0).
+template <int PLANES, bool NORM, bool GUARD>
+__device__ __forceinline__ void store_kc(char* lds, const float4* reg, int i, int k0, int kend, const float* nmean, const float* nstd, int kbeg) {
+  const int f = threadIdx.x + 256 * i;
+  const int row = f >> 2, kq = (f & 3) * 4;
+  const int k = k0 + kq;
+  float4 v = reg[i];
+  if (NORM) {  // Normalizer.normalize (normalizer.py:107-110)
+    const int kc = min(k, kend - 4) - kbeg;
+    const float4 mu = *reinterpret_cast<const float4*>(nmean + kc);
+    const float4 sd = *reinterpret_cast<const float4*>(nstd + kc);
+    v.x = (v.x - mu.x) / sd.x; v.y = (v.y - mu.y) / sd.y; v.z = (v.z - mu.z) / sd.z; v.w = (v.w - mu.w) / sd.w;
+  }
+  if (GUARD) {
+    const bool in = k < kend;
+    v = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+  }
+  char* dst = lds + row * Img<PLANES>::RS + kq * 2;
+  unsigned h[4], m[4], l[4];
+  split3(v.x, h[0], m[0], l[0]);
+  split3(v.y, h[1], m[1], l[1]);
+  split3(v.z, h[2], m[2], l[2]);
+  split3(v.w, h[3], m[3], l[3]);
+  *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+  if (PLANES == 3) {
+    *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pack2(m[0], m[1]), pack2(m[2], m[3]));
+    *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+  }
+}
+
+// ---- m/n-contiguous operand P[k*ld + r]: each thread moves rows r..r+3 of two consecutive k per stage ---------------
+__device__ __forceinline__ void load_mc(float4* reg, const float* __restrict__ P, int ld, int r0, int k0, int R, int kend) {
+  const int kk2 = threadIdx.x & 7, rq = (threadIdx.x >> 3) * 4;
+  const int r = min(r0 + rq, R - 4), k = k0 + 2 * kk2;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) reg[i] = *reinterpret_cast<const float4*>(P + (size_t)min(k + i, kend - 1) * ld + r);
+}
+// part i = rows rq+2i, rq+2i+1
+template <int PLANES, bool GUARD>
+__device__ __forceinline__ void store_mc(char* lds, const float4* reg, int i, int k0, int kend) {
+  const int kk2 = threadIdx.x & 7, rq = (threadIdx.x >> 3) * 4;
+  const int k = k0 + 2 * kk2;
+  const bool in0 = !GUARD || k < kend, in1 = !GUARD || k + 1 < kend;
+  const float a[2] = {i == 0 ? reg[0].x : reg[0].z, i == 0 ? reg[0].y : reg[0].w};  // k even
+  const float b[2] = {i == 0 ? reg[1].x : reg[1].z, i == 0 ? reg[1].y : reg[1].w};  // k odd
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    char* dst = lds + (rq + 2 * i + j) * Img<PLANES>::RS + kk2 * 4;
+    unsigned ha, ma, la, hb, mb, lb;
+    split3(in0 ? a[j] : 0.f, ha, ma, la);
+    split3(in1 ? b[j] : 0.f, hb, mb, lb);
+    *reinterpret_cast<unsigned*>(dst) = pack2(ha, hb);
+    if (PLANES == 3) {
+      *reinterpret_cast<unsigned*>(dst + 32) = pack2(ma, mb);
+      *reinterpret_cast<unsigned*>(dst + 64) = pack2(la, lb);
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8 frag(const char* lds, int row, int plane, int h, int rs) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + row * rs + plane * 32 + h * 16));
+}
+
+template <bool AKC, bool BKC, int EPI, bool NORM, int PLANES>
+__global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
+  static_assert(!NORM || AKC, "fused normalisation needs a k-contiguous A");
+  using I = Img<PLANES>;
+  constexpr int STAGE = 2 * I::SIZE;
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  constexpr int NORM_MAXK = 512;  // fused normalisation: the first layer's K (= obs_stride)
+  __shared__ __attribute__((aligned(16))) float nmean[NORM ? NORM_MAXK : 4], nstd[NORM ? NORM_MAXK : 4];
+
+  // XCD-aware remap (blocks b and b+8 share an XCD): each XCD gets a contiguous run of tiles, N-tile fastest
+  const int total = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q = total >> 3, r = total & 7, xcd = orig & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  const int kchunk = ((g.K + split - 1) / split + BK - 1) / BK * BK;
+  const int kbeg = blockIdx.z * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
+
+  // Register ring, DEPTH stages deep: one stage is only 24 MFMAs (768 cycles) per wave, far less than a global-load
+  // round trip, so the loads of stage t+DEPTH are issued while stage t is multiplied.  Static ring indices (the K loop is
+  // unrolled DEPTH stages per trip), no branch around a load, and a raw s_barrier with an LDS-only wait: __syncthreads()
+  // would drain the ring (its fence waits for vmcnt(0)).  Inside a stage the split of the NEXT stage's registers (VALU)
+  // is spread between the MFMA groups: an MFMA holds the SIMD's issue port for 8 of its 32 cycles, the rest is free.
+  // Only whole 16-deep stages go through the pipeline; a K tail (K % 16) is one extra, guarded stage at the end.
+  constexpr int DEPTH = 4;
+  float4 ra[DEPTH][2], rb[DEPTH][2];
+  const int nkf = kend > kbeg ? (kend - kbeg) / BK : 0;  // whole stages
+  if (nk == 0) return;  // (K range of this split-K slice is empty: cannot happen for the slab counts the host picks)
+  if (NORM) {
+    for (int i = threadIdx.x; i < kend - kbeg; i += 256) { nmean[i] = g.a_mean[kbeg + i]; nstd[i] = g.a_std[kbeg + i]; }
+    __syncthreads();
+  }
+  auto fetch = [&](int kt, float4* a_reg, float4* b_reg) {
+    const int k0 = kbeg + min(kt, nk - 1) * BK;  // past the end: a redundant reload of the last stage, never consumed
+    if (AKC) load_kc(a_reg, g.A, g.lda, m0, k0, g.M, kend);
+    else load_mc(a_reg, g.A, g.lda, m0, k0, g.M, kend);
+    if (BKC) load_kc(b_reg, g.B, g.ldb, n0, k0, g.N, kend);
+    else load_mc(b_reg, g.B, g.ldb, n0, k0, g.N, kend);
+  };
+  // quarter q (0..3) of: registers of stage kt -> LDS buffer kt&1
+  auto stash_part = [&](auto guard, int q, int kt, const float4* a_reg, const float4* b_reg) {
+    constexpr bool GUARD = decltype(guard)::value;
+    const int k0 = kbeg + min(kt, nk - 1) * BK;
+    char* a_dst = lds + (kt & 1) * STAGE;
+    if (q < 2) {
+      if (AKC) store_kc<PLANES, NORM, GUARD>(a_dst, a_reg, q, k0, kend, nmean, nstd, kbeg);
+      else store_mc<PLANES, GUARD>(a_dst, a_reg, q, k0, kend);
+    } else {
+      if (BKC) store_kc<PLANES, false, GUARD>(a_dst + I::SIZE, b_reg, q - 2, k0, kend, nullptr, nullptr, 0);
+      else store_mc<PLANES, GUARD>(a_dst + I::SIZE, b_reg, q - 2, k0, kend);
+    }
+  };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto mfma_group = [&](int a, int b, const bf16x8 (*fa)[PLANES], const bf16x8 (*fb)[PLANES]) {
+    if (PLANES == 3) {  // smallest terms first
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
+    }
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+  };
+  auto read_frags = [&](int kt, bf16x8 (*fa)[PLANES], bf16x8 (*fb)[PLANES]) {
+    const char* a_cur = lds + (kt & 1) * STAGE;
+    const char* b_cur = a_cur + I::SIZE;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int p = 0; p < PLANES; ++p) fa[a][p] = frag(a_cur, wm0 + a * 32 + li, p, lh, I::RS);
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int p = 0; p < PLANES; ++p) fb[b][p] = frag(b_cur, wn0 + b * 32 + li, p, lh, I::RS);
+  };
+  // one pipelined stage: slot s of the ring held stage kt (already in LDS buffer kt&1) and is refilled with stage
+  // kt+DEPTH; stage kt+1 goes to the other LDS buffer (last read during stage kt-1, which every wave has left).  After
+  // the last stage this writes a duplicate nobody reads.
+  auto stage = [&](int kt, float4* a_free, float4* b_free, const float4* a_next, const float4* b_next) {
+    fetch(kt + DEPTH, a_free, b_free);
+    bf16x8 fa[2][PLANES], fb[2][PLANES];
+    read_frags(kt, fa, fb);
+    mfma_group(0, 0, fa, fb);
+    stash_part(std::false_type{}, 0, kt + 1, a_next, b_next);
+    mfma_group(0, 1, fa, fb);
+    stash_part(std::false_type{}, 1, kt + 1, a_next, b_next);
+    mfma_group(1, 0, fa, fb);
+    stash_part(std::false_type{}, 2, kt + 1, a_next, b_next);
+    mfma_group(1, 1, fa, fb);
+    stash_part(std::false_type{}, 3, kt + 1, a_next, b_next);
+    if (PLANES == 3) {
+      // pin the interleave: per MFMA up to 5 VALU, and a DS write after every second one
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    }
+    lds_barrier();
+  };
+  if (nkf > 0) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fetch(d, ra[d], rb[d]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stash_part(std::false_type{}, q, 0, ra[0], rb[0]);
+    lds_barrier();
+    int kt = 0;
+    for (; kt + DEPTH <= nkf; kt += DEPTH) {
+#pragma unroll
+      for (int s = 0; s < DEPTH; ++s) stage(kt + s, ra[s], rb[s], ra[(s + 1) % DEPTH], rb[(s + 1) % DEPTH]);
+    }
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; ++s)
+      if (kt + s < nkf) stage(kt + s, ra[s], rb[s], ra[(s + 1) % DEPTH], rb[(s + 1) % DEPTH]);
+  }
+  if (nk > nkf) {  // K tail: one guarded, unpipelined stage (every wave is past the last barrier of the pipeline)
+    fetch(nkf, ra[0], rb[0]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stash_part(std::true_type{}, q, nkf, ra[0], rb[0]);
+    lds_barrier();
+    bf16x8 fa[2][PLANES], fb[2][PLANES];
+    read_frags(nkf, fa, fb);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) mfma_group(a, b, fa, fb);
+  }
+
+  // epilogue: lane owns column n0+wn0+b*32+li; register x is row (x&3)+8*(x>>2)+4*lh of the 32x32 tile
+  const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
+  float* C = g.C + (size_t)blockIdx.z * (size_t)g.M * g.ldc;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int col = n0 + wn0 + b * 32 + li;
+    const bool col_ok = col < g.N;
+    const float bias = (col_ok && (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU)) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int rbase = m0 + wm0 + a * 32 + 4 * lh;
+      float mk[16];
+      float cs = 0.f;
+      if (epi == ADDHIP_EPI_MASK) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const int row = rbase + (x & 3) + 8 * (x >> 2);
+          mk[x] = (col_ok && row < g.M) ? g.mask[(size_t)row * g.ldmask + col] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int row = rbase + (x & 3) + 8 * (x >> 2);
+        float v = g.alpha * acc[a][b][x] + bias;
+        if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        if (epi == ADDHIP_EPI_MASK) v = mk[x] > 0.f ? v : 0.f;
+        if (col_ok && row < g.M) {
+          C[(size_t)row * g.ldc + col] = v;
+          if (epi == ADDHIP_EPI_MASK) cs += v;
+        }
+      }
+      if (epi == ADDHIP_EPI_MASK && g.colsum) {
+        cs += __shfl_xor(cs, 32, 64);
+        if (lh == 0 && col_ok) atomicAdd(&g.colsum[col], cs);
+      }
+    }
+  }
+}
+
+template <int PLANES>
+int launch_split(const addhip_gemm_t& g, hipStream_t st) {
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  dim3 grid(tiles_m * tiles_n, 1, split), block(256);
+  const bool norm = g.a_mean != nullptr;
+#define ADDHIP_LAUNCH(AK, BKc, EPI, NORM) \
+  hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, EPI, NORM, PLANES>), grid, block, 0, st, g, tiles_m, tiles_n)
+  if (g.a_kcontig && g.b_kcontig) {
+    if (norm) {
+      if (g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_BIAS_RELU, true);
+      else return (addhip::set_error("gemm: fused normalisation is only built for the bias+ReLU epilogue"), -1);
+    } else if (g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_BIAS_RELU, false);
+    else if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_MASK, false);
+    else ADDHIP_LAUNCH(true, true, EPI_RUNTIME, false);
+  } else if (g.a_kcontig && !g.b_kcontig) {
+    if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_LAUNCH(true, false, ADDHIP_EPI_MASK, false);
+    else ADDHIP_LAUNCH(true, false, EPI_RUNTIME, false);
+  } else if (!g.a_kcontig && g.b_kcontig) {
+    ADDHIP_LAUNCH(false, true, EPI_RUNTIME, false);
+  } else {
+    if (g.epilogue == ADDHIP_EPI_NONE) ADDHIP_LAUNCH(false, false, ADDHIP_EPI_NONE, false);
+    else ADDHIP_LAUNCH(false, false, EPI_RUNTIME, false);
+  }
+#undef ADDHIP_LAUNCH
+  return addhip::check_launch("gemm_split_kernel");
+}
+
+}  // namespace
+
+namespace addhip {
+// called by addhip_gemm_f32 (gemm.hip) after argument validation, for the shapes that fill the chip with 128x128 tiles
+int gemm_split_dispatch(const addhip_gemm_t& g, int planes, hipStream_t st) {
+  if (g.a_mean && g.K > 512) return (set_error("gemm: fused normalisation on the bf16 paths needs K <= 512"), -1);
+  return planes == 3 ? launch_split<3>(g, st) : launch_split<1>(g, st);
+}
+}  // namespace addhip

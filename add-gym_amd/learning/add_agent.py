@@ -20,6 +20,7 @@ from .. import _lib as L
 from .. import dist as D
 from ..anim.motion_lib import MotionLib
 from ..envs.env import ImitationEnvironment
+from .. import hotpath as H
 from ..hotpath import gemm, make_task
 from ..util.logger import Logger
 from .model import Model, NetRunner, Plan
@@ -53,6 +54,13 @@ class ADDAgent:
         self.N = N = env.num_envs
         self._load_params(cfg)
         self.T = T = self._steps_per_iter
+        # agent.matmul_precision: "fp32" (fp32 MFMA, default), "bf16x3" (exact 3-way bf16 split, fp32-level error, ~2.7x the
+        # MFMA rate) or "bf16"; operands, results and every other kernel stay fp32 (include/addhip.h: ADDHIP_PREC_*)
+        prec = str(cfg.get("matmul_precision", "fp32"))
+        if prec not in H.PRECISIONS:
+            raise ValueError(f"agent.matmul_precision must be one of {sorted(H.PRECISIONS)}")
+        H.DEFAULT_PRECISION = H.PRECISIONS[prec]
+        self._matmul_precision = prec
 
         # ---- motion library + sampler (add_motion.py:14-33)
         kin = env.robot._kin_char_model

@@ -155,6 +155,11 @@ int addhip_kin_engine_step(float* sim_pose, float* sim_vel, const float* target,
 /* ---- dense layers: torch.nn.Linear(+ReLU) stacks of PPOModel/ADDModel (ppo_model.py:13-21,
  *      add_model.py:12-15, nets/fc_*layers_1024units.py) on fp32 MFMA ---- */
 enum { ADDHIP_EPI_NONE = 0, ADDHIP_EPI_BIAS = 1, ADDHIP_EPI_BIAS_RELU = 2, ADDHIP_EPI_MASK = 3 };
+/* ADDHIP_PREC_F32: v_mfma_f32_32x32x2_f32.  ADDHIP_PREC_BF16X3: each fp32 operand split exactly into three bf16 chunks,
+ * six bf16 MFMAs per k-step accumulated in fp32 (error bound 2^-23 |a||b| per product, i.e. fp32-level; the reference
+ * itself runs its matmuls in TF32, main.py:16-18).  ADDHIP_PREC_BF16: operands truncated to bf16, fp32 accumulate.
+ * The split paths are used for shapes that fill the chip with 128x128 tiles; other shapes always take the fp32 path. */
+enum { ADDHIP_PREC_F32 = 0, ADDHIP_PREC_BF16 = 1, ADDHIP_PREC_BF16X3 = 3 };
 typedef struct {
   int32_t M, N, K;          /* C[M,N] = sum_k A(m,k) * B(n,k) */
   const float* A; int32_t lda; int32_t a_kcontig; /* 1: A[m*lda+k], 0: A[k*lda+m] */
@@ -168,6 +173,7 @@ typedef struct {
   float alpha;              /* scale applied to acc before the epilogue */
   float* colsum;            /* optional, MASK epilogue only: colsum[n] += sum_m C[m,n] (the bias gradient of the layer
                                whose pre-activation gradient this GEMM produces; atomics, caller zeroes) */
+  int32_t precision;        /* ADDHIP_PREC_*: how the fp32 products are formed (operands and results are fp32 either way) */
 } addhip_gemm_t;
 int addhip_gemm_f32(const addhip_gemm_t* g, void* stream);
 
