@@ -41,7 +41,7 @@ constexpr int OFF_ROWS = (OFF_ZERO + 1 + 3) / 4 * 4;        // 16-byte aligned
 constexpr int LROW = 48;
 __device__ __forceinline__ constexpr int row_off(int r, int c) { return OFF_ROWS + r * LROW + (c / 9) * 12 + (c % 9); }
 constexpr int work_of(bool vel) { return OFF_ROWS + rows_of(vel) * LROW; }   // floats per wave
-constexpr int map_of(bool vel, bool phase) { return vel ? 1024 : (phase ? 640 : 512); }  // obs_stride + 2*disc_stride must fit
+constexpr int map_of(bool vel, bool phase) { return vel ? 1024 : 640; }  // obs_stride + 2*disc_stride must fit
 
 enum { K_SKIP = 0, K_POSE = 1, K_VEL = 2, K_SIM = 3, K_HIST = 4, K_SIMV = 5, K_HISTV = 6 };
 

@@ -252,6 +252,63 @@ int launch_cfg(const addhip_gemm_t& g, hipStream_t st) {
   return addhip::check_launch("gemm_kernel");
 }
 
+// ------------------------------------------------------------------ a handful of rows (M <= 8, k-contiguous A)
+// e.g. the discriminator's single zero-difference sample: a tile kernel would run 4 workgroups through the whole K loop.
+// BKC: one wavefront per output column (lanes stride over k, wave reduction); !BKC: one thread per output column.
+constexpr int SMALL_M = 8;
+template <bool BKC>
+__global__ __launch_bounds__(256) void gemm_small_m_kernel(addhip_gemm_t g) {
+  float acc[SMALL_M];
+#pragma unroll
+  for (int m = 0; m < SMALL_M; ++m) acc[m] = 0.f;
+  int n;
+  bool writer;
+  if (BKC) {
+    n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= g.N) return;  // whole wave
+    const float* b = g.B + (size_t)n * g.ldb;
+    for (int k = lane * 4; k < g.K; k += 256) {  // K % 4 == 0 (checked by the caller)
+      const float4 bv = *reinterpret_cast<const float4*>(b + k);
+#pragma unroll
+      for (int m = 0; m < SMALL_M; ++m)
+        if (m < g.M) {
+          const float4 av = *reinterpret_cast<const float4*>(g.A + (size_t)m * g.lda + k);
+          acc[m] += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < SMALL_M; ++m)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o, 64);
+    writer = lane == 0;
+  } else {
+    n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= g.N) return;
+    for (int k = 0; k < g.K; ++k) {
+      const float bv = g.B[(size_t)k * g.ldb + n];
+#pragma unroll
+      for (int m = 0; m < SMALL_M; ++m)
+        if (m < g.M) acc[m] += g.A[(size_t)m * g.lda + k] * bv;
+    }
+    writer = true;
+  }
+  if (!writer) return;
+  const int epi = g.epilogue;
+  const float bias = (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU) ? g.bias[n] : 0.f;
+  float cs = 0.f;
+#pragma unroll
+  for (int m = 0; m < SMALL_M; ++m)
+    if (m < g.M) {
+      float v = g.alpha * acc[m] + bias;
+      if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+      if (epi == ADDHIP_EPI_MASK) v = g.mask[(size_t)m * g.ldmask + n] > 0.f ? v : 0.f;
+      g.C[(size_t)m * g.ldc + n] = v;
+      cs += v;
+    }
+  if (epi == ADDHIP_EPI_MASK && g.colsum) atomicAdd(&g.colsum[n], cs);
+}
+
 // ------------------------------------------------------------------ small reductions
 __global__ void slab_reduce_kernel(const float* in, int slabs, long long stride, float* out, long long count, float scale, int accumulate) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,6 +366,11 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   ADDHIP_REQUIRE(g.precision == ADDHIP_PREC_F32 || g.precision == ADDHIP_PREC_BF16 || g.precision == ADDHIP_PREC_BF16X3, "gemm: bad precision");
   if (g.alpha == 0.0f) g.alpha = 1.0f;
   hipStream_t st = (hipStream_t)stream;
+  if (g.M <= SMALL_M && g.a_kcontig && !g.a_mean && g.split_k <= 1) {
+    if (g.b_kcontig) hipLaunchKernelGGL(gemm_small_m_kernel<true>, dim3((g.N + 3) / 4), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_small_m_kernel<false>, dim3((g.N + 255) / 256), dim3(256), 0, st, g);
+    return addhip::check_launch("gemm_small_m_kernel");
+  }
   if (g.N <= 32) return launch_cfg<128, 32, 4, 1, 16>(g, st);
   if (g.N <= 64) return launch_cfg<128, 64, 2, 2, 16>(g, st);
   // keep >= ~1 block per CU on the skinny rollout shapes

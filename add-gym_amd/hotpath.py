@@ -24,6 +24,12 @@ def pad4(n):
     return (n + 3) // 4 * 4
 
 
+def pad16(n):
+    """Row strides of obs / disc-obs buffers: whole 64-byte groups, so that the K extent of the first-layer GEMMs is a whole
+    number of 16-deep MFMA stages (no tail stage) and rows start on 64-byte boundaries."""
+    return (n + 15) // 16 * 16
+
+
 def check_supported(task):
     """The HIP path covers the observation flags of configs/task/pose.yaml plus the global/height toggles.
     Anything else fails loudly instead of silently computing something different."""
@@ -67,7 +73,7 @@ def make_task(task, dt, max_episode_length=None):
     t.enable_phase_obs = int(bool(task.get("enable_phase_obs", True)))
     t.num_phase_encoding = int(task.get("num_phase_encoding", 0))
     t.obs_dim, t.disc_dim = obs_dims(task)
-    t.obs_stride, t.disc_stride = pad4(t.obs_dim), pad4(t.disc_dim)
+    t.obs_stride, t.disc_stride = pad16(t.obs_dim), pad16(t.disc_dim)
     return t
 
 

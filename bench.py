@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_f32_32x32x2_f32
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 32 cycles per instruction per SIMD)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy ceiling)
 ENV_STEP_BYTES = 4573         # algorithmic bytes per env-step of the fused obs/reward/done kernel
 
@@ -38,6 +39,9 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=256)
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement after the headline run")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                    help="agent.matmul_precision: how addhip_gemm_f32 forms its fp32 products (include/addhip.h ADDHIP_PREC_*)")
     return ap.parse_args()
 
 
@@ -65,6 +69,25 @@ def time_gemms(agent, reps=3):
             ms += e0.elapsed_time(e1)
     ms /= reps
     return dict(launches=len(calls), flops=flops, ms=ms)
+
+
+def gemm_roofline(agent, precision):
+    """HIP-event time of all GEMM launches of one optimiser step against the MFMA peak of the instruction that forms the
+    products: fp32 MFMA 157.3 TFLOP/s; bf16x3 = six bf16 MFMAs per fp32 product -> 2500 / 6 TFLOP/s of fp32 work."""
+    g = time_gemms(agent)
+    tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    if precision == "fp32":
+        peak, kern = MFMA_F32_PEAK_TFLOPS, "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all GEMM launches of one optimiser step)"
+        # PMC, profiles/r01_gemm_pmc.md: (WRITE_SIZE 1207.7 MB + 2 x FETCH_SIZE 2465.1 MB) / 30 launches of one optimiser step
+        traffic = (1207.7e6 + 2 * 2465.1e6) / 30
+    else:
+        products = 6 if precision == "bf16x3" else 1
+        peak = MFMA_BF16_PEAK_TFLOPS / products
+        kern = "gemm_split_kernel (v_mfma_f32_32x32x16_bf16 x %d per k-step; small shapes stay on gemm_kernel); all GEMM launches of one optimiser step" % products
+        traffic = None
+    return {"bound": "mfma", "kernel": kern, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic,
+            "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"],
+            "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS}
 
 
 def env_step_at_scale(num_envs=65536):
@@ -177,32 +200,41 @@ def main():
     from add_gym_amd.config import load_config
     from add_gym_amd.learning.add_agent import ADDAgent
 
-    cfg = load_config("train", [f"engine.num_envs={a.envs}", "task.motion_file=synthetic:1x3600", f"seed={1 + rank}"])
-    agent = ADDAgent(cfg, distributed=distributed)
-    agent.reset_all_envs()
-    agent._init_train()
-    gc.collect()
-    gc.freeze()  # as ADDAgent.train_model does: keep full collections (tens of ms) out of the launch loop
-
     def sync():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        agent._train_iter()
-        agent._iter += 1
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        agent._train_iter()
-        agent._iter += 1
-    sync()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def make_agent(precision):
+        cfg = load_config("train", [f"engine.num_envs={a.envs}", "task.motion_file=synthetic:1x3600", f"seed={1 + rank}",
+                                    f"agent.matmul_precision={precision}"])
+        ag = ADDAgent(cfg, distributed=distributed)
+        ag.reset_all_envs()
+        ag._init_train()
+        gc.collect()
+        gc.freeze()  # as ADDAgent.train_model does: keep full collections (tens of ms) out of the launch loop
+        return ag
+
+    def timed(ag):
+        """W untimed + exactly K timed iterations, barrier + synchronize on both sides, max over ranks."""
+        for _ in range(a.warmup):
+            ag._train_iter()
+            ag._iter += 1
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            ag._train_iter()
+            ag._iter += 1
+        sync()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    agent = make_agent(a.precision)
+    dt = timed(agent)
     env_steps = agent.T * agent.N * world * a.steps
     out = {
         "metric": "env-steps/sec (rollout+update), G1 imitation, 4096 envs/GPU",
@@ -216,13 +248,7 @@ def main():
     }
     if rank == 0:
         print(f"[bench] timed region done: {env_steps / dt:.0f} env-steps/s; measuring kernels + cpu baseline", file=sys.stderr, flush=True)
-        g = time_gemms(agent)
-        tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all GEMM launches of one optimiser step)",
-                           "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                           # PMC, profiles/r01_gemm_pmc.md: (WRITE_SIZE 1207.7 MB + 2 x FETCH_SIZE 2465.1 MB) / 30 launches of one optimiser step
-                           "traffic": (1207.7e6 + 2 * 2465.1e6) / 30,
-                           "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"]}
+        out["roofline"] = gemm_roofline(agent, a.precision)
         ms = time_env_step(agent)
         gbs = ENV_STEP_BYTES * agent.N / (ms * 1e-3) / 1e9
         out["roofline_env_step"] = {"bound": "hbm", "kernel": "env_step_kernel (addhip_env_step)", "achieved": gbs,
@@ -238,6 +264,18 @@ def main():
                                               "us_per_launch": ms2 * 1e3, "envs": big}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_envs, agent.T)
+    if a.precision == "fp32" and not a.no_alt:
+        # Same workload with agent.matmul_precision=bf16x3 (exact 3-way bf16 split of every fp32 operand, six bf16 MFMAs per
+        # k-step, fp32 accumulate: fp32-level error bound, include/addhip.h ADDHIP_PREC_BF16X3).  Reported beside the
+        # headline, which stays on the fp32 MFMA instruction; every rank runs it (the gradient all-reduce needs them all).
+        del agent
+        agent2 = make_agent("bf16x3")
+        dt2 = timed(agent2)
+        if rank == 0:
+            out["alt_precision"] = {"matmul_precision": "bf16x3", "value": env_steps / dt2, "unit": "env-steps/s", "ms_per_step": 1000.0 * dt2 / a.steps,
+                                    "dtype": "f32 operands and results; products = 6 bf16 MFMAs on an exact 3-way split, fp32 accumulate",
+                                    "roofline": gemm_roofline(agent2, "bf16x3")}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

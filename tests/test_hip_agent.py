@@ -63,7 +63,8 @@ def test_minibatch_loss_gradients_and_adamw_match_reference():
     mb = dict(norm_obs=on.normalize(g["in.obs"]), norm_action=an.normalize(g["in.action"]), a_logp=g["in.a_logp"], adv=g["in.adv"],
               tar_val=g["in.tar_val"], rand_action_mask=g["in.rand_action_mask"], norm_diff=dn.normalize(g["in.disc_obs_demo"] - g["in.disc_obs"]))
     W = ag._W
-    W["norm_obs"].copy_(T(mb["norm_obs"]))
+    W["norm_obs"].zero_()
+    W["norm_obs"][:, :264] = T(mb["norm_obs"])
     W["norm_act"].zero_()
     W["norm_act"][:, :29] = T(mb["norm_action"])
     W["mb_logp"].copy_(T(mb["a_logp"]))
@@ -201,7 +202,8 @@ def test_one_full_iteration_matches_reference_and_oracle():
     done = B["done"].cpu().numpy()
     assert np.array_equal(done, g["buf.done"])                                   # bit-exact flags, whole rollout
     assert np.array_equal(B["motion_time"].cpu().numpy(), g["buf.motion_times"])  # bit-exact clocks and reset times
-    np.testing.assert_allclose(B["obs"][Tn - 1].cpu().numpy(), g["buf.obs_last"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(B["obs"][Tn - 1].cpu().numpy()[:, :264], g["buf.obs_last"], rtol=0, atol=5e-5)
+    assert np.all(B["obs"].cpu().numpy()[..., 264:] == 0)
     np.testing.assert_allclose(B["reward"].cpu().numpy(), g["buf.reward"], rtol=5e-4, atol=5e-5)
     np.testing.assert_allclose(B["adv"].cpu().numpy(), g["buf.adv"], rtol=5e-3, atol=5e-3)
     np.testing.assert_allclose(B["adv"].cpu().numpy(), orc.buf["adv"], rtol=5e-3, atol=5e-3)

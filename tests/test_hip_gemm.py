@@ -138,6 +138,10 @@ def test_gemm_split_k_weight_grad_shape(split):
 def test_gemm_single_row_and_alpha():
     run_gemm(1, 1024, 116, 1, 1, epilogue=2)
     run_gemm(1, 512, 1024, 1, 1, epilogue=2)
+    for m in (1, 3, 8):  # the few-row kernel: both B layouts, every epilogue
+        for epi in (0, 1, 2, 3):
+            run_gemm(m, 1024, 512, 1, 0, epilogue=epi)
+            run_gemm(m, 516, 128, 1, 1, epilogue=epi)
     run_gemm(200, 116, 1024, 1, 0, alpha=0.5)
 
 
