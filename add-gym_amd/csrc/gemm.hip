@@ -283,13 +283,35 @@ __global__ __launch_bounds__(256) void gemm_small_m_kernel(addhip_gemm_t g) {
       for (int o = 32; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o, 64);
     writer = lane == 0;
   } else {
-    n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= g.N) return;
-    for (int k = 0; k < g.K; ++k) {
-      const float bv = g.B[(size_t)k * g.ldb + n];
+    // 32 columns x 8 k-slices per workgroup; each thread walks its slice 8 rows at a time (8 independent loads in flight)
+    __shared__ float part[8][SMALL_M][32];
+    const int c = threadIdx.x & 31, ks = threadIdx.x >> 5;
+    n = blockIdx.x * 32 + c;
+    const int nn = min(n, g.N - 1);
+    const int kper = (g.K + 7) / 8;
+    const int k0 = ks * kper, k1 = min(g.K, k0 + kper);
+    for (int k = k0; k < k1; k += 8) {
+      float bv[8];
 #pragma unroll
-      for (int m = 0; m < SMALL_M; ++m)
-        if (m < g.M) acc[m] += g.A[(size_t)m * g.lda + k] * bv;
+      for (int j = 0; j < 8; ++j) bv[j] = g.B[(size_t)min(k + j, g.K - 1) * g.ldb + nn];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k + j < k1) {
+#pragma unroll
+          for (int m = 0; m < SMALL_M; ++m)
+            if (m < g.M) acc[m] += g.A[(size_t)m * g.lda + k + j] * bv[j];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < SMALL_M; ++m) part[ks][m][c] = acc[m];
+    __syncthreads();
+    if (ks != 0 || n >= g.N) return;
+#pragma unroll
+    for (int m = 0; m < SMALL_M; ++m) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += part[q][m][c];
+      acc[m] = t;
     }
     writer = true;
   }
@@ -368,7 +390,7 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (g.M <= SMALL_M && g.a_kcontig && !g.a_mean && g.split_k <= 1) {
     if (g.b_kcontig) hipLaunchKernelGGL(gemm_small_m_kernel<true>, dim3((g.N + 3) / 4), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(gemm_small_m_kernel<false>, dim3((g.N + 255) / 256), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_small_m_kernel<false>, dim3((g.N + 31) / 32), dim3(256), 0, st, g);
     return addhip::check_launch("gemm_small_m_kernel");
   }
   if (g.N <= 32) return launch_cfg<128, 32, 4, 1, 16>(g, st);
