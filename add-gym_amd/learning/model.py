@@ -7,7 +7,7 @@ add_model.py:29-46, nets/fc_3layers_1024units.py, nets/fc_2layers_1024units.py):
   actor  obs -> 1024 -> 1024 -> 512 -> 29 (ReLU; fixed logstd)      critic obs -> 1024 -> 1024 -> 512 -> 1
   disc   disc_obs -> 1024 -> 512 -> 1
 Device layout differences (all invisible in checkpoints): rows of the 29-wide actor head are padded
-to 32, the 114-wide discriminator input to 116 columns, 1-wide heads are stored as vectors.
+to 32, input columns to the row strides of the obs buffers (264 -> 272, 114 -> 128), 1-wide heads are stored as vectors.
 """
 import math
 
