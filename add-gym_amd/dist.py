@@ -22,6 +22,22 @@ def all_reduce_mean_(flat):
     return flat
 
 
+def all_reduce_sum_async(flat):
+    """Start an in-place sum over ranks of one gradient bucket; returns the work handle (None on one rank).  The collective
+    is ordered after the kernels already enqueued on the current stream (process-group semantics) and runs on the
+    backend's own stream, i.e. beside whatever the caller enqueues next."""
+    if world_size() > 1:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
+def wait_all(handles):
+    """Make the current stream wait for the collectives started by all_reduce_sum_async (no host block with nccl)."""
+    for h in handles:
+        if h is not None:
+            h.wait()
+
+
 def all_reduce_sum_(*tensors):
     """In-place sums over ranks (normaliser statistics); returns the world size so callers can scale their counts."""
     w = world_size()

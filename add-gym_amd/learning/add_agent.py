@@ -242,6 +242,7 @@ class ADDAgent:
         p.add("addhip_col_sum", L.ptr(W["d_mean"]), Mb, 32, 32, m.g("actor", "bh"), 1.0, 0)
         self._gemm(p, Mb, hA, 32, L.ptr(W["d_mean"]), 32, 1, m.p("actor", "Wh"), hA, 0, L.ptr(ra.dz[-1]), hA, L.EPI_MASK, mask=L.ptr(ra.h[-1]), ldmask=hA)
         ra.backward(p, L.ptr(W["norm_obs"]), Mb)
+        self._update_marks = [("actor", len(p.calls))]  # the net's gradient is complete after this many calls
         # critic
         rc.forward(p, L.ptr(W["norm_obs"]), Mb)
         p.add("addhip_critic_head", L.ptr(rc.h[-1]), hC, hC, Mb, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(W["mb_tar"]), self._critic_loss_weight,
@@ -249,6 +250,7 @@ class ADDAgent:
         p.add("addhip_weighted_col_sum", L.ptr(W["dv"]), L.ptr(rc.h[-1]), hC, hC, Mb, m.g("critic", "Wh"), 1.0, 0)
         p.add("addhip_col_sum", L.ptr(W["dv"]), Mb, 1, 1, m.g("critic", "bh"), 1.0, 0)
         rc.backward(p, L.ptr(W["norm_obs"]), Mb)
+        self._update_marks.append(("critic", len(p.calls)))
         # discriminator: Mb agent/demo differences + one zero-difference row (row Mb of norm_diff stays 0)
         Md = Mb + 1
         nd = L.ptr(W["norm_diff"])
@@ -277,6 +279,7 @@ class ADDAgent:
         p.add("addhip_l2_grad", m.p("disc", "W0"), m.g("disc", "W0"), m.n_elem("disc", "W0"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
         p.add("addhip_l2_grad", m.p("disc", "W1"), m.g("disc", "W1"), m.n_elem("disc", "W1"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
         p.add("addhip_l2_grad", m.p("disc", "Wh"), m.g("disc", "Wh"), m.n_elem("disc", "Wh"), 2.0 * ls_d * (wd + self._disc_logit_reg), L.ptr(W["stats"]) + 4 * 25)
+        self._update_marks.append(("disc", len(p.calls)))
 
         self._gather_c = L.GatherT(L.ptr(W["perm_idx"]), Mb, L.ptr(B["obs"]), OS, tk.obs_dim, L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(B["action"]),
                                    L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), L.ptr(B["a_logp"]), L.ptr(B["adv"]), L.ptr(B["tar_val"]), L.ptr(B["rand_mask"]),
@@ -447,9 +450,19 @@ class ADDAgent:
             for _ in range(num_batches):
                 self._next_minibatch_indices()
                 L.call("addhip_gather_minibatch", self._gather_c, st)
-                self._update_plan.run(st)
-                if self._world > 1:  # the exchange step: mean gradient over ranks (RCCL all-reduce over xGMI)
-                    D.all_reduce_mean_(m.grads)
+                if self._world > 1:
+                    # the exchange step: mean gradient over ranks (RCCL all-reduce over xGMI), one bucket per net, each
+                    # started as soon as that net's backward is enqueued so that it overlaps the next net's GEMMs
+                    first, pending = 0, []
+                    for net, mark in self._update_marks:
+                        self._update_plan.run(st, first, mark)
+                        a, b = m.net_ranges[net]
+                        pending.append(D.all_reduce_sum_async(m.grads[a:b]))
+                        first = mark
+                    D.wait_all(pending)
+                    m.grads.mul_(1.0 / self._world)
+                else:
+                    self._update_plan.run(st)
                 m.opt_step += 1
                 L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, self._lr, 0.9, 0.999, 1e-8,
                        self._wd, m.opt_step, st)

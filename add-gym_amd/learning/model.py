@@ -61,6 +61,12 @@ class Model:
                 self.offsets[(net.name, key)] = (off, shape)
                 off += (n + 3) // 4 * 4
         self.count = off
+        # contiguous [start, end) of each net in the flat buffers (gradient buckets of the data-parallel exchange)
+        self.net_ranges = {}
+        for net in self.nets:
+            first = self.offsets[(net.name, net.specs[0][0])][0]
+            last_off, last_shape = self.offsets[(net.name, net.specs[-1][0])]
+            self.net_ranges[net.name] = (first, last_off + (math.prod(last_shape) + 3) // 4 * 4)
         self.params = torch.zeros(off, device=device)
         self.grads = torch.zeros(off, device=device)
         self.exp_avg = torch.zeros(off, device=device)
@@ -182,8 +188,8 @@ class Plan:
     def hold(self, *objs):
         self.keep.extend(objs)
 
-    def run(self, stream):
-        for name, fn, args in self.calls:
+    def run(self, stream, first=0, last=None):
+        for name, fn, args in self.calls[first:last]:
             rc = fn(*args, stream)
             if rc != 0:
                 raise L.AddhipError(f"{name} failed ({rc}): {self._lib.addhip_last_error().decode()}")

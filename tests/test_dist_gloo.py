@@ -44,7 +44,14 @@ def _worker(rank, world, port, tmp):
     names = model.names()
     grads = torch.autograd.grad(loss, [model.p[n] for n in names])
     flat = torch.cat([g.reshape(-1) for g in grads])
+    flat_b = flat.clone()
     D.all_reduce_mean_(flat)
+    # the agent's exchange: one asynchronous bucket per net, started in turn, one wait, one scale (add_agent._update_model)
+    third = flat_b.numel() // 3
+    cuts = [0, third, 2 * third, flat_b.numel()]
+    pending = [D.all_reduce_sum_async(flat_b[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    D.wait_all(pending)
+    flat_b.mul_(1.0 / world)
     # normaliser sums
     x = torch.tensor(rng.standard_normal((2, 50, 9)).astype(np.float32))[rank]
     s1, s2 = x.sum(0), (x * x).sum(0)
@@ -52,7 +59,7 @@ def _worker(rank, world, port, tmp):
     b = torch.full((5,), float(rank))
     D.broadcast_(b, 0)
     if rank == 0:
-        torch.save(dict(flat=flat, s1=s1, s2=s2, w=w, b=b), tmp)
+        torch.save(dict(flat=flat, flat_b=flat_b, s1=s1, s2=s2, w=w, b=b), tmp)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,6 +86,7 @@ def test_two_rank_gradient_mean_and_normaliser_sums(tmp_path):
     # the zero-difference "positive" sample enters every rank's loss once: mean over ranks == single-process value as well
     scale = ref.abs().max()
     assert (got["flat"] - ref).abs().max() <= 2e-5 * scale
+    assert torch.equal(got["flat_b"], got["flat"])  # bucketed asynchronous exchange == one flat all-reduce
     x = torch.tensor(rng.standard_normal((2, 50, 9)).astype(np.float32)).reshape(100, 9)
     assert got["w"] == 2
     torch.testing.assert_close(got["s1"], x.sum(0), rtol=1e-5, atol=1e-5)
