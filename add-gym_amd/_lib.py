@@ -114,6 +114,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: libaddhip.so must bind to the HIP runtime already in the process (the one torch ships and allocates
+    # with); loaded the other way round, two runtimes coexist and launches fail with "no ROCm-capable device"
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise AddhipError(f"{LIB_PATH} not found: build it with `make -C add-gym_amd/csrc` (or __graft_entry__.build()). "
                           "There is no CPU fallback for the hot path.")
