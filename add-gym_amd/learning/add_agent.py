@@ -192,10 +192,13 @@ class ADDAgent:
             for i, h in enumerate(net.hidden):
                 in_ld = net.in_ld if i == 0 else net.hidden[i - 1]
                 need = max(need, 2 * split_k_for(h, in_ld, Mb + 1) * h * in_ld)  # x2: gradient-penalty product shares the reduce
-        self._slabs = z(need)
-        self._run_actor = NetRunner(m, m.actor, rows, dev, self._slabs)
-        self._run_critic = NetRunner(m, m.critic, rows, dev, self._slabs)
-        self._run_disc = NetRunner(m, m.disc, rows, dev, self._slabs)
+        # split-K scratch: one per net, because the three nets' update sections run on three concurrent streams
+        self._slabs_all = z(3, need)
+        self._slabs = self._slabs_all[0]
+        self._run_actor = NetRunner(m, m.actor, rows, dev, self._slabs_all[0])
+        self._run_critic = NetRunner(m, m.critic, rows, dev, self._slabs_all[1])
+        self._run_disc = NetRunner(m, m.disc, rows, dev, self._slabs_all[2])
+        self._side_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         OS, DS = self._task.obs_stride, self._task.disc_stride
         hd = m.disc.hidden
         self._W = dict(mean=z(rows, 32), d_mean=z(rows, 32), noise=z(N, L.NUM_DOF), u=z(3, N), logits=z(rows), nv=z(1),
@@ -450,24 +453,46 @@ class ADDAgent:
             for _ in range(num_batches):
                 self._next_minibatch_indices()
                 L.call("addhip_gather_minibatch", self._gather_c, st)
-                if self._world > 1:
-                    # the exchange step: mean gradient over ranks (RCCL all-reduce over xGMI), one bucket per net, each
-                    # started as soon as that net's backward is enqueued so that it overlaps the next net's GEMMs
-                    first, pending = 0, []
-                    for net, mark in self._update_marks:
-                        self._update_plan.run(st, first, mark)
-                        a, b = m.net_ranges[net]
-                        pending.append(D.all_reduce_sum_async(m.grads[a:b]))
-                        first = mark
-                    D.wait_all(pending)
-                    m.grads.mul_(1.0 / self._world)
-                else:
-                    self._update_plan.run(st)
+                self._run_update_sections()
                 m.opt_step += 1
                 L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, self._lr, 0.9, 0.999, 1e-8,
                        self._wd, m.opt_step, st)
                 steps += 1
         return steps
+
+    def _run_update_sections(self):
+        """The actor, critic and discriminator sections of the update plan are independent until the optimiser: they run on
+        three streams, so that one net's tile write-out bursts and partial last waves of workgroups overlap another
+        net's MFMA phases (all tiles of one GEMM launch are in phase with each other).  With more than one rank each
+        section is followed, on its own stream, by the asynchronous all-reduce of that net's gradient bucket (the exchange
+        step: mean gradient over ranks, RCCL over xGMI), which therefore also overlaps the other nets' GEMMs."""
+        m, plan = self._model, self._update_plan
+        main = torch.cuda.current_stream()
+        streams = [main] + self._side_streams
+        fork = torch.cuda.Event()
+        fork.record(main)
+        # stream-ordered asynchronous collectives are an nccl (RCCL) property; any other backend (gloo in rehearsals) gets one
+        # blocking all-reduce of the whole gradient after the join
+        overlap = self._world > 1 and torch.distributed.get_backend() == "nccl"
+        first, pending = 0, []
+        for (net, mark), s in zip(self._update_marks, streams):
+            if s is not main:
+                s.wait_event(fork)
+            plan.run(s.cuda_stream, first, mark)
+            if overlap:
+                a, b = m.net_ranges[net]
+                with torch.cuda.stream(s):
+                    pending.append(D.all_reduce_sum_async(m.grads[a:b]))
+            first = mark
+        for s in self._side_streams:
+            done = torch.cuda.Event()
+            done.record(s)
+            main.wait_event(done)
+        if overlap:
+            D.wait_all(pending)
+            m.grads.mul_(1.0 / self._world)
+        elif self._world > 1:
+            D.all_reduce_mean_(m.grads)
 
     def _need_normalizer_update(self):
         return self._sample_count < self._normalizer_samples
