@@ -51,6 +51,10 @@ class KinCharModel:
     def get_body_id(self, name):
         return self._body_names.index(name)
 
+    def joint_axes(self):
+        """[D,3] hinge axes in dof order (part of the identity of a step table built with this tree)."""
+        return self._axes.tolist()
+
     def dof_ranges(self):
         return self._ranges
 

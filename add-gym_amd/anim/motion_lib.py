@@ -27,20 +27,64 @@ def torch_cpu_arange(n, step, vec=8):
 
 
 class MotionLib:
-    def __init__(self, motion_file, motion_order, kin_char_model, dt, device, reference_compat=True, frames_list=None, weights=None):
+    CACHE_VERSION = 1
+    _HOST_FIELDS = ("host_pose", "host_vel", "_motion_num_frames", "_motion_lengths", "_motion_loop_modes", "_motion_weights", "_step_counts",
+                    "_raw_start", "_step_start")
+
+    def __init__(self, motion_file, motion_order, kin_char_model, dt, device, reference_compat=True, frames_list=None, weights=None,
+                 cache_dir=None):
+        """cache_dir (task.motion_cache_dir): keep the finished 100 Hz step tables on disk, keyed by the clips' bytes, the
+        joint order, dt and the kinematic tree, so that later launches skip the ~1.5 s/clip host ingest.  (The reference
+        instead rewrites each .motion file as a .pkl next to it, motion_lib.py:164-200: a side effect on the dataset.)"""
         self._device, self._kin, self._dt = device, kin_char_model, dt
         self._dt_inv = round(1 / dt)  # motion_lib.py:23
         self.reference_compat = bool(reference_compat)
+        self.from_cache = False
         if frames_list is None and str(motion_file).startswith("synthetic:"):
             from .synth import parse_synthetic, synth_clip
 
             clips, nframes = parse_synthetic(motion_file)
             frames_list = [synth_clip(kin_char_model, list(motion_order), c, nframes) for c in range(clips)]
             weights = [1.0] * clips
+        cache_file = None
         if frames_list is None:
             files, weights = self._fetch_motion_files(motion_file)
+            if cache_dir:
+                cache_file = os.path.join(cache_dir, self._cache_key(files, weights, list(motion_order)) + ".pt")
+                if os.path.exists(cache_file) and self._load_cache(cache_file):
+                    self._upload()
+                    return
             frames_list = [motion_io.load_motion(f).frames for f in files]
         self._build(frames_list, weights, list(motion_order))
+        if cache_file is not None:
+            os.makedirs(cache_dir, exist_ok=True)
+            tmp = cache_file + f".{os.getpid()}.tmp"
+            torch.save({"version": self.CACHE_VERSION, **{k: getattr(self, k) for k in self._HOST_FIELDS}}, tmp)
+            os.replace(tmp, cache_file)  # atomic: several ranks may build the same table at once
+
+    def _cache_key(self, files, weights, order):
+        import hashlib
+
+        h = hashlib.sha256()
+        h.update(repr((self.CACHE_VERSION, float(self._dt), order, [float(w) for w in weights], self._kin.get_joint_order(),
+                       [list(map(float, a)) for a in self._kin.joint_axes()])).encode())
+        for f in files:
+            with open(f, "rb") as fh:
+                h.update(hashlib.sha256(fh.read()).digest())
+        return h.hexdigest()[:32]
+
+    def _load_cache(self, path):
+        try:
+            blob = torch.load(path, weights_only=True)  # our own file; tensors only
+        except Exception:
+            return False
+        if blob.get("version") != self.CACHE_VERSION or any(k not in blob for k in self._HOST_FIELDS):
+            return False
+        for k in self._HOST_FIELDS:
+            setattr(self, k, blob[k])
+        self.total_steps = int(self._step_counts.sum())
+        self.from_cache = True
+        return True
 
     # motion_lib.py:337-358
     @staticmethod

@@ -65,7 +65,7 @@ class ADDAgent:
         # ---- motion library + sampler (add_motion.py:14-33)
         kin = env.robot._kin_char_model
         self._motion_lib = MotionLib(task["motion_file"], list(task["motion_joint_order"]), kin, env.ctrl_dt, dev,
-                                     reference_compat=task.get("reference_compat", True))
+                                     reference_compat=task.get("reference_compat", True), cache_dir=task.get("motion_cache_dir", None))
         lib = self._motion_lib
         self._task = make_task(task, env.ctrl_dt, max_episode_length=lib.get_total_length())
         tk = self._task

@@ -29,7 +29,7 @@ def make_agent(cfg, frames_list, weights):
 
     orig = A.MotionLib
 
-    def lib(motion_file, order, kin, dt, dev, reference_compat=True):
+    def lib(motion_file, order, kin, dt, dev, reference_compat=True, cache_dir=None):
         return MotionLib(None, order, kin, dt, dev, reference_compat=reference_compat, frames_list=frames_list, weights=weights)
 
     A.MotionLib = lib
