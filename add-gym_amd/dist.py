@@ -26,7 +26,7 @@ def all_reduce_sum_async(flat):
     """Start an in-place sum over ranks of one gradient bucket; returns the work handle (None on one rank).  The collective
     is ordered after the kernels already enqueued on the current stream (process-group semantics) and runs on the
     backend's own stream, i.e. beside whatever the caller enqueues next."""
-    if world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
     return None
 

@@ -473,7 +473,9 @@ class ADDAgent:
         fork.record(main)
         # stream-ordered asynchronous collectives are an nccl (RCCL) property; any other backend (gloo in rehearsals) gets one
         # blocking all-reduce of the whole gradient after the join
-        overlap = self._world > 1 and torch.distributed.get_backend() == "nccl"
+        # (ADDHIP_EXERCISE_EXCHANGE=1: take the multi-rank code path in a 1-rank nccl group, to rehearse it on a single GPU)
+        exchange = self._world > 1 or (self._distributed and os.environ.get("ADDHIP_EXERCISE_EXCHANGE") == "1")
+        overlap = exchange and torch.distributed.get_backend() == "nccl"
         first, pending = 0, []
         for (net, mark), s in zip(self._update_marks, streams):
             if s is not main:
@@ -491,7 +493,7 @@ class ADDAgent:
         if overlap:
             D.wait_all(pending)
             m.grads.mul_(1.0 / self._world)
-        elif self._world > 1:
+        elif exchange:
             D.all_reduce_mean_(m.grads)
 
     def _need_normalizer_update(self):

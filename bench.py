@@ -191,7 +191,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path is HIP-only)")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("ADDHIP_EXERCISE_EXCHANGE") == "1"  # the latter: 1-rank RCCL group, rehearsal only
+    if distributed and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if distributed:
         # "nccl" is RCCL on ROCm.  ADDHIP_DIST_BACKEND=gloo exists only to rehearse the multi-rank plumbing on a box with
         # fewer GPUs than ranks (several ranks then share a device); it is never the measured configuration.
