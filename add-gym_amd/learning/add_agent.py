@@ -283,6 +283,20 @@ class ADDAgent:
         p.add("addhip_l2_grad", m.p("disc", "W1"), m.g("disc", "W1"), m.n_elem("disc", "W1"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
         p.add("addhip_l2_grad", m.p("disc", "Wh"), m.g("disc", "Wh"), m.n_elem("disc", "Wh"), 2.0 * ls_d * (wd + self._disc_logit_reg), L.ptr(W["stats"]) + 4 * 25)
         self._update_marks.append(("disc", len(p.calls)))
+        # Launch / exchange schedule of one optimiser step: (stream, first call, last call, gradient range to all-reduce after it).
+        # Actor and critic hand over everything but their first layer as soon as it is final; the collectives are issued
+        # in the order they become ready, because one communicator runs them in issue order.
+        (_, end_a), (_, end_c), (_, end_d) = self._update_marks
+
+        def tail_range(net):  # [W1 .. end of net)
+            return m.offsets[(net, "W1")][0], m.net_ranges[net][1]
+
+        def head_range(net):  # [W0, b0]
+            return m.net_ranges[net][0], m.offsets[(net, "W1")][0]
+
+        ea, ec = ra.early_mark, rc.early_mark
+        self._update_schedule = [(0, 0, ea, tail_range("actor")), (1, end_a, ec, tail_range("critic")), (2, end_c, end_d, m.net_ranges["disc"]),
+                                 (0, ea, end_a, head_range("actor")), (1, ec, end_c, head_range("critic"))]
 
         self._gather_c = L.GatherT(L.ptr(W["perm_idx"]), Mb, L.ptr(B["obs"]), OS, tk.obs_dim, L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(B["action"]),
                                    L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), L.ptr(B["a_logp"]), L.ptr(B["adv"]), L.ptr(B["tar_val"]), L.ptr(B["rand_mask"]),
@@ -476,16 +490,15 @@ class ADDAgent:
         # (ADDHIP_EXERCISE_EXCHANGE=1: take the multi-rank code path in a 1-rank nccl group, to rehearse it on a single GPU)
         exchange = self._world > 1 or (self._distributed and os.environ.get("ADDHIP_EXERCISE_EXCHANGE") == "1")
         overlap = exchange and torch.distributed.get_backend() == "nccl"
-        first, pending = 0, []
-        for (net, mark), s in zip(self._update_marks, streams):
-            if s is not main:
-                s.wait_event(fork)
-            plan.run(s.cuda_stream, first, mark)
+        pending = []
+        for s in self._side_streams:
+            s.wait_event(fork)
+        for si, first, last, (a, b) in self._update_schedule:
+            s = streams[si]
+            plan.run(s.cuda_stream, first, last)
             if overlap:
-                a, b = m.net_ranges[net]
                 with torch.cuda.stream(s):
                     pending.append(D.all_reduce_sum_async(m.grads[a:b]))
-            first = mark
         for s in self._side_streams:
             done = torch.cuda.Event()
             done.record(s)

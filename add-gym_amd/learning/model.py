@@ -200,6 +200,7 @@ class NetRunner:
 
     def __init__(self, model, net, rows, device, slabs):
         self.m, self.net, self.rows, self.slabs = model, net, rows, slabs
+        self.early_mark = None
         self.h = [torch.zeros(rows, h, device=device) for h in net.hidden]
         self.dz = [torch.zeros(rows, h, device=device) for h in net.hidden]
 
@@ -245,6 +246,10 @@ class NetRunner:
                 plan.add("addhip_gemm_f32", g2)
                 total = 2 * s
             plan.add("addhip_slab_reduce", L.ptr(self.slabs), total, slab, m.g(net.name, f"W{i}"), slab, 1.0, 0)
+            if i == 1:
+                # every gradient of this net except W0 / b0 is final here (b1 came with the dX GEMM of layer 2, the head's
+                # with the loss kernels): an early bucket for the data-parallel exchange
+                self.early_mark = len(plan.calls)
             if i == n - 1:  # the top layer's dz comes from the loss kernels; the others get their bias gradient from the
                 plan.add("addhip_col_sum", L.ptr(self.dz[i]), rows, out_d, out_d, m.g(net.name, f"b{i}"), 1.0, 0)  # dX GEMM below
             if i > 0:
