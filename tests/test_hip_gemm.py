@@ -132,6 +132,7 @@ def test_gemm_fused_normalisation():
 def test_gemm_split_k_weight_grad_shape(split):
     # dW[out,in] = dY^T X : both operands m-contiguous, reduction over the minibatch rows
     run_gemm(1024, 264, 4096 + 17, 0, 0, split_k=split)
+    run_gemm(1024, 272, 4096 + 17, 0, 0, split_k=max(split, 11))  # >= 256 tiles of 128x96: the 96-wide configuration
     run_gemm(32, 512, 1000, 0, 0, split_k=split)
 
 

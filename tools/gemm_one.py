@@ -9,7 +9,7 @@ prec = a[0] if a else 0
 M, N, K = a[1:4] if len(a) >= 4 else (16384, 1024, 1024)
 akc, bkc, epi = a[4:7] if len(a) >= 7 else (1, 1, 2)
 split = a[7] if len(a) >= 8 else 1
-A, B, C, bias = torch.randn(M*K, device="cuda"), torch.randn(N*K, device="cuda"), torch.zeros(M*N, device="cuda"), torch.randn(N, device="cuda")
+A, B, C, bias = torch.randn(M*K, device="cuda"), torch.randn(N*K, device="cuda"), torch.zeros(M*N*split, device="cuda"), torch.randn(N, device="cuda")
 mask = torch.randn(M*N, device="cuda")
 g = gemm(M, N, K, L.ptr(A), K if akc else M, akc, L.ptr(B), K if bkc else N, bkc, L.ptr(C), N, epi, L.ptr(bias), L.ptr(mask), N, precision=prec, split_k=split)
 st = torch.cuda.current_stream()
