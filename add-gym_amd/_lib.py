@@ -66,7 +66,7 @@ class GatherT(C.Structure):
 
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
-PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 3
+PREC_F32, PREC_BF16, PREC_BF16X2, PREC_BF16X3 = 0, 1, 2, 3
 
 i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
 P = C.POINTER

@@ -385,7 +385,8 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   if (g.split_k > 1) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_NONE, "gemm: split-K slabs take no epilogue");
   if (g.a_mean || g.a_std) ADDHIP_REQUIRE(g.a_kcontig && g.a_mean && g.a_std, "gemm: fused normalisation needs a k-contiguous A and both mean/std");
   if (g.colsum) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && g.split_k <= 1, "gemm: colsum needs the MASK epilogue");
-  ADDHIP_REQUIRE(g.precision == ADDHIP_PREC_F32 || g.precision == ADDHIP_PREC_BF16 || g.precision == ADDHIP_PREC_BF16X3, "gemm: bad precision");
+  ADDHIP_REQUIRE(g.precision == ADDHIP_PREC_F32 || g.precision == ADDHIP_PREC_BF16 || g.precision == ADDHIP_PREC_BF16X2 ||
+                     g.precision == ADDHIP_PREC_BF16X3, "gemm: bad precision");
   if (g.alpha == 0.0f) g.alpha = 1.0f;
   hipStream_t st = (hipStream_t)stream;
   if (g.M <= SMALL_M && g.a_kcontig && !g.a_mean && g.split_k <= 1) {
@@ -403,7 +404,7 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   const int waste128 = (g.N + 127) / 128 * 128 - g.N, waste96 = (g.N + 95) / 96 * 96 - g.N;
   const bool narrow = waste128 >= 64 && waste96 < 32 &&
                       (long long)((g.M + 127) / 128) * ((g.N + 95) / 96) * (g.split_k > 1 ? g.split_k : 1) >= 256;
-  if (g.precision == ADDHIP_PREC_BF16X3 || g.precision == ADDHIP_PREC_BF16) return addhip::gemm_split_dispatch(g, g.precision, st);
+  if (g.precision != ADDHIP_PREC_F32) return addhip::gemm_split_dispatch(g, g.precision, st);
   if (narrow) return launch_cfg<128, 96, 4, 1, 32>(g, st);
   return launch_cfg<128, 128, 2, 2, 32>(g, st);
 }

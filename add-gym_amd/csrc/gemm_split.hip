@@ -5,7 +5,9 @@
 // A product of two bf16 values is exact in fp32, so the only roundings are those of the fp32 accumulation -- the same
 // ones v_mfma_f32_32x32x2_f32 performs.  The CDNA4 bf16 MFMA rate is 16x its fp32 MFMA rate, so six bf16 MFMAs per
 // k-step are 2.7x cheaper than the fp32 instruction for the same arithmetic (gemm.hip keeps the fp32-MFMA path).
-// PLANES = 1 is the plain bf16 product (operands rounded toward zero to bf16, fp32 accumulate).
+// PLANES = 2 keeps hi and mid (16 significant bits per operand) and the three products above 2^-16: a TF32-class mode
+// with 64x less error than TF32 at half the MFMA work of the exact split.  PLANES = 1 is the plain bf16 product
+// (operands rounded toward zero to bf16, fp32 accumulate).
 //
 // Same interface, tiling and epilogues as gemm.hip: 128x128 tile, 4 wavefronts of 64x64 (2x2 MFMA accumulators),
 // operands stay fp32 in HBM and are split on their way into LDS.  LDS image of an operand tile: [row][plane][16 k] bf16
@@ -77,10 +79,8 @@ __device__ __forceinline__ void store_kc(char* lds, const float4* reg, int i, in
   split3(v.z, h[2], m[2], l[2]);
   split3(v.w, h[3], m[3], l[3]);
   *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-  if (PLANES == 3) {
-    *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pack2(m[0], m[1]), pack2(m[2], m[3]));
-    *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
-  }
+  if (PLANES >= 2) *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pack2(m[0], m[1]), pack2(m[2], m[3]));
+  if (PLANES == 3) *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
 }
 
 // ---- m/n-contiguous operand P[k*ld + r]: each thread moves rows r..r+3 of two consecutive k per stage ---------------
@@ -105,10 +105,8 @@ __device__ __forceinline__ void store_mc(char* lds, const float4* reg, int i, in
     split3(in0 ? a[j] : 0.f, ha, ma, la);
     split3(in1 ? b[j] : 0.f, hb, mb, lb);
     *reinterpret_cast<unsigned*>(dst) = pack2(ha, hb);
-    if (PLANES == 3) {
-      *reinterpret_cast<unsigned*>(dst + 32) = pack2(ma, mb);
-      *reinterpret_cast<unsigned*>(dst + 64) = pack2(la, lb);
-    }
+    if (PLANES >= 2) *reinterpret_cast<unsigned*>(dst + 32) = pack2(ma, mb);
+    if (PLANES == 3) *reinterpret_cast<unsigned*>(dst + 64) = pack2(la, lb);
   }
 }
 
@@ -195,6 +193,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
+    }
+    if (PLANES >= 2) {
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
     }
@@ -227,13 +227,14 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
     stash_part(std::false_type{}, 2, kt + 1, a_next, b_next);
     mfma_group(1, 1, fa, fb);
     stash_part(std::false_type{}, 3, kt + 1, a_next, b_next);
-    if (PLANES == 3) {
-      // pin the interleave: per MFMA up to 5 VALU, and a DS write after every second one
+    if (PLANES >= 2) {
+      // pin the interleave: the split's VALU work spread evenly over the MFMAs, a DS write after every second (third) one
+      constexpr int NM = PLANES == 3 ? 24 : 12, PER = PLANES == 3 ? 5 : 8;
 #pragma unroll
-      for (int i = 0; i < 24; ++i) {
+      for (int i = 0; i < NM; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-        if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
+        if (PLANES == 3 ? (i & 1) : true) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       }
     }
     lds_barrier();
@@ -339,6 +340,6 @@ namespace addhip {
 // called by addhip_gemm_f32 (gemm.hip) after argument validation, for the shapes that fill the chip with 128x128 tiles
 int gemm_split_dispatch(const addhip_gemm_t& g, int planes, hipStream_t st) {
   if (g.a_mean && g.K > 512) return (set_error("gemm: fused normalisation on the bf16 paths needs K <= 512"), -1);
-  return planes == 3 ? launch_split<3>(g, st) : launch_split<1>(g, st);
+  return planes == 3 ? launch_split<3>(g, st) : planes == 2 ? launch_split<2>(g, st) : launch_split<1>(g, st);
 }
 }  // namespace addhip

@@ -79,7 +79,7 @@ def make_task(task, dt, max_episode_length=None):
 
 # how addhip_gemm_f32 forms its products unless a descriptor says otherwise (agent.matmul_precision sets it)
 DEFAULT_PRECISION = L.PREC_F32
-PRECISIONS = {"fp32": L.PREC_F32, "f32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}
+PRECISIONS = {"fp32": L.PREC_F32, "f32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16x2": L.PREC_BF16X2, "bf16": L.PREC_BF16}
 
 
 def gemm(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, epilogue=L.EPI_NONE, bias=None, mask=None, ldmask=0, a_mean=None, a_std=None,

@@ -55,7 +55,8 @@ class ADDAgent:
         self._load_params(cfg)
         self.T = T = self._steps_per_iter
         # agent.matmul_precision: "fp32" (fp32 MFMA, default), "bf16x3" (exact 3-way bf16 split, fp32-level error, ~2.7x the
-        # MFMA rate) or "bf16"; operands, results and every other kernel stay fp32 (include/addhip.h: ADDHIP_PREC_*)
+        # MFMA rate), "bf16x2" (two leading chunks, TF32-class) or "bf16"; operands, results and every other kernel stay fp32
+        # (include/addhip.h: ADDHIP_PREC_*)
         prec = os.environ.get("ADDHIP_MATMUL_PRECISION") or str(cfg.get("matmul_precision", "fp32"))
         if prec not in H.PRECISIONS:
             raise ValueError(f"agent.matmul_precision must be one of {sorted(H.PRECISIONS)}")

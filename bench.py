@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement after the headline run")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x2", "bf16"],
                     help="agent.matmul_precision: how addhip_gemm_f32 forms its fp32 products (include/addhip.h ADDHIP_PREC_*)")
     return ap.parse_args()
 
@@ -81,7 +81,7 @@ def gemm_roofline(agent, precision):
         # PMC, profiles/r01_gemm_pmc.md: (WRITE_SIZE 1207.7 MB + 2 x FETCH_SIZE 2465.1 MB) / 30 launches of one optimiser step
         traffic = (1207.7e6 + 2 * 2465.1e6) / 30
     else:
-        products = 6 if precision == "bf16x3" else 1
+        products = {"bf16x3": 6, "bf16x2": 3, "bf16": 1}[precision]
         peak = MFMA_BF16_PEAK_TFLOPS / products
         kern = "gemm_split_kernel (v_mfma_f32_32x32x16_bf16 x %d per k-step; small shapes stay on gemm_kernel); all GEMM launches of one optimiser step" % products
         traffic = None
@@ -270,16 +270,24 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_envs, agent.T)
     if a.precision == "fp32" and not a.no_alt:
-        # Same workload with agent.matmul_precision=bf16x3 (exact 3-way bf16 split of every fp32 operand, six bf16 MFMAs per
-        # k-step, fp32 accumulate: fp32-level error bound, include/addhip.h ADDHIP_PREC_BF16X3).  Reported beside the
-        # headline, which stays on the fp32 MFMA instruction; every rank runs it (the gradient all-reduce needs them all).
+        # Same workload with the bf16-MFMA product modes of addhip_gemm_f32 (operands, results and every other kernel stay fp32;
+        # include/addhip.h ADDHIP_PREC_*), reported beside the headline, which stays on the fp32 MFMA instruction:
+        #   bf16x3 = exact 3-way bf16 split of every operand, six MFMAs per k-step, fp32-level error bound;
+        #   bf16x2 = the two leading chunks, three MFMAs, error 2^-15 |a||b| (the reference's GPU path runs TF32: 2^-11).
+        # Every rank runs them (the gradient all-reduce needs all ranks).
         del agent
-        agent2 = make_agent("bf16x3")
-        dt2 = timed(agent2)
+        alts = []
+        for prec, what in (("bf16x3", "6 bf16 MFMAs on an exact 3-way split (fp32-level error)"),
+                           ("bf16x2", "3 bf16 MFMAs on the two leading chunks (16 significant bits per operand; TF32-class, 64x less error than TF32)")):
+            agent2 = make_agent(prec)
+            dt2 = timed(agent2)
+            if rank == 0:
+                alts.append({"matmul_precision": prec, "value": env_steps / dt2, "unit": "env-steps/s", "ms_per_step": 1000.0 * dt2 / a.steps,
+                             "dtype": "f32 operands and results; products = " + what + ", fp32 accumulate",
+                             "roofline": gemm_roofline(agent2, prec)})
+            del agent2
         if rank == 0:
-            out["alt_precision"] = {"matmul_precision": "bf16x3", "value": env_steps / dt2, "unit": "env-steps/s", "ms_per_step": 1000.0 * dt2 / a.steps,
-                                    "dtype": "f32 operands and results; products = 6 bf16 MFMAs on an exact 3-way split, fp32 accumulate",
-                                    "roofline": gemm_roofline(agent2, "bf16x3")}
+            out["alt_precision"] = alts
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:

@@ -157,9 +157,10 @@ int addhip_kin_engine_step(float* sim_pose, float* sim_vel, const float* target,
 enum { ADDHIP_EPI_NONE = 0, ADDHIP_EPI_BIAS = 1, ADDHIP_EPI_BIAS_RELU = 2, ADDHIP_EPI_MASK = 3 };
 /* ADDHIP_PREC_F32: v_mfma_f32_32x32x2_f32.  ADDHIP_PREC_BF16X3: each fp32 operand split exactly into three bf16 chunks,
  * six bf16 MFMAs per k-step accumulated in fp32 (error bound 2^-23 |a||b| per product, i.e. fp32-level; the reference
- * itself runs its matmuls in TF32, main.py:16-18).  ADDHIP_PREC_BF16: operands truncated to bf16, fp32 accumulate.
+ * itself runs its matmuls in TF32, main.py:16-18).  ADDHIP_PREC_BF16X2: the two leading chunks only (16 significant bits per operand, three MFMAs per
+ * k-step: error bound 2^-15 |a||b|, 64x below TF32).  ADDHIP_PREC_BF16: operands truncated to bf16, fp32 accumulate.
  * The split paths are used for shapes that fill the chip with 128x128 tiles; other shapes always take the fp32 path. */
-enum { ADDHIP_PREC_F32 = 0, ADDHIP_PREC_BF16 = 1, ADDHIP_PREC_BF16X3 = 3 };
+enum { ADDHIP_PREC_F32 = 0, ADDHIP_PREC_BF16 = 1, ADDHIP_PREC_BF16X2 = 2, ADDHIP_PREC_BF16X3 = 3 };
 typedef struct {
   int32_t M, N, K;          /* C[M,N] = sum_k A(m,k) * B(n,k) */
   const float* A; int32_t lda; int32_t a_kcontig; /* 1: A[m*lda+k], 0: A[k*lda+m] */
