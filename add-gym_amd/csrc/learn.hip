@@ -395,12 +395,13 @@ __global__ __launch_bounds__(256) void critic_head_kernel(const float* H, int ld
     float v = wave_sum(acc) + b[0];
     float diff = tar[r] - v;  // ppo_agent.py:215-216
     float dv = loss_scale * 2.f * (v - tar[r]) / (float)M;
-    for (int k = lane * 4; k < K; k += 256) {
-      float4 h = *reinterpret_cast<const float4*>(H + (size_t)r * ld + k);
-      float4 ww = *reinterpret_cast<const float4*>(w + k);
-      float4 o = make_float4(h.x > 0.f ? dv * ww.x : 0.f, h.y > 0.f ? dv * ww.y : 0.f, h.z > 0.f ? dv * ww.z : 0.f, h.w > 0.f ? dv * ww.w : 0.f);
-      *reinterpret_cast<float4*>(dZ + (size_t)r * ld + k) = o;
-    }
+    if (dZ)  // (NULL: addhip_head_backward produces it together with the head's gradients)
+      for (int k = lane * 4; k < K; k += 256) {
+        float4 h = *reinterpret_cast<const float4*>(H + (size_t)r * ld + k);
+        float4 ww = *reinterpret_cast<const float4*>(w + k);
+        float4 o = make_float4(h.x > 0.f ? dv * ww.x : 0.f, h.y > 0.f ? dv * ww.y : 0.f, h.z > 0.f ? dv * ww.z : 0.f, h.w > 0.f ? dv * ww.w : 0.f);
+        *reinterpret_cast<float4*>(dZ + (size_t)r * ld + k) = o;
+      }
     if (lane == 0) { dv_out[r] = dv; se += diff * diff; }
   }
   float t = block_sum(se, sh);
@@ -452,6 +453,54 @@ __global__ void outer_mask_kernel(const float* v, const float* w, const float* H
     float4 o = make_float4(h.x > 0.f ? s * ww.x : 0.f, h.y > 0.f ? s * ww.y : 0.f, h.z > 0.f ? s * ww.z : 0.f, h.w > 0.f ? s * ww.w : 0.f);
     *reinterpret_cast<float4*>(out + r * ld + k) = o;
   }
+}
+
+// One pass over the last hidden layer's activations H for everything a scalar head needs in the backward direction:
+//   dZ[r,k]  = (H[r,k] > 0) ? v[r] * w[k] : 0        gradient w.r.t. the layer's pre-activation (what outer_mask writes)
+//   dW[k]   += sum_r v[r] * H[r,k]                    head weight gradient       (weighted_col_sum)
+//   db[0]   += sum_r v[r]                             head bias gradient         (col_sum of v)
+//   dbt[k]  += sum_r dZ[r,k]                          the layer's bias gradient  (col_sum of dZ)
+// A lane owns the same columns for every row its wave visits, so the column sums are per-lane registers; the four waves
+// of a workgroup are combined in LDS and each workgroup issues one atomic per column.  K <= 1024.
+__global__ __launch_bounds__(256) void head_backward_kernel(const float* v, const float* w, const float* H, int ld, int K, long long rows, float* dZ,
+                                                            float* dW, float* db, float* dbt) {
+  __shared__ float red[4][1024];
+  __shared__ float sh[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 gw[4], gb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) gw[j] = gb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sv = 0.f;
+  for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+    const float s = v[r];
+    if (lane == 0) sv += s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = lane * 4 + 256 * j;
+      if (k < K) {
+        const float4 h = *reinterpret_cast<const float4*>(H + r * ld + k);
+        const float4 ww = *reinterpret_cast<const float4*>(w + k);
+        const float4 o = make_float4(h.x > 0.f ? s * ww.x : 0.f, h.y > 0.f ? s * ww.y : 0.f, h.z > 0.f ? s * ww.z : 0.f, h.w > 0.f ? s * ww.w : 0.f);
+        if (dZ) *reinterpret_cast<float4*>(dZ + r * ld + k) = o;
+        gw[j].x += s * h.x; gw[j].y += s * h.y; gw[j].z += s * h.z; gw[j].w += s * h.w;
+        gb[j].x += o.x; gb[j].y += o.y; gb[j].z += o.z; gb[j].w += o.w;
+      }
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    float* out = pass == 0 ? dW : dbt;
+    if (!out) continue;  // uniform
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = lane * 4 + 256 * j;
+      if (k < K) *reinterpret_cast<float4*>(&red[wave][k]) = pass == 0 ? gw[j] : gb[j];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) atomicAdd(&out[k], red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+    __syncthreads();
+  }
+  const float t = block_sum(sv, sh);
+  if (threadIdx.x == 0 && db) atomicAdd(db, t);
 }
 
 __global__ __launch_bounds__(256) void grad_penalty_kernel(const float* g, int ld, int dim, int M, float coef, float* G, float* stats) {
@@ -656,15 +705,15 @@ extern "C" int addhip_actor_loss(const float* mean, const float* norm_action, co
                                  float stdv, float logp_const, float clip_ratio, float bound_weight, float loss_scale, const float* n_valid,
                                  float* d_mean, float* stats, void* stream) {
   ADDHIP_REQUIRE(mean && norm_action && old_logp && adv && rand_mask && n_valid && d_mean && stats && M > 0, "actor_loss: bad arguments");
-  hipLaunchKernelGGL(actor_loss_kernel, dim3(row_grid(M) < 1024 ? row_grid(M) : 1024), dim3(256), 0, ST, mean, norm_action, old_logp, adv, rand_mask, M,
+  hipLaunchKernelGGL(actor_loss_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, mean, norm_action, old_logp, adv, rand_mask, M,
                      stdv, logp_const, clip_ratio, bound_weight, loss_scale, n_valid, d_mean, stats);
   return addhip::check_launch("actor_loss_kernel");
 }
 
 extern "C" int addhip_critic_head(const float* H, int32_t ld, int32_t K, int32_t M, const float* w, const float* b, const float* tar, float loss_scale,
                                   float* dZ, float* dv_out, float* stats, void* stream) {
-  ADDHIP_REQUIRE(H && w && b && tar && dZ && dv_out && stats && M > 0 && K % 4 == 0 && ld % 4 == 0, "critic_head: bad arguments");
-  hipLaunchKernelGGL(critic_head_kernel, dim3(row_grid(M) < 1024 ? row_grid(M) : 1024), dim3(256), 0, ST, H, ld, K, M, w, b, tar, loss_scale, dZ,
+  ADDHIP_REQUIRE(H && w && b && tar && dv_out && stats && M > 0 && K % 4 == 0 && ld % 4 == 0, "critic_head: bad arguments");
+  hipLaunchKernelGGL(critic_head_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, H, ld, K, M, w, b, tar, loss_scale, dZ,
                      dv_out, stats);
   return addhip::check_launch("critic_head_kernel");
 }
@@ -672,7 +721,7 @@ extern "C" int addhip_critic_head(const float* H, int32_t ld, int32_t K, int32_t
 extern "C" int addhip_disc_head(const float* H, int32_t ld, int32_t K, int32_t M, const float* h_pos, const float* w, const float* b, float loss_scale,
                                 float* dlogit, float* dlogit_pos, float* stats, void* stream) {
   ADDHIP_REQUIRE(H && h_pos && w && b && dlogit && dlogit_pos && stats && M > 0 && K % 4 == 0 && ld % 4 == 0, "disc_head: bad arguments");
-  hipLaunchKernelGGL(disc_head_kernel, dim3(row_grid(M + 1) < 1024 ? row_grid(M + 1) : 1024), dim3(256), 0, ST, H, ld, K, M, h_pos, w, b, loss_scale,
+  hipLaunchKernelGGL(disc_head_kernel, dim3(row_grid(M + 1) < 256 ? row_grid(M + 1) : 256), dim3(256), 0, ST, H, ld, K, M, h_pos, w, b, loss_scale,
                      dlogit, dlogit_pos, stats);
   return addhip::check_launch("disc_head_kernel");
 }
@@ -688,9 +737,17 @@ extern "C" int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int
   return addhip::check_launch("outer_mask_kernel(bcast)");
 }
 
+extern "C" int addhip_head_backward(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* dZ, float* dW_head,
+                                    float* db_head, float* db_top, void* stream) {
+  ADDHIP_REQUIRE(v && w && H && rows > 0 && K > 0 && K <= 1024 && K % 4 == 0 && ld % 4 == 0 && ld >= K, "head_backward: bad arguments (K <= 1024)");
+  const int grid = row_grid(rows) < 256 ? row_grid(rows) : 256;
+  hipLaunchKernelGGL(head_backward_kernel, dim3(grid), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, dZ, dW_head, db_head, db_top);
+  return addhip::check_launch("head_backward_kernel");
+}
+
 extern "C" int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, float* stats, void* stream) {
   ADDHIP_REQUIRE(g && G && stats && M > 0 && dim <= ld, "grad_penalty: bad arguments");
-  hipLaunchKernelGGL(grad_penalty_kernel, dim3(row_grid(M) < 1024 ? row_grid(M) : 1024), dim3(256), 0, ST, g, ld, dim, M, coef, G, stats);
+  hipLaunchKernelGGL(grad_penalty_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, g, ld, dim, M, coef, G, stats);
   return addhip::check_launch("grad_penalty_kernel");
 }
 

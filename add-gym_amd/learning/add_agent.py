@@ -234,6 +234,8 @@ class ADDAgent:
         # ---- update step on one gathered minibatch (ppo_agent.py:194-275, add_agent.py:141-202)
         p = self._update_plan = Plan()
         ls_d = self._disc_loss_weight
+        # (the whole flat gradient is zeroed once per step, before the three sections fork: _run_update_sections; bias and head
+        # gradients are then accumulated by atomics from the kernels that already hold the data)
         # actor
         ra.forward(p, L.ptr(W["norm_obs"]), Mb)
         self._gemm(p, Mb, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
@@ -243,17 +245,18 @@ class ADDAgent:
         sA = 32
         self._gemm(p, 32, hA, Mb, L.ptr(W["d_mean"]), 32, 0, L.ptr(ra.h[-1]), hA, 0, L.ptr(self._slabs), hA, split_k=sA)
         p.add("addhip_slab_reduce", L.ptr(self._slabs), sA, 32 * hA, m.g("actor", "Wh"), 32 * hA, 1.0, 0)
-        p.add("addhip_col_sum", L.ptr(W["d_mean"]), Mb, 32, 32, m.g("actor", "bh"), 1.0, 0)
-        self._gemm(p, Mb, hA, 32, L.ptr(W["d_mean"]), 32, 1, m.p("actor", "Wh"), hA, 0, L.ptr(ra.dz[-1]), hA, L.EPI_MASK, mask=L.ptr(ra.h[-1]), ldmask=hA)
-        ra.backward(p, L.ptr(W["norm_obs"]), Mb)
+        p.add("addhip_col_sum", L.ptr(W["d_mean"]), Mb, 32, 32, m.g("actor", "bh"), 1.0, 1)
+        self._gemm(p, Mb, hA, 32, L.ptr(W["d_mean"]), 32, 1, m.p("actor", "Wh"), hA, 0, L.ptr(ra.dz[-1]), hA, L.EPI_MASK, mask=L.ptr(ra.h[-1]), ldmask=hA,
+                   colsum=m.g("actor", f"b{len(m.actor.hidden) - 1}"))
+        ra.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True)
         self._update_marks = [("actor", len(p.calls))]  # the net's gradient is complete after this many calls
         # critic
         rc.forward(p, L.ptr(W["norm_obs"]), Mb)
         p.add("addhip_critic_head", L.ptr(rc.h[-1]), hC, hC, Mb, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(W["mb_tar"]), self._critic_loss_weight,
-              L.ptr(rc.dz[-1]), L.ptr(W["dv"]), L.ptr(W["stats"]) + 4 * 8)
-        p.add("addhip_weighted_col_sum", L.ptr(W["dv"]), L.ptr(rc.h[-1]), hC, hC, Mb, m.g("critic", "Wh"), 1.0, 0)
-        p.add("addhip_col_sum", L.ptr(W["dv"]), Mb, 1, 1, m.g("critic", "bh"), 1.0, 0)
-        rc.backward(p, L.ptr(W["norm_obs"]), Mb)
+              None, L.ptr(W["dv"]), L.ptr(W["stats"]) + 4 * 8)
+        p.add("addhip_head_backward", L.ptr(W["dv"]), m.p("critic", "Wh"), L.ptr(rc.h[-1]), hC, hC, Mb, L.ptr(rc.dz[-1]), m.g("critic", "Wh"),
+              m.g("critic", "bh"), m.g("critic", f"b{len(m.critic.hidden) - 1}"))
+        rc.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True)
         self._update_marks.append(("critic", len(p.calls)))
         # discriminator: Mb agent/demo differences + one zero-difference row (row Mb of norm_diff stays 0)
         Md = Mb + 1
@@ -261,9 +264,8 @@ class ADDAgent:
         rd.forward(p, nd, Md)
         p.add("addhip_disc_head", L.ptr(rd.h[-1]), hD, hD, Mb, L.ptr(rd.h[-1]) + 4 * Mb * hD, m.p("disc", "Wh"), m.p("disc", "bh"), ls_d,
               L.ptr(W["dlogit"]), L.ptr(W["dlogit"]) + 4 * Mb, L.ptr(W["stats"]) + 4 * 12)
-        p.add("addhip_outer_mask", L.ptr(W["dlogit"]), m.p("disc", "Wh"), L.ptr(rd.h[-1]), hD, hD, Md, L.ptr(rd.dz[-1]))
-        p.add("addhip_weighted_col_sum", L.ptr(W["dlogit"]), L.ptr(rd.h[-1]), hD, hD, Md, m.g("disc", "Wh"), 1.0, 0)
-        p.add("addhip_col_sum", L.ptr(W["dlogit"]), Md, 1, 1, m.g("disc", "bh"), 1.0, 0)
+        p.add("addhip_head_backward", L.ptr(W["dlogit"]), m.p("disc", "Wh"), L.ptr(rd.h[-1]), hD, hD, Md, L.ptr(rd.dz[-1]), m.g("disc", "Wh"),
+              m.g("disc", "bh"), m.g("disc", f"b{len(m.disc.hidden) - 1}"))
         # gradient penalty chain (hand-derived double backward, add_agent.py:166-178): g = ((w3*m2) W2 * m1) W1
         h1, h2 = rd.h[0], rd.h[1] if len(rd.h) > 1 else None
         if len(m.disc.hidden) != 2:
@@ -277,7 +279,8 @@ class ADDAgent:
         self._gemm(p, Mb, d1, DS, L.ptr(W["G"]), DS, 1, m.p("disc", "W0"), DS, 1, L.ptr(W["e1"]), d1, L.EPI_MASK, mask=L.ptr(h1), ldmask=d1)
         self._gemm(p, Mb, d2, d1, L.ptr(W["e1"]), d1, 1, m.p("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, mask=L.ptr(h2), ldmask=d2)
         p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
-        rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1"]), d1, L.ptr(W["G"]), DS, Mb), 1: (L.ptr(W["a2"]), d2, L.ptr(W["e1"]), d1, Mb)})
+        rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1"]), d1, L.ptr(W["G"]), DS, Mb), 1: (L.ptr(W["a2"]), d2, L.ptr(W["e1"]), d1, Mb)},
+                    grads_zeroed=True, top_bias_done=True)
         # L2 terms (add_agent.py:161-164, 181-186): logit reg on the head weights, weight decay on all disc weights
         wd = self._disc_weight_decay
         p.add("addhip_l2_grad", m.p("disc", "W0"), m.g("disc", "W0"), m.n_elem("disc", "W0"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
@@ -484,6 +487,7 @@ class ADDAgent:
         m, plan = self._model, self._update_plan
         main = torch.cuda.current_stream()
         streams = [main] + self._side_streams
+        L.call("addhip_fill_zero", L.ptr(m.grads), m.count, main.cuda_stream)  # MPOptimizer.step's zero_grad (mp_optimizer.py:14-16)
         fork = torch.cuda.Event()
         fork.record(main)
         # stream-ordered asynchronous collectives are an nccl (RCCL) property; any other backend (gloo in rehearsals) gets one

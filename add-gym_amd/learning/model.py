@@ -224,9 +224,11 @@ class NetRunner:
                 plan.add("addhip_gemm_f32", g)
             prev, ld, k = L.ptr(self.h[i]), h, h
 
-    def backward(self, plan, x_ptr, rows, extra_dw=None):
+    def backward(self, plan, x_ptr, rows, extra_dw=None, grads_zeroed=False, top_bias_done=False):
         """dz[-1] must hold d loss / d (pre-activation of the last hidden layer).  extra_dw: {layer: (A_ptr, lda, B_ptr, ldb)}
-        second product accumulated into dW of that layer (the gradient-penalty terms)."""
+        second product accumulated into dW of that layer (the gradient-penalty terms).  grads_zeroed: the caller cleared the
+        whole gradient buffer at the start of the step (no per-bias memsets here); top_bias_done: the kernel that produced
+        dz[-1] also accumulated the top layer's bias gradient."""
         net, m = self.net, self.m
         n = len(net.hidden)
         for i in reversed(range(n)):
@@ -250,11 +252,12 @@ class NetRunner:
                 # every gradient of this net except W0 / b0 is final here (b1 came with the dX GEMM of layer 2, the head's
                 # with the loss kernels): an early bucket for the data-parallel exchange
                 self.early_mark = len(plan.calls)
-            if i == n - 1:  # the top layer's dz comes from the loss kernels; the others get their bias gradient from the
-                plan.add("addhip_col_sum", L.ptr(self.dz[i]), rows, out_d, out_d, m.g(net.name, f"b{i}"), 1.0, 0)  # dX GEMM below
+            if i == n - 1 and not top_bias_done:  # the top layer's dz comes from the loss kernels; the others get their bias
+                plan.add("addhip_col_sum", L.ptr(self.dz[i]), rows, out_d, out_d, m.g(net.name, f"b{i}"), 1.0, int(grads_zeroed))  # gradient from the dX GEMM below
             if i > 0:
                 prev_d = net.hidden[i - 1]
-                plan.add("addhip_fill_zero", m.g(net.name, f"b{i - 1}"), prev_d)
+                if not grads_zeroed:
+                    plan.add("addhip_fill_zero", m.g(net.name, f"b{i - 1}"), prev_d)
                 for r0, cnt in self._row_chunks(rows):
                     g3 = gemm(cnt, prev_d, out_d, L.ptr(self.dz[i]) + 4 * r0 * out_d, out_d, 1, m.p(net.name, f"W{i}"), prev_d, 0,
                               L.ptr(self.dz[i - 1]) + 4 * r0 * prev_d, prev_d, L.EPI_MASK, mask=L.ptr(self.h[i - 1]) + 4 * r0 * prev_d, ldmask=prev_d,

@@ -262,6 +262,7 @@ int addhip_actor_loss(const float* mean, const float* norm_action, const float* 
 int addhip_count_mask(const float* rand_mask, int32_t M, float* out, void* stream);
 /* PPOAgent._compute_critic_loss (ppo_agent.py:209-219): v = H.w+b; dv = scale*2(v-tar)/M;
  * dZ[m,:] = dv*w*(H>0) ; stats[0] += sum (tar-v)^2 ; dv_out for the dw/db reductions */
+/* (dZ may be NULL: addhip_head_backward then produces it together with the head's gradients) */
 int addhip_critic_head(const float* H, int32_t ld, int32_t K, int32_t M, const float* w, const float* b,
                        const float* tar, float loss_scale, float* dZ, float* dv_out, float* stats, void* stream);
 /* ADDAgent._compute_disc_loss head part (add_agent.py:141-202, amp_agent.py:177-192): logits, BCE(0.1) on the
@@ -269,6 +270,14 @@ int addhip_critic_head(const float* H, int32_t ld, int32_t K, int32_t M, const f
  * stats += {sum bce_neg, bce_pos, sum logit_neg, logit_pos, #neg<0, pos>0} */
 int addhip_disc_head(const float* H, int32_t ld, int32_t K, int32_t M, const float* h_pos, const float* w,
                      const float* b, float loss_scale, float* dlogit, float* dlogit_pos, float* stats, void* stream);
+/* Backward of a scalar head (critic value / discriminator logit) in one pass over the last hidden layer H [rows,ld]:
+ * dZ[r,k] = (H[r,k] > 0) ? v[r]*w[k] : 0 (the layer's pre-activation gradient; what addhip_outer_mask writes), and the
+ * column sums that autograd would produce for the head weight (sum_r v[r] H[r,k]), the head bias (sum_r v[r]) and the
+ * layer's bias (sum_r dZ[r,k]), ACCUMULATED by atomics into dW_head[K], db_head[1], db_top[K] (caller zeroes; any output
+ * may be NULL).  Replaces outer_mask + weighted_col_sum + 2 x col_sum and three of their four passes over H.  K <= 1024. */
+int addhip_head_backward(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows,
+                         float* dZ, float* dW_head, float* db_head, float* db_top, void* stream);
+
 /* out[m,k] = v[m] * w[k] * (H[m,k] > 0)    (back through a 1-wide head into the last hidden layer) */
 int addhip_outer_mask(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows,
                       float* out, void* stream);

@@ -79,6 +79,7 @@ def test_minibatch_loss_gradients_and_adamw_match_reference():
     m = ag._model
     for step in range(3):
         W["stats"].zero_()
+        m.grads.zero_()  # zero_grad: _run_update_sections does it before the sections fork
         ag._update_plan.run(st)
         torch.cuda.synchronize()
         grads_hip = {k: v.numpy() for k, v in m.export(m.grads).items() if k != "_model._action_dist._logstd_net"}

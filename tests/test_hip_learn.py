@@ -305,6 +305,23 @@ def test_critic_and_disc_heads_and_grad_penalty():
     L.call("addhip_outer_mask", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, L.ptr(out), L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), Ht.grad.numpy() * (H > 0), rtol=1e-4, atol=1e-9)
+    # the fused backward of a scalar head: same dZ, plus the head-weight / head-bias / layer-bias gradients, accumulated
+    out2 = torch.full((M + 1, K), 7.0, device="cuda")
+    gW, gb, gt_ = torch.full((K,), 0.25, device="cuda"), torch.full((1,), 0.25, device="cuda"), torch.full((K,), 0.25, device="cuda")
+    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, L.ptr(out2), L.ptr(gW), L.ptr(gb), L.ptr(gt_), L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+    dl64, H64, o64 = dl.cpu().numpy().astype(np.float64), H.astype(np.float64), out.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(gW.cpu().numpy() - 0.25, dl64 @ H64, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(gb.cpu().numpy() - 0.25, dl64.sum(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(gt_.cpu().numpy() - 0.25, o64.sum(0), rtol=1e-4, atol=1e-6)
+    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, None, None, None, None, L.current_stream())  # every output optional
+    # critic head without its dZ pass (dZ = NULL)
+    dv2, st4 = torch.zeros(M, device="cuda"), torch.zeros(4, device="cuda")
+    L.call("addhip_critic_head", L.ptr(dH), K, K, M, L.ptr(dw), L.ptr(db), P(T(tar)), 1.0, None, L.ptr(dv2), L.ptr(st4), L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dv2, dv)
+    np.testing.assert_allclose(st4.cpu().numpy()[0], st.cpu().numpy()[0], rtol=1e-5)  # atomics: summation order differs
     # gradient penalty (add_agent.py:166-178)
     g = np.zeros((M, 116), F)
     g[:, :114] = rng.standard_normal((M, 114)) * 0.1
