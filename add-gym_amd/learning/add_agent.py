@@ -233,7 +233,9 @@ class ADDAgent:
 
         # ---- update step on one gathered minibatch (ppo_agent.py:194-275, add_agent.py:141-202)
         p = self._update_plan = Plan()
-        ls_d = self._disc_loss_weight
+        # every loss coefficient carries 1/world: the all-reduce SUM of the gradients is then their mean over ranks
+        gs = 1.0 / self._world
+        ls_d = self._disc_loss_weight * gs
         # (the whole flat gradient is zeroed once per step, before the three sections fork: _run_update_sections; bias and head
         # gradients are then accumulated by atomics from the kernels that already hold the data)
         # actor
@@ -241,7 +243,7 @@ class ADDAgent:
         self._gemm(p, Mb, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
         p.add("addhip_count_mask", L.ptr(W["mb_mask"]), Mb, L.ptr(W["nv"]))
         p.add("addhip_actor_loss", L.ptr(W["mean"]), L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_mask"]), Mb, m.std32,
-              m.logp_const, self._ppo_clip_ratio, self._action_bound_weight, 1.0, L.ptr(W["nv"]), L.ptr(W["d_mean"]), L.ptr(W["stats"]))
+              m.logp_const, self._ppo_clip_ratio, self._action_bound_weight, gs, L.ptr(W["nv"]), L.ptr(W["d_mean"]), L.ptr(W["stats"]))
         sA = 32
         self._gemm(p, 32, hA, Mb, L.ptr(W["d_mean"]), 32, 0, L.ptr(ra.h[-1]), hA, 0, L.ptr(self._slabs), hA, split_k=sA)
         p.add("addhip_slab_reduce", L.ptr(self._slabs), sA, 32 * hA, m.g("actor", "Wh"), 32 * hA, 1.0, 0)
@@ -252,7 +254,7 @@ class ADDAgent:
         self._update_marks = [("actor", len(p.calls))]  # the net's gradient is complete after this many calls
         # critic
         rc.forward(p, L.ptr(W["norm_obs"]), Mb)
-        p.add("addhip_critic_head", L.ptr(rc.h[-1]), hC, hC, Mb, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(W["mb_tar"]), self._critic_loss_weight,
+        p.add("addhip_critic_head", L.ptr(rc.h[-1]), hC, hC, Mb, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(W["mb_tar"]), self._critic_loss_weight * gs,
               None, L.ptr(W["dv"]), L.ptr(W["stats"]) + 4 * 8)
         p.add("addhip_head_backward", L.ptr(W["dv"]), m.p("critic", "Wh"), L.ptr(rc.h[-1]), hC, hC, Mb, L.ptr(rc.dz[-1]), m.g("critic", "Wh"),
               m.g("critic", "bh"), m.g("critic", f"b{len(m.critic.hidden) - 1}"))
@@ -291,16 +293,10 @@ class ADDAgent:
         # Actor and critic hand over everything but their first layer as soon as it is final; the collectives are issued
         # in the order they become ready, because one communicator runs them in issue order.
         (_, end_a), (_, end_c), (_, end_d) = self._update_marks
-
-        def tail_range(net):  # [W1 .. end of net)
-            return m.offsets[(net, "W1")][0], m.net_ranges[net][1]
-
-        def head_range(net):  # [W0, b0]
-            return m.net_ranges[net][0], m.offsets[(net, "W1")][0]
-
         ea, ec = ra.early_mark, rc.early_mark
-        self._update_schedule = [(0, 0, ea, tail_range("actor")), (1, end_a, ec, tail_range("critic")), (2, end_c, end_d, m.net_ranges["disc"]),
-                                 (0, ea, end_a, head_range("actor")), (1, ec, end_c, head_range("critic"))]
+        br = m.bucket_ranges
+        self._update_schedule = [(0, 0, ea, br["actor_tail"]), (1, end_a, ec, br["critic_tail"]), (2, end_c, end_d, br["disc"]),
+                                 (0, ea, end_a, None), (1, ec, end_c, None)]  # the two first layers: one bucket after the join
 
         self._gather_c = L.GatherT(L.ptr(W["perm_idx"]), Mb, L.ptr(B["obs"]), OS, tk.obs_dim, L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(B["action"]),
                                    L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), L.ptr(B["a_logp"]), L.ptr(B["adv"]), L.ptr(B["tar_val"]), L.ptr(B["rand_mask"]),
@@ -498,21 +494,23 @@ class ADDAgent:
         pending = []
         for s in self._side_streams:
             s.wait_event(fork)
-        for si, first, last, (a, b) in self._update_schedule:
+        for si, first, last, bucket in self._update_schedule:
             s = streams[si]
             plan.run(s.cuda_stream, first, last)
-            if overlap:
+            if overlap and bucket is not None:
                 with torch.cuda.stream(s):
-                    pending.append(D.all_reduce_sum_async(m.grads[a:b]))
+                    pending.append(D.all_reduce_sum_async(m.grads[bucket[0]:bucket[1]]))
         for s in self._side_streams:
             done = torch.cuda.Event()
             done.record(s)
             main.wait_event(done)
+        # (every loss coefficient of the plan carries 1/world, so the SUM over ranks is already the mean: no scaling pass)
         if overlap:
+            a, b = m.bucket_ranges["first_layers"]
+            pending.append(D.all_reduce_sum_async(m.grads[a:b]))
             D.wait_all(pending)
-            m.grads.mul_(1.0 / self._world)
         elif exchange:
-            D.all_reduce_mean_(m.grads)
+            D.all_reduce_sum_(m.grads)
 
     def _need_normalizer_update(self):
         return self._sample_count < self._normalizer_samples

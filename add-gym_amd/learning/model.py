@@ -53,20 +53,28 @@ class Model:
         if model_cfg.get("actor_std_type", "FIXED") != "FIXED":
             raise NotImplementedError("only actor_std_type FIXED (configs/agent/add_g1.yaml) is implemented")
         self.init_output_scale = float(model_cfg["actor_init_output_scale"])
+        # Flat layout, chosen for the data-parallel exchange (each bucket one contiguous range, in the order the gradients
+        # become final during a backward pass): [actor W1.. head][critic W1.. head][discriminator][actor W0 b0][critic W0 b0]
         off = 0
         self.offsets = {}
-        for net in self.nets:
+
+        def place(net, keys):
+            nonlocal off
+            first = off
             for key, shape in net.specs:
-                n = math.prod(shape)
-                self.offsets[(net.name, key)] = (off, shape)
-                off += (n + 3) // 4 * 4
+                if key in keys:
+                    self.offsets[(net.name, key)] = (off, shape)
+                    off += (math.prod(shape) + 3) // 4 * 4
+            return first, off
+
+        first_layer = ("W0", "b0")
+        rest = lambda net: [k for k, _ in net.specs if k not in first_layer]
+        self.bucket_ranges = {"actor_tail": place(self.actor, rest(self.actor)), "critic_tail": place(self.critic, rest(self.critic)),
+                              "disc": place(self.disc, [k for k, _ in self.disc.specs])}
+        a0 = place(self.actor, first_layer)
+        c0 = place(self.critic, first_layer)
+        self.bucket_ranges["first_layers"] = (a0[0], c0[1])
         self.count = off
-        # contiguous [start, end) of each net in the flat buffers (gradient buckets of the data-parallel exchange)
-        self.net_ranges = {}
-        for net in self.nets:
-            first = self.offsets[(net.name, net.specs[0][0])][0]
-            last_off, last_shape = self.offsets[(net.name, net.specs[-1][0])]
-            self.net_ranges[net.name] = (first, last_off + (math.prod(last_shape) + 3) // 4 * 4)
         self.params = torch.zeros(off, device=device)
         self.grads = torch.zeros(off, device=device)
         self.exp_avg = torch.zeros(off, device=device)
