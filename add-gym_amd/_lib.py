@@ -103,6 +103,7 @@ SIGNATURES = {
     "addhip_grad_penalty": [vp, i32, i32, i32, f32, vp, vp, vp],
     "addhip_weighted_col_sum": [vp, vp, i32, i32, i64, vp, f32, i32, vp],
     "addhip_l2_grad": [vp, vp, i64, f32, vp, vp],
+    "addhip_grad_clip": [vp, i64, f32, vp, vp, vp],
     "addhip_adamw": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
     "addhip_return_tracker_fold": [vp, i32, vp, vp],
 }

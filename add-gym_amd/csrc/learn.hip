@@ -561,6 +561,28 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long 
   }
 }
 
+// torch.nn.utils.clip_grad_norm_ (mp_optimizer.py:45-46): total 2-norm over the whole flat gradient, then
+// grad *= min(1, max_norm / (norm + 1e-6)).  scratch[0] receives the sum of squares (double), scratch[1] the norm (stats).
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* g, long long n, double* scratch) {
+  __shared__ double shd[4];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float x = g[i];
+    s += (double)x * x;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&scratch[0], shd[0] + shd[1] + shd[2] + shd[3]);
+}
+__global__ void grad_scale_kernel(float* g, long long n, float max_norm, const double* scratch, float* norm_out) {
+  const float norm = (float)sqrt(scratch[0]);
+  const float coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+  if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
+  if (coef >= 1.0f) return;  // uniform
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) g[i] *= coef;
+}
+
 __global__ void return_tracker_fold_kernel(const float* ep, int T, float* state) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float episodes = state[0], mret = state[1], mlen = state[2];
@@ -780,6 +802,18 @@ extern "C" int addhip_adamw(float* param, const float* grad, float* exp_avg, flo
   hipLaunchKernelGGL(adamw_kernel, dim3(elem_grid(count)), dim3(256), 0, ST, param, grad, exp_avg, exp_avg_sq, (long long)count, lr, beta1, beta2, eps,
                      weight_decay, step_size, bc2_sqrt);
   return addhip::check_launch("adamw_kernel");
+}
+
+extern "C" int addhip_grad_clip(float* grad, int64_t count, float max_norm, float* scratch, float* norm_out, void* stream) {
+  ADDHIP_REQUIRE(grad && scratch && count > 0 && max_norm > 0.0f, "grad_clip: bad arguments");
+  ADDHIP_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7u) == 0, "grad_clip: scratch must be 8-byte aligned");
+  double* sc = reinterpret_cast<double*>(scratch);
+  ADDHIP_HIP(hipMemsetAsync(sc, 0, sizeof(double), ST));
+  const int grid = elem_grid(count) < 1024 ? elem_grid(count) : 1024;
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(grid), dim3(256), 0, ST, grad, (long long)count, sc);
+  if (int rc = addhip::check_launch("grad_sumsq_kernel")) return rc;
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(elem_grid(count)), dim3(256), 0, ST, grad, (long long)count, max_norm, sc, norm_out);
+  return addhip::check_launch("grad_scale_kernel");
 }
 
 extern "C" int addhip_return_tracker_fold(const float* ep_stats, int32_t T, float* state, void* stream) {

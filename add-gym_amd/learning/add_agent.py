@@ -135,8 +135,7 @@ class ADDAgent:
             raise NotImplementedError("optimizer.type must be 'Adam' (-> AdamW like the reference's MPOptimizer)")
         self._lr = float(opt["learning_rate"])
         self._wd = float(opt.get("weight_decay", 0.0))
-        if float(opt.get("grad_clip", 0.0)) > 0:
-            raise NotImplementedError("optimizer.grad_clip > 0 is not implemented (the reference's default config never enables it)")
+        self._grad_clip = float(opt.get("grad_clip", 0.0))  # mp_optimizer.py:10, 42-46 (0 = off: the reference's default)
         if self._distributed:  # DDP ctor behaviour: every rank starts from rank 0's weights (base_agent.py:50-57)
             D.broadcast_(self._model.params, 0)
 
@@ -468,6 +467,8 @@ class ADDAgent:
                 self._next_minibatch_indices()
                 L.call("addhip_gather_minibatch", self._gather_c, st)
                 self._run_update_sections()
+                if self._grad_clip > 0.0:
+                    L.call("addhip_grad_clip", L.ptr(m.grads), m.count, self._grad_clip, L.ptr(W["scratch"]), None, st)
                 m.opt_step += 1
                 L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, self._lr, 0.9, 0.999, 1e-8,
                        self._wd, m.opt_step, st)

@@ -291,6 +291,11 @@ int addhip_weighted_col_sum(const float* v, const float* X, int32_t ld, int32_t 
 /* grad[i] += coef * w[i]  (2*lambda*W terms: disc_logit_reg, disc_weight_decay) ; stats_out += sum w^2 (optional) */
 int addhip_l2_grad(const float* w, float* grad, int64_t count, float coef, float* sumsq_out, void* stream);
 
+/* MPOptimizer._clip_grads (mp_optimizer.py:45-46) = torch.nn.utils.clip_grad_norm_ over the whole flat gradient:
+ * grad *= min(1, max_norm / (||grad||_2 + 1e-6)).  scratch: >= 2 floats, 8-byte aligned (device); norm_out[0] (or NULL)
+ * receives the unclipped norm. */
+int addhip_grad_clip(float* grad, int64_t count, float max_norm, float* scratch, float* norm_out, void* stream);
+
 /* torch.optim.AdamW step on a flat buffer (mp_optimizer.py:14-40; lr, betas (0.9,0.999), eps 1e-8) */
 int addhip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);

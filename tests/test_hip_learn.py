@@ -379,3 +379,22 @@ def test_philox_fills_and_return_tracker():
     m1 = (3 / 5) * 2.0 + (2 / 5) * 1.5
     m2 = (1 / 6) * 2.0 + (5 / 6) * m1
     np.testing.assert_allclose(state.cpu().numpy(), [6.0, m2, (1 / 6) * 8 + (5 / 6) * ((3 / 5) * 10 + (2 / 5) * 12)], rtol=1e-6)
+
+
+def test_grad_clip_matches_torch_clip_grad_norm():
+    """MPOptimizer._clip_grads (mp_optimizer.py:45-46)."""
+    import torch
+    import add_gym_amd._lib as L
+
+    rng = np.random.default_rng(11)
+    g = rng.standard_normal(100003).astype(F) * 0.01
+    for max_norm in (0.5, 100.0):  # clipping / not clipping
+        t = torch.tensor(g, requires_grad=True)
+        t.grad = torch.tensor(g)
+        want_norm = float(torch.nn.utils.clip_grad_norm_([t], max_norm))
+        d = T(g)
+        scratch, norm = torch.zeros(4, device="cuda"), torch.zeros(1, device="cuda")
+        L.call("addhip_grad_clip", L.ptr(d), g.size, max_norm, L.ptr(scratch), L.ptr(norm), L.current_stream())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(norm.item(), want_norm, rtol=1e-6)
+        np.testing.assert_allclose(d.cpu().numpy(), t.grad.numpy(), rtol=2e-6, atol=0)
