@@ -80,7 +80,7 @@ SIGNATURES = {
     "addhip_gemm_f32": [P(GemmT), vp],
     "addhip_slab_reduce": [vp, i32, i64, vp, i64, f32, i32, vp],
     "addhip_col_sum": [vp, i32, i32, i32, vp, f32, i32, vp],
-    "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp],
+    "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp],
     "addhip_fill_normal": [vp, i64, u64, u64, vp],
     "addhip_fill_uniform": [vp, i64, u64, u64, vp],
     "addhip_fill_zero": [vp, i64, vp],

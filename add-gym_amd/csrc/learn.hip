@@ -76,10 +76,12 @@ __global__ void fill_normal_kernel(float* out, long long n, uint64_t seed, uint6
 
 // ------------------------------------------------------------------ rollout actor head
 __global__ __launch_bounds__(256) void actor_sample_kernel(const float* mean, int ldm, const float* noise, float stdv, float logp_const,
-                                                           const float* a_mean, const float* a_std, int n, int deterministic,
-                                                           float* action, float* a_logp, float* rand_mask) {
+                                                           const float* a_mean, const float* a_std, int n, int deterministic_all,
+                                                           const float* explore_u, float exp_prob, float* action, float* a_logp, float* rand_mask) {
   const int lane = threadIdx.x & 63;
   for (int env = blockIdx.x * 4 + (threadIdx.x >> 6); env < n; env += gridDim.x * 4) {
+    // rand_action_mask = bernoulli(exp_prob) per env (ppo_agent.py:80-88): a uniform draw below the probability explores
+    const bool deterministic = deterministic_all || (explore_u && !(explore_u[env] < exp_prob));
     float sq = 0.f, act = 0.f;
     if (lane < ADDHIP_NUM_DOF) {
       float mu = mean[(size_t)env * ldm + lane];
@@ -375,8 +377,8 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, cons
     }
   }
   float t0 = block_sum(st_min, sh), t1 = block_sum(st_clip, sh), t2 = block_sum(st_ratio, sh), t3 = block_sum(st_bound, sh);
-  if (threadIdx.x == 0) {
-    atomicAdd(&stats[0], t0); atomicAdd(&stats[1], t1); atomicAdd(&stats[2], t2); atomicAdd(&stats[3], t3);
+  if (threadIdx.x == 0) {  // per-minibatch MEANS over the exploring samples (ppo_agent.py:229-247): nv varies with exp_prob < 1
+    atomicAdd(&stats[0], t0 / nv); atomicAdd(&stats[1], t1 / nv); atomicAdd(&stats[2], t2 / nv); atomicAdd(&stats[3], t3 / nv);
   }
 }
 
@@ -616,12 +618,12 @@ extern "C" int addhip_fill_uniform(float* out, int64_t count, uint64_t seed, uin
 }
 
 extern "C" int addhip_actor_sample(const float* mean, int32_t ld_mean, const float* noise, float stdv, float logp_const, const float* a_mean,
-                                   const float* a_std, int32_t num_envs, int32_t deterministic, float* action, float* a_logp, float* rand_mask,
-                                   void* stream) {
+                                   const float* a_std, int32_t num_envs, int32_t deterministic, const float* explore_u, float exp_prob, float* action,
+                                   float* a_logp, float* rand_mask, void* stream) {
   ADDHIP_REQUIRE(mean && a_mean && a_std && action && a_logp && rand_mask && num_envs > 0, "actor_sample: bad arguments");
   ADDHIP_REQUIRE(deterministic || noise, "actor_sample: noise missing");
   hipLaunchKernelGGL(actor_sample_kernel, dim3(row_grid(num_envs)), dim3(256), 0, ST, mean, ld_mean, noise, stdv, logp_const, a_mean, a_std,
-                     num_envs, deterministic, action, a_logp, rand_mask);
+                     num_envs, deterministic, explore_u, exp_prob, action, a_logp, rand_mask);
   return addhip::check_launch("actor_sample_kernel");
 }
 

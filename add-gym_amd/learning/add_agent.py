@@ -167,8 +167,9 @@ class ADDAgent:
         if float(c["action_entropy_weight"]) != 0 or float(c["action_reg_weight"]) != 0:
             raise NotImplementedError("action_entropy_weight / action_reg_weight != 0 are not implemented (add_g1.yaml sets both to 0)")
         self._critic_loss_weight = float(c["critic_loss_weight"])
-        if float(c.get("exp_prob_beg", 1.0)) != 1.0 or float(c.get("exp_prob_end", 1.0)) != 1.0:
-            raise NotImplementedError("exploration-probability annealing is not implemented (defaults: always explore)")
+        self._exp_anneal_samples = float(c.get("exp_anneal_samples", float("inf")))  # ppo_agent.py:32-34
+        self._exp_prob_beg = float(c.get("exp_prob_beg", 1.0))
+        self._exp_prob_end = float(c.get("exp_prob_end", 1.0))
         self._disc_loss_weight = float(c["disc_loss_weight"])
         self._disc_logit_reg = float(c["disc_logit_reg"])
         self._disc_grad_penalty = float(c["disc_grad_penalty"])
@@ -201,7 +202,7 @@ class ADDAgent:
         self._side_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         OS, DS = self._task.obs_stride, self._task.disc_stride
         hd = m.disc.hidden
-        self._W = dict(mean=z(rows, 32), d_mean=z(rows, 32), noise=z(N, L.NUM_DOF), u=z(3, N), logits=z(rows), nv=z(1),
+        self._W = dict(mean=z(rows, 32), d_mean=z(rows, 32), noise=z(N, L.NUM_DOF), explore_u=z(N), u=z(3, N), logits=z(rows), nv=z(1),
                        norm_obs=z(Mb, OS), norm_act=z(Mb, 32), mb_logp=z(Mb), mb_adv=z(Mb), mb_tar=z(Mb), mb_mask=z(Mb), norm_diff=z(rows + 1, DS),
                        dv=z(Mb), dlogit=z(Mb + 1), a2=z(Mb, hd[-1]), a1=z(Mb, hd[0]), g=z(Mb, DS), G=z(Mb, DS), e1=z(Mb, hd[0]), da2=z(Mb, hd[-1]),
                        stats=z(32), scratch=z(4096, dt=torch.float64), adv_stats=z(2), rstats=z(2), perm_idx=z(Mb, dt=torch.int64))
@@ -360,8 +361,24 @@ class ADDAgent:
             W["noise"].copy_(self.inject["noise"][t])
         elif not deterministic:
             L.call("addhip_fill_normal", L.ptr(W["noise"]), self.N * L.NUM_DOF, self._seed, (1 << 40) + self._iter * self.T + t, st)
+        explore_u, exp_prob = None, 1.0
+        if not deterministic:
+            exp_prob = self._get_exp_prob()
+            if exp_prob < 1.0:  # rand_action_mask = bernoulli(exp_prob) (ppo_agent.py:80-88)
+                if self.inject is not None and "explore_u" in self.inject:
+                    W["explore_u"].copy_(self.inject["explore_u"][t])
+                else:
+                    L.call("addhip_fill_uniform", L.ptr(W["explore_u"]), self.N, self._seed, (3 << 40) + self._iter * self.T + t, st)
+                explore_u = L.ptr(W["explore_u"])
         L.call("addhip_actor_sample", L.ptr(W["mean"]), 32, L.ptr(W["noise"]), m.std32, m.logp_const, L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), self.N,
-               int(deterministic), L.ptr(B["action"][slot_t]), L.ptr(B["a_logp"][slot_t]), L.ptr(B["rand_mask"][slot_t]), st)
+               int(deterministic), explore_u, exp_prob, L.ptr(B["action"][slot_t]), L.ptr(B["a_logp"][slot_t]), L.ptr(B["rand_mask"][slot_t]), st)
+
+    def _get_exp_prob(self):
+        """ppo_agent.py:161-168."""
+        if math.isfinite(self._exp_anneal_samples):
+            l = min(max(float(self._sample_count) / self._exp_anneal_samples, 0.0), 1.0)
+            return (1.0 - l) * self._exp_prob_beg + l * self._exp_prob_end
+        return self._exp_prob_beg
 
     def _step_env(self, slot_t, out_c, env_c):
         """Environment.step (env.py:150-155) then the fused HIP env step."""
@@ -557,8 +574,7 @@ class ADDAgent:
         rs = W["rstats"].double().cpu().numpy()
         trk = self._train_state.cpu().numpy()
         Mb, M1 = float(self.Mb), float(self.Mb)
-        nvalid = Mb  # rand_action_mask is 1 everywhere (exp_prob = 1)
-        actor_min, clipf, ratio, bound = -s[0] / nvalid, s[1] / nvalid, s[2] / nvalid, s[3] / nvalid
+        actor_min, clipf, ratio, bound = -s[0], s[1], s[2], s[3]  # already per-minibatch means over the exploring samples
         actor_loss = actor_min + self._action_bound_weight * bound
         critic_loss = s[8] / Mb
         bce_neg, bce_pos = s[12] / M1, s[13]
@@ -672,7 +688,7 @@ class ADDAgent:
         lg.log("Train_Episodes", ti.pop("num_eps"), collection="1_Info", quiet=True)
         for k, v in ti.items():
             lg.log(k.title(), v)
-        lg.log("Exp_Prob", 1.0)
+        lg.log("Exp_Prob", self._get_exp_prob())
 
     def state_dict(self):
         Nm, tk = self._Nrm, self._task

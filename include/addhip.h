@@ -186,11 +186,14 @@ int addhip_col_sum(const float* X, int32_t M, int32_t N, int32_t ld, float* out,
                    int32_t accumulate, void* stream);
 
 /* ---- rollout actor head: DistributionGaussianDiag.sample/log_prob (distribution_gaussian_diag.py:84-94)
- *      + Normalizer.unnormalize (normalizer.py:112-114) + exp-buffer record (ppo_agent.py:72-109) ---- */
+ *      + Normalizer.unnormalize (normalizer.py:112-114) + exp-buffer record (ppo_agent.py:72-109).
+ *      deterministic != 0: mode for every env (test mode).  Otherwise, with explore_u [N] uniforms in [0,1) (or NULL =
+ *      always explore): env n samples iff explore_u[n] < exp_prob, else takes the mode and gets rand_mask 0
+ *      (rand_action_mask = bernoulli(exp_prob), ppo_agent.py:80-88, 161-168) ---- */
 int addhip_actor_sample(const float* mean, int32_t ld_mean, const float* noise /*[N,29] N(0,1)*/, float std,
                         float logp_const /* fl32(-0.5*29*log(2pi)) - sum(logstd) */, const float* a_mean, const float* a_std, int32_t num_envs,
-                        int32_t deterministic, float* action /*[N,32]*/, float* a_logp, float* rand_mask,
-                        void* stream);
+                        int32_t deterministic, const float* explore_u, float exp_prob, float* action /*[N,32]*/, float* a_logp,
+                        float* rand_mask, void* stream);
 
 /* counter-based Philox4x32-10 fills (stateless: element i of call (seed,stream_id) is fixed) */
 int addhip_fill_normal(float* out, int64_t count, uint64_t seed, uint64_t stream_id, void* stream_);

@@ -55,12 +55,24 @@ def test_actor_sample_matches_reference_golden():
     act = torch.zeros(n, 32, device="cuda")
     logp = torch.zeros(n, device="cuda")
     mask = torch.zeros(n, device="cuda")
-    L.call("addhip_actor_sample", P(T(mean32)), 32, P(T(g["noise"])), std, c, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0,
+    L.call("addhip_actor_sample", P(T(mean32)), 32, P(T(g["noise"])), std, c, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0, None, 1.0,
            L.ptr(act), L.ptr(logp), L.ptr(mask), L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(act.cpu().numpy()[:, :29], g["action"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(logp.cpu().numpy(), g["a_logp"], rtol=1e-5, atol=1e-4)
     assert np.all(mask.cpu().numpy() == 1) and np.all(act.cpu().numpy()[:, 29:] == 0)
+    # exploration probability < 1 (ppo_agent.py:80-88): env i explores iff u[i] < p, else it takes the mode with mask 0
+    u = np.random.default_rng(3).random(n).astype(F)
+    act2, logp2, mask2 = torch.zeros(n, 32, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    L.call("addhip_actor_sample", P(T(mean32)), 32, P(T(g["noise"])), std, c, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0, P(T(u)), 0.5,
+           L.ptr(act2), L.ptr(logp2), L.ptr(mask2), L.current_stream())
+    torch.cuda.synchronize()
+    ex = u < 0.5
+    assert 0 < ex.sum() < n and np.array_equal(mask2.cpu().numpy(), ex.astype(F))
+    assert torch.equal(act2[T(ex)], act[T(ex)]) and torch.equal(logp2[T(ex)], logp[T(ex)])
+    mode = (mean * g["a_std"] + g["a_mean"]).astype(F)
+    np.testing.assert_allclose(act2.cpu().numpy()[~ex][:, :29], mode[~ex], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(logp2.cpu().numpy()[~ex], c, rtol=1e-6)  # log-density at the mode
 
 
 def test_td_lambda_adv_matches_reference_golden():
@@ -256,11 +268,11 @@ def test_actor_loss_head_gradient():
     g = mt.grad.numpy()
     np.testing.assert_allclose(dm.cpu().numpy()[:, :29], g, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(g).max())
     s = stats.cpu().numpy()
-    nvf = mask.sum()
-    np.testing.assert_allclose(-s[0] / nvf, loss.item(), rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(s[3] / nvf, bound.item(), rtol=1e-4, atol=1e-7)
-    np.testing.assert_allclose(s[2] / nvf, ratio.mean().item(), rtol=1e-4)
-    np.testing.assert_allclose(s[1] / nvf, (torch.abs(ratio - 1) > 0.2).float().mean().item(), atol=2.0 / nvf)
+    nvf = mask.sum()  # the statistics are means over the exploring samples already
+    np.testing.assert_allclose(-s[0], loss.item(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(s[3], bound.item(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(s[2], ratio.mean().item(), rtol=1e-4)
+    np.testing.assert_allclose(s[1], (torch.abs(ratio - 1) > 0.2).float().mean().item(), atol=2.0 / nvf)
 
 
 def test_critic_and_disc_heads_and_grad_penalty():
