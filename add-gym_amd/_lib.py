@@ -37,7 +37,7 @@ class TaskT(C.Structure):
 
 class EnvT(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("sim_pose", f32p), ("sim_vel", f32p), ("time", f32p), ("time_off", f32p), ("motion_id", f32p),
-                ("hist", f32p), ("hist_vel", f32p), ("done", f32p), ("contact", f32p), ("ref_pose", f32p), ("ref_vel", f32p), ("ret_acc", f32p), ("len_acc", f32p)]
+                ("hist", f32p), ("hist_vel", f32p), ("done", f32p), ("contact", f32p), ("ref_pose", f32p), ("ref_vel", f32p), ("ret_acc", f32p), ("len_acc", f32p), ("dof_err_w", f32p)]
 
 
 class StepOutT(C.Structure):

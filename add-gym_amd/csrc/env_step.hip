@@ -310,7 +310,7 @@ struct StepArgs {
   Tables tb;
   const float* sim_pose; const float* sim_vel; float* time; const float* time_off; const int* motion_id; float* hist; float* hist_vel;
   const float* clip_len; const int* clip_loop;
-  int* done; const unsigned char* contact; float* ret_acc; int* len_acc;
+  int* done; const unsigned char* contact; float* ret_acc; int* len_acc; const float* dof_err_w;
   float* ref_pose; float* ref_vel;
   float* obs; float* obs2; float* obs_timeout; float* disc; float* demo;
   float* reward; int* done_rec; int* motion_id_rec; float* motion_time_rec; float* ep_stats;
@@ -324,7 +324,7 @@ struct StepArgs {
 // tracker): its ~300 instructions are paid once per group instead of once per env, and its loads / stores of the
 // per-env scalars are coalesced.
 constexpr int SLOT_MAX = 16, SLOT_W = 33;  // odd stride: conflict-free lane-per-slot reads
-enum { S_PE = 26, S_VE = 27, S_TIME = 28, S_TM = 29, S_ID = 30 };
+enum { S_PE = 26, S_VE = 27, S_TIME = 28, S_TM = 29, S_ID = 30, S_PEU = 31 };  // PE/VE: weighted sums (reward); PEU: unweighted pose sum (done)
 
 // LDS source of root value j (0..25) in the staged rows
 __device__ __forceinline__ int root_src(int j) {
@@ -347,7 +347,7 @@ __device__ __forceinline__ unsigned long long reward_done_group(const addhip_tas
   const int id = __float_as_int(rt[S_ID]);
   const float clip_len = a.clip_len[id];
   const int clip_loop = a.clip_loop[id];
-  const float pe = rt[S_PE], ve = rt[S_VE], time_new = rt[S_TIME], tm = rt[S_TM];
+  const float pe = rt[S_PE], ve = rt[S_VE], pe_unweighted = rt[S_PEU], time_new = rt[S_TIME], tm = rt[S_TM];
   const float dx = rt[7] - rt[0], dy = rt[8] - rt[1], dz = rt[9] - rt[2];
   Quat q_sim{rt[3], rt[4], rt[5], rt[6]}, q_ref{rt[10], rt[11], rt[12], rt[13]};
   Vec3 v_sim{rt[14], rt[15], rt[16]}, w_sim{rt[17], rt[18], rt[19]}, v_ref{rt[20], rt[21], rt[22]}, w_ref{rt[23], rt[24], rt[25]};
@@ -375,7 +375,7 @@ __device__ __forceinline__ unsigned long long reward_done_group(const addhip_tas
   if (t.enable_early_termination) {
     bool failed = contact;
     if (t.pose_termination) {
-      bool pose_fail = (pe / (float)ADDHIP_NUM_DOF) > t.pose_termination_dist;
+      bool pose_fail = (pe_unweighted / (float)ADDHIP_NUM_DOF) > t.pose_termination_dist;  // add_done.py:129-132: plain mean
       if (track_root) pose_fail = pose_fail || (root_err_full > t.pose_termination_dist);
       failed = failed || pose_fail;
     }
@@ -431,6 +431,7 @@ __global__ __launch_bounds__(64 * WAVES) void env_step_kernel(addhip_task_t t, S
   const int dof_a = lane < 32 ? row_off(R_REF, 7 + (dof_lane ? hl : 0)) : row_off(R_REFV, 6 + (dof_lane ? hl : 0));
   const int dof_b = lane < 32 ? row_off(R_SIM, 7 + (dof_lane ? hl : 0)) : row_off(R_SIMV, 6 + (dof_lane ? hl : 0));
   const int root_off = root_src(lane < 26 ? lane : 0);
+  const float dof_w = (a.dof_err_w && dof_lane) ? a.dof_err_w[hl] : 1.0f;  // add_reward.py:28-52 (joint weights, per dof)
   __syncthreads();  // maps; from here on the waves of a workgroup run independently
   // a wave owns ONE group of envs_per_wave consecutive envs (no outer loop: the scalar phase after the env loop then
   // starts from an empty register file instead of having its constants hoisted across the loop)
@@ -469,12 +470,13 @@ __global__ __launch_bounds__(64 * WAVES) void env_step_kernel(addhip_task_t t, S
       derive<GLOBAL, VEL, PHASE>(t, w, lane, phase);
       {  // reward inputs of this env -> slot k
         float* sl = slots + k * SLOT_W;
-        float sq = 0.0f;
-        if (dof_lane) { const float d = w[dof_a] - w[dof_b]; sq = d * d; }  // joint weights are all 1 (add_reward.py:31-34)
+        float squ = 0.0f;
+        if (dof_lane) { const float d = w[dof_a] - w[dof_b]; squ = d * d; }
+        float sq = squ * dof_w;
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        for (int o = 16; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); squ += __shfl_xor(squ, o, 64); }
         if (lane < 26) sl[lane] = w[root_off];
-        if (lane == 0) { sl[S_PE] = sq; sl[S_TIME] = time_new; sl[S_TM] = tm; sl[S_ID] = __int_as_float(id); }
+        if (lane == 0) { sl[S_PE] = sq; sl[S_PEU] = squ; sl[S_TIME] = time_new; sl[S_TM] = tm; sl[S_ID] = __int_as_float(id); }
         if (lane == 32) sl[S_VE] = sq;
       }
       wave_sync();
@@ -702,7 +704,7 @@ extern "C" int addhip_env_step(const addhip_motion_t* m, const addhip_task_t* t,
   int epw = e->num_envs / 8192;
   epw = epw < 1 ? 1 : (epw > SLOT_MAX ? SLOT_MAX : epw);
   StepArgs a{tables_of(m), e->sim_pose, e->sim_vel, e->time, e->time_off, e->motion_id, e->hist, e->hist_vel, m->clip_len, m->clip_loop,
-             e->done, e->contact, e->ret_acc, e->len_acc, e->ref_pose, e->ref_vel, o->obs, o->obs_next_in, o->obs_timeout, o->disc_obs, o->disc_demo,
+             e->done, e->contact, e->ret_acc, e->len_acc, e->dof_err_w, e->ref_pose, e->ref_vel, o->obs, o->obs_next_in, o->obs_timeout, o->disc_obs, o->disc_demo,
              o->reward, o->done, o->motion_id_rec, o->motion_time_rec, o->ep_stats, e->num_envs, head, epw};
   const int groups = (e->num_envs + epw - 1) / epw;
   const int blocks = (groups + WAVES - 1) / WAVES;

@@ -42,8 +42,8 @@ def check_supported(task):
     if len(task.get("tar_obs_steps", [1])) > L.MAX_TAR:
         raise NotImplementedError(f"at most {L.MAX_TAR} target steps")
     jw = task.get("joint_err_w", None)
-    if jw is not None and any(float(w) != 1.0 for w in jw):
-        raise NotImplementedError("task.joint_err_w other than all-ones is not implemented")
+    if jw is not None and len(jw) != L.NUM_DOF:
+        raise NotImplementedError("task.joint_err_w must list one weight per joint (29 one-dof joints for G1)")
 
 
 def make_task(task, dt, max_episode_length=None):

@@ -105,10 +105,12 @@ class ADDAgent:
                            hist=z(N, L.HIST, L.POSE_W), hist_vel=z(N, L.HIST, L.POSE_W) if tk.enable_vel_obs else None, done=z(N, dt=torch.int32),
                            ref_pose=None, ref_vel=None,  # optional outputs of the step kernel (gathered reference rows); not needed here
                            ret_acc=z(N), len_acc=z(N, dt=torch.int32), ret_acc_test=z(N), len_acc_test=z(N, dt=torch.int32))
+        jw = task.get("joint_err_w", None)  # add_reward.py:24-52: per joint in kinematic-tree order; every G1 joint has one dof
+        S["dof_err_w"] = None if jw is None else torch.tensor([float(w) for w in jw], dtype=torch.float32, device=dev)
         self._env_c = L.EnvT(N, *[L.ptr(S[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "hist_vel", "done", "contact",
-                                                         "ref_pose", "ref_vel", "ret_acc", "len_acc")])
+                                                         "ref_pose", "ref_vel", "ret_acc", "len_acc", "dof_err_w")])
         self._env_c_test = L.EnvT(N, *[L.ptr(S[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "hist_vel", "done", "contact",
-                                                              "ref_pose", "ref_vel", "ret_acc_test", "len_acc_test")])
+                                                              "ref_pose", "ref_vel", "ret_acc_test", "len_acc_test", "dof_err_w")])
         self._head = 0  # ring slot that receives the next state (circular_buffer.py:8)
 
         # ---- experience buffer (experience_buffer.py; 13 buffers of base/ppo/amp/add agents), obs has T+1 slots

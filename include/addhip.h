@@ -88,6 +88,8 @@ typedef struct {
   /* return tracker (base_agent.py:564-621) */
   float* ret_acc;       /* [N] */
   int32_t* len_acc;     /* [N] */
+  const float* dof_err_w; /* [29] per-dof weights of the reward's pose / velocity error sums (task.joint_err_w expanded to
+                             dofs, add_reward.py:28-52) or NULL = all ones; the done flags use the unweighted mean */
 } addhip_env_t;
 
 /* outputs of one env step; any pointer may be NULL to skip that output */

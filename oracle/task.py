@@ -34,6 +34,7 @@ class TaskCfg:
         self.reward_root_pose_w, self.reward_root_vel_w = 0.15, 0.1
         self.reward_pose_scale, self.reward_vel_scale = 0.25, 0.01
         self.reward_root_pose_scale, self.reward_root_vel_scale = 5.0, 1.0
+        self.dof_err_w = None  # add_reward.py:28-52: per-dof weights of the pose / velocity error sums (None = all ones)
         for k, v in kw.items():
             assert hasattr(self, k), k
             setattr(self, k, v)
@@ -302,7 +303,7 @@ class TaskState:
         self.update_ref()
         self.hist_push(sim)
         obs, d_obs, d_demo = self.compute_obs(sim)
-        r = reward(self.cfg, sim, self.ref)
+        r = reward(self.cfg, sim, self.ref, self.cfg.dof_err_w)
         self.done = done_flags(self.cfg, self.time, self.motion_times(), self.lib.lengths[self.motion_ids],
                                self.lib.loop_modes[self.motion_ids], sim[0], sim[4], self.ref[0], self.ref[4], contact)
         return obs, d_obs, d_demo, r, self.done.copy()

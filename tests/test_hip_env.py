@@ -32,14 +32,15 @@ def T(x, dtype=None):
     return torch.tensor(np.ascontiguousarray(x), dtype=dtype, device="cuda")
 
 
-def make_env(L, n, pose, vel, time, off, ids, hist, contact=None, hist_vel=None):
+def make_env(L, n, pose, vel, time, off, ids, hist, contact=None, hist_vel=None, dof_err_w=None):
     import torch
 
     st = dict(sim_pose=T(pose), sim_vel=T(vel), time=T(time, torch.float32), time_off=T(off, torch.float32), motion_id=T(ids, torch.int32),
               hist=T(hist), hist_vel=None if hist_vel is None else T(hist_vel), done=torch.zeros(n, dtype=torch.int32, device="cuda"),
               contact=None if contact is None else T(contact.astype(np.uint8)), ref_pose=torch.zeros(n, 36, device="cuda"),
-              ref_vel=torch.zeros(n, 36, device="cuda"), ret_acc=torch.zeros(n, device="cuda"), len_acc=torch.zeros(n, dtype=torch.int32, device="cuda"))
-    c = L.EnvT(n, *[L.ptr(st[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "hist_vel", "done", "contact", "ref_pose", "ref_vel", "ret_acc", "len_acc")])
+              ref_vel=torch.zeros(n, 36, device="cuda"), ret_acc=torch.zeros(n, device="cuda"), len_acc=torch.zeros(n, dtype=torch.int32, device="cuda"),
+              dof_err_w=None if dof_err_w is None else T(dof_err_w))
+    c = L.EnvT(n, *[L.ptr(st[k]) for k in ("sim_pose", "sim_vel", "time", "time_off", "motion_id", "hist", "hist_vel", "done", "contact", "ref_pose", "ref_vel", "ret_acc", "len_acc", "dof_err_w")])
     return st, c
 
 
@@ -69,14 +70,15 @@ VARIANTS = {"default": {}, "local": dict(global_obs=False), "noheight": dict(roo
             "local_vel": dict(global_obs=False, enable_vel_obs=True)}
 
 
-@pytest.mark.parametrize("vname", list(VARIANTS))
+@pytest.mark.parametrize("vname", list(VARIANTS) + ["joint_w"])
 def test_env_step_matches_reference(vname):
     import torch
     import add_gym_amd._lib as L
     from add_gym_amd.hotpath import make_task
 
-    v = variant(gload("obs_reward_done"), vname)
-    task = make_task({**DEFAULT_TASK, **VARIANTS[vname]}, 0.01)
+    # "joint_w": non-uniform task.joint_err_w (add_reward.py:24-52), its own fixture; same states as "default"
+    v = variant(gload("obs_reward_done_jw" if vname == "joint_w" else "obs_reward_done"), vname)
+    task = make_task({**DEFAULT_TASK, **VARIANTS.get(vname, {})}, 0.01)
     mot = HipMotion()
     n = v["time"].shape[0]
     pose = pack_pose(v["root_pos"], v["root_rot"], v["dof_pos"])
@@ -84,7 +86,7 @@ def test_env_step_matches_reference(vname):
     head = int(v["hist_head"])
     with_vel = bool(task.enable_vel_obs)
     st, env = make_env(L, n, pose, vel, v["time"], v["time_off"], v["motion_ids"], fixture_hist(v), v["contact"],
-                       fixture_hist_vel(v) if with_vel else None)
+                       fixture_hist_vel(v) if with_vel else None, v["dof_err_w"] if vname == "joint_w" else None)
     o, out = make_out(L, n, task)
     L.call("addhip_env_step", mot.c, task, env, out, head, L.current_stream())
     torch.cuda.synchronize()

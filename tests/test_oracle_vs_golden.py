@@ -159,6 +159,22 @@ def test_obs_reward_done(vname):
         assert set(np.unique(done)) == {0, 1, 2, 3}  # every flag occurs
 
 
+def test_obs_reward_done_joint_error_weights():
+    """task.joint_err_w (add_reward.py:24-52): weighted pose / velocity error sums in the reward; the done flags keep the
+    unweighted mean (add_done.py:129-132)."""
+    v = variant(gload("obs_reward_done_jw"), "joint_w")
+    cfg = T.TaskCfg(dof_err_w=v["dof_err_w"])
+    lib = oracle_lib(golden_tables=True)
+    n = v["time"].shape[0]
+    ts = _task_from_fixture(v, cfg, lib, n)
+    obs, d_obs, d_demo, r, done = ts.step(tuple(v[k] for k in FIELDS), v["contact"])
+    close(obs, v["obs"], atol=3e-6)
+    close(r, v["reward"], atol=3e-6)
+    assert np.array_equal(done, v["done"])
+    base = variant(gload("obs_reward_done"), "default")
+    assert np.array_equal(v["done"], base["done"]) and np.abs(v["reward"] - base["reward"]).max() > 1e-3  # same states, other reward
+
+
 @pytest.mark.parametrize("tag", ["one", "two"])
 def test_reset(tag):
     v = variant(gload("reset"), tag)

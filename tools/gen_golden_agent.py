@@ -118,8 +118,18 @@ def hist_arrays(obs):
 
 
 # ------------------------------------------------------------------------------------
-def gen_obs_reward_done():
-    variants = {
+# joint_err_w (add_reward.py:24-52): one weight per joint in kinematic-tree order (all 29 G1 joints are 1-dof)
+JOINT_ERR_W = [0.5, 0.5, 2.0, 1.0, 1.0, 2.0, 1.5, 1.5, 0.25, 3.0, 3.0, 1.0, 0.75, 0.75, 1.0, 0.1, 0.1, 1.0, 2.5, 2.5, 1.0, 1.0, 1.0, 0.3, 0.3, 0.3,
+               0.3, 0.0, 0.0]
+
+
+def gen_obs_reward_done_jw():
+    """A separate fixture (the first one stays byte-identical): non-uniform joint error weights."""
+    gen_obs_reward_done({"joint_w": dict(joint_err_w=JOINT_ERR_W)}, "obs_reward_done_jw")
+
+
+def gen_obs_reward_done(variants=None, name="obs_reward_done"):
+    variants = variants or {
         "default": {},
         "local": dict(global_obs=False),
         "noheight": dict(root_height_obs=False),
@@ -167,7 +177,9 @@ def gen_obs_reward_done():
         for k, v in {**pre, **post, **res}.items():
             out[f"{vname}.{k}"] = v
         out[f"{vname}.noncontact_ids"] = ag._add_done._noncontact_body_ids
-    _save("obs_reward_done", **out)
+        if "joint_err_w" in over:
+            out[f"{vname}.dof_err_w"] = ag._add_reward._dof_err_w.clone()
+    _save(name, **out)
 
 
 def gen_reset():
@@ -424,5 +436,5 @@ def gen_loop_1iter():
     _save("loop_1iter", **out)
 
 
-AGENT_GENS = dict(obs_reward_done=gen_obs_reward_done, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
+AGENT_GENS = dict(obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
                   td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
