@@ -188,11 +188,14 @@ class MotionLib:
         L.call("addhip_motion_lookup", self.c_struct, L.ptr(ids32), L.ptr(t32), n, L.ptr(idx), None, None, L.current_stream())
         return idx
 
-    def get_precomputed_motion_step(self, motion_ids, motion_times):
-        """(root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel) like motion_lib.py:322-335."""
+    def get_precomputed_motion_step(self, motion_ids, motion_times, packed=False):
+        """(root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel) like motion_lib.py:322-335; packed=True returns
+        the two [n,36] rows (pose = pos3|quat4|dof29, vel = vel3|ang3|dofvel29|0) instead of the six views."""
         n = motion_ids.shape[0]
         pose = torch.empty(n, L.POSE_W, device=self._device)
         vel = torch.empty(n, L.POSE_W, device=self._device)
         ids32, t32 = motion_ids.to(torch.int32).contiguous(), motion_times.to(torch.float32).contiguous()
         L.call("addhip_motion_lookup", self.c_struct, L.ptr(ids32), L.ptr(t32), n, None, L.ptr(pose), L.ptr(vel), L.current_stream())
+        if packed:
+            return pose, vel
         return pose[:, 0:3], pose[:, 3:7], vel[:, 0:3], vel[:, 3:6], pose[:, 7:], vel[:, 6:35]
