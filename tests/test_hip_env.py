@@ -55,6 +55,45 @@ def make_out(L, n, task):
     return o, c
 
 
+@pytest.mark.parametrize("n_big,vname", [(16384 + 37, "default"), (65536 + 5, "default"), (270000, "default"), (32768 + 3, "vel_phase")])
+def test_env_step_grouped_path_is_identical_to_one_env_per_wave(n_big, vname):
+    """From 16 384 envs on, a wave owns a GROUP of 2-16 consecutive envs (rows of the next env prefetched, reward inputs
+    parked per slot, one lane per env for the scalar phase; ragged last group).  Tiling the 32 golden envs to a ragged
+    large count must reproduce, env by env and bit for bit, what the one-env-per-wave launch gives for the 32."""
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import make_task
+
+    v = variant(gload("obs_reward_done"), vname)
+    task = make_task({**DEFAULT_TASK, **VARIANTS[vname]}, 0.01)
+    mot = HipMotion()
+    n = v["time"].shape[0]
+    pose = pack_pose(v["root_pos"], v["root_rot"], v["dof_pos"])
+    vel = pack_vel(v["root_vel"], v["root_ang_vel"], v["dof_vel"])
+    head = int(v["hist_head"])
+    with_vel = bool(task.enable_vel_obs)
+    hv = fixture_hist_vel(v) if with_vel else None
+    idx = np.arange(n_big) % n
+
+    def run(sel):
+        st, env = make_env(L, len(sel), pose[sel], vel[sel], v["time"][sel], v["time_off"][sel], v["motion_ids"][sel], fixture_hist(v)[sel],
+                           v["contact"][sel], None if hv is None else hv[sel])
+        o, out = make_out(L, len(sel), task)
+        L.call("addhip_env_step", mot.c, task, env, out, head, L.current_stream())
+        torch.cuda.synchronize()
+        return st, o
+
+    st0, o0 = run(np.arange(n))
+    st1, o1 = run(idx)
+    sel = torch.tensor(idx, device="cuda")
+    for k in ("obs", "disc", "demo", "reward", "done", "mid", "mtime", "tmo"):
+        assert torch.equal(o1[k], o0[k][sel]), k
+    for k in ("time", "done", "hist", "ref_pose", "ref_vel", "ret_acc", "len_acc") + (("hist_vel",) if with_vel else ()):
+        assert torch.equal(st1[k], st0[k][sel]), k
+    fin = (v["done"] != 0)[idx]
+    assert float(o1["ep"][2]) == fin.sum()
+
+
 def fixture_hist(v, prefix=""):
     return np.concatenate([v[prefix + "hist_root_pos"], v[prefix + "hist_root_rot"], v[prefix + "hist_dof_pos"]], axis=-1).astype(F)
 
