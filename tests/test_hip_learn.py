@@ -410,3 +410,45 @@ def test_grad_clip_matches_torch_clip_grad_norm():
         torch.cuda.synchronize()
         np.testing.assert_allclose(norm.item(), want_norm, rtol=1e-6)
         np.testing.assert_allclose(d.cpu().numpy(), t.grad.numpy(), rtol=2e-6, atol=0)
+
+
+def test_full_size_td_lambda_and_flat_optimiser():
+    """BASELINE configs[1] sizes (T=32, N=4096 envs; 4.35 M parameters): TD(lambda) against the oracle recurrence on random
+    rewards / values / done flags, and the flat AdamW against torch.optim.AdamW over three steps."""
+    import torch
+    import add_gym_amd._lib as L
+    from oracle import learn as OL
+
+    rng = np.random.default_rng(17)
+    Tn, n = 32, 4096
+    r = rng.standard_normal((Tn, n)).astype(F)
+    vals_all = rng.standard_normal((Tn + 1, n)).astype(F)
+    done = rng.choice([0, 0, 0, 0, 0, 0, 1, 2], size=(Tn, n)).astype(np.int32)
+    mask = (rng.random((Tn, n)) < 0.9).astype(F)
+    nxt = vals_all[1:].copy()
+    nxt[(done == 1) | (done == 2)] = 0.0
+    want = OL.td_lambda_return(r, nxt, done, 0.99, 0.95)
+    va = T(vals_all)
+    tar, adv = torch.zeros(Tn, n, device="cuda"), torch.zeros(Tn, n, device="cuda")
+    scratch, stats = torch.zeros(4096, dtype=torch.float64, device="cuda"), torch.zeros(2, device="cuda")
+    L.call("addhip_td_lambda_adv", P(T(r)), L.ptr(va[1:]), None, L.ptr(va), P(T(done, torch.int32)), P(T(mask)), Tn, n, 0.99, 0.95, 0.0, 0.0, 4.0,
+           L.ptr(tar), L.ptr(adv), L.ptr(scratch), L.ptr(stats), L.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(tar.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    a = (want - vals_all[:-1])[mask == 1]
+    np.testing.assert_allclose(stats.cpu().numpy(), [a.mean(dtype=np.float64), a.std(ddof=1, dtype=np.float64)], rtol=1e-4, atol=1e-6)
+    norm = np.clip((want - vals_all[:-1] - stats[0].item()) / max(stats[1].item(), 1e-5), -4.0, 4.0)
+    np.testing.assert_allclose(adv.cpu().numpy(), norm, rtol=1e-4, atol=1e-4)
+
+    count = 4349983 + 1361  # parameters + layout padding
+    p0 = (rng.standard_normal(count) * 0.05).astype(F)
+    p = torch.nn.Parameter(torch.tensor(p0))
+    opt = torch.optim.AdamW([p], 1e-4, weight_decay=0.0)
+    dp, m, v = T(p0), torch.zeros(count, device="cuda"), torch.zeros(count, device="cuda")
+    for step in range(1, 4):
+        g = (rng.standard_normal(count) * 1e-3).astype(F)
+        p.grad = torch.tensor(g)
+        opt.step()
+        L.call("addhip_adamw", L.ptr(dp), P(T(g)), L.ptr(m), L.ptr(v), count, 1e-4, 0.9, 0.999, 1e-8, 0.0, step, L.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dp.cpu().numpy(), p.detach().numpy(), rtol=1e-6, atol=1e-8)
