@@ -158,8 +158,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
   constexpr int DEPTH = 4;
   float4 ra[DEPTH][2], rb[DEPTH][2];
   const int nkf = kend > kbeg ? (kend - kbeg) / BK : 0;  // whole stages
-  if (nk == 0) return;  // (K range of this split-K slice is empty: cannot happen for the slab counts the host picks)
-  if (NORM) {
+  // (nk == 0: the K range of this split-K slice is empty -- more slices than 16-deep stages; its slab is all zeros, written
+  //  by the epilogue below like any other)
+  if (NORM && nk > 0) {
     for (int i = threadIdx.x; i < kend - kbeg; i += 256) { nmean[i] = g.a_mean[kbeg + i]; nstd[i] = g.a_std[kbeg + i]; }
     __syncthreads();
   }
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
     }
     lds_barrier();
   };
-  if (nkf > 0) {
+  if (nkf > 0) {  // (nkf > 0 implies nk > 0: the clamp min(kt, nk - 1) in fetch is then in range)
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) fetch(d, ra[d], rb[d]);
 #pragma unroll

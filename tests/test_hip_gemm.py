@@ -105,6 +105,9 @@ def test_gemm_split_bf16_paths(a_kc, b_kc, precision):
     plain bf16 within the bf16 bound; ragged M/N/K edges, every layout, split-K, every epilogue."""
     run_gemm(16384 + (0 if not a_kc else 1), 1024, 264, a_kc, b_kc, precision=precision)
     run_gemm(4100, 1024, 1024 + 4, a_kc, b_kc, precision=precision)
+    run_gemm(16384, 128, 512, a_kc, b_kc, precision=precision)  # 128 tiles: half a chip, still on the bf16-MFMA path
+    if not a_kc and not b_kc:
+        run_gemm(32, 512, 256, 0, 0, split_k=32, precision=precision)  # more split-K slices than 16-deep stages: empty slabs are zeros
     if not a_kc and not b_kc:
         run_gemm(1024, 264, 16385, 0, 0, split_k=22, precision=precision)
         run_gemm(1024, 1024, 16384, 0, 0, split_k=8, precision=precision)
