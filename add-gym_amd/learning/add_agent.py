@@ -405,11 +405,11 @@ class ADDAgent:
             self._reset_envs(False, B["obs"][t + 1], B["disc_obs"][t + 1], B["disc_demo"][t + 1], (self._iter * T + t) * 2 + 1)
         self._total_samples += T * self.N
 
-    def _forward_rows(self, runner, src, rows, normalize):
+    def _forward_rows(self, runner, src, rows, normalize, stream=None):
         p = Plan()
         Nm = self._Nrm
         runner.forward(p, src, rows, a_mean=L.ptr(Nm["obs_mean"]) if normalize else None, a_std=L.ptr(Nm["obs_std"]) if normalize else None)
-        p.run(self._stream())
+        p.run(self._stream() if stream is None else stream)
 
     def _build_train_data(self):
         """add_agent.py:110-139 then ppo_agent.py:111-159."""
@@ -421,6 +421,26 @@ class ADDAgent:
         chunk = self._eval_rows
         hD, hC = m.disc.hidden[-1], m.critic.hidden[-1]
         record = self._need_normalizer_update()
+        # the critic pass (side stream) and the discriminator pass (this stream) are independent until TD(lambda)
+        main, side = torch.cuda.current_stream(), self._side_streams[0]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        side.wait_event(fork)
+        cs = side.cuda_stream
+
+        # One critic pass over the T+1 obs slots gives V(obs[t]) and, shifted by one slot, V(next_obs[t]) = V(obs[t+1]) for
+        # every sample whose env was not reset (the reference evaluates next_obs separately, ppo_agent.py:117-126; the
+        # rows are identical, so are the values).  Reset envs: SUCC/FAIL take the terminal values, TIME takes V of the
+        # pre-reset row the step kernel parked in obs_timeout.
+        def critic_rows(src, dst, total):
+            for r0 in range(0, total, chunk):
+                rows = min(chunk, total - r0)
+                self._forward_rows(self._run_critic, src + 4 * r0 * tk.obs_stride, rows, True, cs)
+                L.call("addhip_head_gemv", L.ptr(self._run_critic.h[-1]), hC, hC, rows, m.p("critic", "Wh"), m.p("critic", "bh"), dst + 4 * r0, cs)
+        critic_rows(L.ptr(B["obs"]), L.ptr(B["vals"]), (T + 1) * N)
+        critic_rows(L.ptr(B["obs_timeout"]), L.ptr(B["timeout_vals"]), N)
+        joined = torch.cuda.Event()
+        joined.record(side)
         for r0 in range(0, rows_total, chunk):
             rows = min(chunk, rows_total - r0)
             do = L.ptr(B["disc_obs"]) + 4 * r0 * tk.disc_stride
@@ -432,17 +452,7 @@ class ADDAgent:
             L.call("addhip_head_gemv", L.ptr(self._run_disc.h[-1]), hD, hD, rows, m.p("disc", "Wh"), m.p("disc", "bh"), L.ptr(W["logits"]), st)
             L.call("addhip_disc_reward", L.ptr(W["logits"]), L.ptr(B["reward"]) + 4 * r0, rows, self._disc_reward_scale, self._task_reward_weight,
                    self._disc_reward_weight, L.ptr(W["rstats"]), st)
-        # One critic pass over the T+1 obs slots gives V(obs[t]) and, shifted by one slot, V(next_obs[t]) = V(obs[t+1]) for
-        # every sample whose env was not reset (the reference evaluates next_obs separately, ppo_agent.py:117-126; the
-        # rows are identical, so are the values).  Reset envs: SUCC/FAIL take the terminal values, TIME takes V of the
-        # pre-reset row the step kernel parked in obs_timeout.
-        def critic_rows(src, dst, total):
-            for r0 in range(0, total, chunk):
-                rows = min(chunk, total - r0)
-                self._forward_rows(self._run_critic, src + 4 * r0 * tk.obs_stride, rows, True)
-                L.call("addhip_head_gemv", L.ptr(self._run_critic.h[-1]), hC, hC, rows, m.p("critic", "Wh"), m.p("critic", "bh"), dst + 4 * r0, st)
-        critic_rows(L.ptr(B["obs"]), L.ptr(B["vals"]), (T + 1) * N)
-        critic_rows(L.ptr(B["obs_timeout"]), L.ptr(B["timeout_vals"]), N)
+        main.wait_event(joined)
         W["norm_diff"][:self.Mb + 1].zero_()  # row Mb must stay the zero-difference sample for the update plan
         L.call("addhip_sampler_update", self._smp_c, self._num_clips, st)
         succ = self._env.get_reward_succ() / (1.0 - self._discount)  # base_agent.py:472-480
