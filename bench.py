@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=256)
+    ap.add_argument("--cpu-envs", type=int, default=1536, help="envs of the CPU-oracle sample (one iteration; about 10 s of host time)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement after the headline run")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x2", "bf16"],
                     help="agent.matmul_precision: how addhip_gemm_f32 forms its fp32 products (include/addhip.h ADDHIP_PREC_*)")
