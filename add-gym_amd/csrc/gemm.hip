@@ -197,11 +197,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
       const int rbase = m0 + wm0 + a * 32 + 4 * lh;
       float mk[16];
       float cs = 0.f;  // MASK: column sum of this lane's 16 stored values (bias gradient)
+      // word of the ReLU sign bits this lane's 32-column group lives in (relu_bits / mask_bits)
+      const int cgroup = n0 + wn0 + b * 32;
       if (epi == ADDHIP_EPI_MASK) {  // all 16 mask loads in flight before any use
+        if (g.mask_bits) {  // 1 bit per element: the 32 lanes of a half read the same word
 #pragma unroll
-        for (int x = 0; x < 16; ++x) {
-          const int row = rbase + (x & 3) + 8 * (x >> 2);
-          mk[x] = (col_ok && row < g.M) ? g.mask[(size_t)row * g.ldmask + col] : 0.f;
+          for (int x = 0; x < 16; ++x) {
+            const int row = rbase + (x & 3) + 8 * (x >> 2);
+            const unsigned wbits = (cgroup < g.N && row < g.M) ? g.mask_bits[(size_t)row * g.ldbits + (cgroup >> 5)] : 0u;
+            mk[x] = ((wbits >> li) & 1u) ? 1.f : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int x = 0; x < 16; ++x) {
+            const int row = rbase + (x & 3) + 8 * (x >> 2);
+            mk[x] = (col_ok && row < g.M) ? g.mask[(size_t)row * g.ldmask + col] : 0.f;
+          }
         }
       }
 #pragma unroll
@@ -213,6 +224,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
         if (col_ok && row < g.M) {
           C[(size_t)row * g.ldc + col] = v;
           if (epi == ADDHIP_EPI_MASK) cs += v;
+        }
+        if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {  // uniform branch; lanes 0-31 hold one row, lanes 32-63 the row 4 below
+          const unsigned long long pos = __ballot(col_ok && row < g.M && v > 0.f);
+          if (li == 0 && row < g.M && cgroup < g.N) g.relu_bits[(size_t)row * g.ldbits + (cgroup >> 5)] = lh ? (unsigned)(pos >> 32) : (unsigned)pos;
         }
       }
       if (epi == ADDHIP_EPI_MASK && g.colsum) {
@@ -381,7 +396,10 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   else ADDHIP_REQUIRE(g.N % 4 == 0, "gemm: N must be a multiple of 4 for an n-contiguous B");
   ADDHIP_REQUIRE(g.epilogue >= ADDHIP_EPI_NONE && g.epilogue <= ADDHIP_EPI_MASK, "gemm: bad epilogue");
   if (g.epilogue == ADDHIP_EPI_BIAS || g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_REQUIRE(g.bias, "gemm: bias missing");
-  if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_REQUIRE(g.mask, "gemm: mask missing");
+  if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_REQUIRE(g.mask || g.mask_bits, "gemm: mask missing");
+  if (g.mask_bits) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && g.M > SMALL_M && g.ldbits * 32 >= g.N, "gemm: mask_bits need the MASK epilogue, M > 8 and ldbits >= ceil(N/32)");
+  if (g.relu_bits) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_BIAS_RELU && g.M > SMALL_M && g.ldbits * 32 >= g.N && g.split_k <= 1,
+                                  "gemm: relu_bits need the BIAS_RELU epilogue, M > 8 and ldbits >= ceil(N/32)");
   if (g.split_k > 1) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_NONE, "gemm: split-K slabs take no epilogue");
   if (g.a_mean || g.a_std) ADDHIP_REQUIRE(g.a_kcontig && g.a_mean && g.a_std, "gemm: fused normalisation needs a k-contiguous A and both mean/std");
   if (g.colsum) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && g.split_k <= 1, "gemm: colsum needs the MASK epilogue");

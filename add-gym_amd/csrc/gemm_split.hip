@@ -281,11 +281,22 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
       const int rbase = m0 + wm0 + a * 32 + 4 * lh;
       float mk[16];
       float cs = 0.f;
-      if (epi == ADDHIP_EPI_MASK) {
+      // word of the ReLU sign bits this lane's 32-column group lives in (relu_bits / mask_bits)
+      const int cgroup = n0 + wn0 + b * 32;
+      if (epi == ADDHIP_EPI_MASK) {  // all 16 mask loads in flight before any use
+        if (g.mask_bits) {  // 1 bit per element: the 32 lanes of a half read the same word
 #pragma unroll
-        for (int x = 0; x < 16; ++x) {
-          const int row = rbase + (x & 3) + 8 * (x >> 2);
-          mk[x] = (col_ok && row < g.M) ? g.mask[(size_t)row * g.ldmask + col] : 0.f;
+          for (int x = 0; x < 16; ++x) {
+            const int row = rbase + (x & 3) + 8 * (x >> 2);
+            const unsigned wbits = (cgroup < g.N && row < g.M) ? g.mask_bits[(size_t)row * g.ldbits + (cgroup >> 5)] : 0u;
+            mk[x] = ((wbits >> li) & 1u) ? 1.f : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int x = 0; x < 16; ++x) {
+            const int row = rbase + (x & 3) + 8 * (x >> 2);
+            mk[x] = (col_ok && row < g.M) ? g.mask[(size_t)row * g.ldmask + col] : 0.f;
+          }
         }
       }
 #pragma unroll
@@ -297,6 +308,10 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
         if (col_ok && row < g.M) {
           C[(size_t)row * g.ldc + col] = v;
           if (epi == ADDHIP_EPI_MASK) cs += v;
+        }
+        if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {  // uniform branch; lanes 0-31 hold one row, lanes 32-63 the row 4 below
+          const unsigned long long pos = __ballot(col_ok && row < g.M && v > 0.f);
+          if (li == 0 && row < g.M && cgroup < g.N) g.relu_bits[(size_t)row * g.ldbits + (cgroup >> 5)] = lh ? (unsigned)(pos >> 32) : (unsigned)pos;
         }
       }
       if (epi == ADDHIP_EPI_MASK && g.colsum) {

@@ -241,7 +241,7 @@ class ADDAgent:
         # (the whole flat gradient is zeroed once per step, before the three sections fork: _run_update_sections; bias and head
         # gradients are then accumulated by atomics from the kernels that already hold the data)
         # actor
-        ra.forward(p, L.ptr(W["norm_obs"]), Mb)
+        ra.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True)
         self._gemm(p, Mb, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
         p.add("addhip_count_mask", L.ptr(W["mb_mask"]), Mb, L.ptr(W["nv"]))
         p.add("addhip_actor_loss", L.ptr(W["mean"]), L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_mask"]), Mb, m.std32,
@@ -250,12 +250,12 @@ class ADDAgent:
         self._gemm(p, 32, hA, Mb, L.ptr(W["d_mean"]), 32, 0, L.ptr(ra.h[-1]), hA, 0, L.ptr(self._slabs), hA, split_k=sA)
         p.add("addhip_slab_reduce", L.ptr(self._slabs), sA, 32 * hA, m.g("actor", "Wh"), 32 * hA, 1.0, 0)
         p.add("addhip_col_sum", L.ptr(W["d_mean"]), Mb, 32, 32, m.g("actor", "bh"), 1.0, 1)
-        self._gemm(p, Mb, hA, 32, L.ptr(W["d_mean"]), 32, 1, m.p("actor", "Wh"), hA, 0, L.ptr(ra.dz[-1]), hA, L.EPI_MASK, mask=L.ptr(ra.h[-1]), ldmask=hA,
-                   colsum=m.g("actor", f"b{len(m.actor.hidden) - 1}"))
+        self._gemm(p, Mb, hA, 32, L.ptr(W["d_mean"]), 32, 1, m.p("actor", "Wh"), hA, 0, L.ptr(ra.dz[-1]), hA, L.EPI_MASK,
+                   colsum=m.g("actor", f"b{len(m.actor.hidden) - 1}"), **ra.mask_args(len(m.actor.hidden) - 1, 0, Mb))
         ra.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True)
         self._update_marks = [("actor", len(p.calls))]  # the net's gradient is complete after this many calls
         # critic
-        rc.forward(p, L.ptr(W["norm_obs"]), Mb)
+        rc.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True)
         p.add("addhip_critic_head", L.ptr(rc.h[-1]), hC, hC, Mb, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(W["mb_tar"]), self._critic_loss_weight * gs,
               None, L.ptr(W["dv"]), L.ptr(W["stats"]) + 4 * 8)
         p.add("addhip_head_backward", L.ptr(W["dv"]), m.p("critic", "Wh"), L.ptr(rc.h[-1]), hC, hC, Mb, L.ptr(rc.dz[-1]), m.g("critic", "Wh"),
@@ -265,7 +265,7 @@ class ADDAgent:
         # discriminator: Mb agent/demo differences + one zero-difference row (row Mb of norm_diff stays 0)
         Md = Mb + 1
         nd = L.ptr(W["norm_diff"])
-        rd.forward(p, nd, Md)
+        rd.forward(p, nd, Md, sign_bits=True)
         p.add("addhip_disc_head", L.ptr(rd.h[-1]), hD, hD, Mb, L.ptr(rd.h[-1]) + 4 * Mb * hD, m.p("disc", "Wh"), m.p("disc", "bh"), ls_d,
               L.ptr(W["dlogit"]), L.ptr(W["dlogit"]) + 4 * Mb, L.ptr(W["stats"]) + 4 * 12)
         p.add("addhip_head_backward", L.ptr(W["dlogit"]), m.p("disc", "Wh"), L.ptr(rd.h[-1]), hD, hD, Md, L.ptr(rd.dz[-1]), m.g("disc", "Wh"),
@@ -276,12 +276,12 @@ class ADDAgent:
             raise NotImplementedError("the gradient-penalty chain is written for the 2-hidden-layer discriminator (fc_2layers_*)")
         d1, d2 = m.disc.hidden
         p.add("addhip_bcast_mask", m.p("disc", "Wh"), L.ptr(h2), d2, d2, Mb, L.ptr(W["a2"]))
-        self._gemm(p, Mb, d1, d2, L.ptr(W["a2"]), d2, 1, m.p("disc", "W1"), d1, 0, L.ptr(W["a1"]), d1, L.EPI_MASK, mask=L.ptr(h1), ldmask=d1)
+        self._gemm(p, Mb, d1, d2, L.ptr(W["a2"]), d2, 1, m.p("disc", "W1"), d1, 0, L.ptr(W["a1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
         self._gemm(p, Mb, DS, d1, L.ptr(W["a1"]), d1, 1, m.p("disc", "W0"), DS, 0, L.ptr(W["g"]), DS)
         p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, L.ptr(W["G"]), L.ptr(W["stats"]) + 4 * 20)
         # second-order terms: da1 = G W1^T ; e1 = da1 * m1 ; da2 = (e1 W2^T) * m2
-        self._gemm(p, Mb, d1, DS, L.ptr(W["G"]), DS, 1, m.p("disc", "W0"), DS, 1, L.ptr(W["e1"]), d1, L.EPI_MASK, mask=L.ptr(h1), ldmask=d1)
-        self._gemm(p, Mb, d2, d1, L.ptr(W["e1"]), d1, 1, m.p("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, mask=L.ptr(h2), ldmask=d2)
+        self._gemm(p, Mb, d1, DS, L.ptr(W["G"]), DS, 1, m.p("disc", "W0"), DS, 1, L.ptr(W["e1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
+        self._gemm(p, Mb, d2, d1, L.ptr(W["e1"]), d1, 1, m.p("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **rd.mask_args(1, 0, Mb))
         p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
         rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1"]), d1, L.ptr(W["G"]), DS, Mb), 1: (L.ptr(W["a2"]), d2, L.ptr(W["e1"]), d1, Mb)},
                     grads_zeroed=True, top_bias_done=True)

@@ -209,6 +209,10 @@ class NetRunner:
     def __init__(self, model, net, rows, device, slabs):
         self.m, self.net, self.rows, self.slabs = model, net, rows, slabs
         self.early_mark = None
+        self._bits_valid = False
+        # ReLU sign bits of the hidden activations (1 bit per element): what the backward GEMMs read as their mask instead of
+        # the fp32 activations themselves (64 MB -> 2 MB per 16384 x 1024 layer)
+        self.hb = [torch.zeros(rows, (h + 31) // 32, dtype=torch.int32, device=device) for h in net.hidden]
         self.h = [torch.zeros(rows, h, device=device) for h in net.hidden]
         self.dz = [torch.zeros(rows, h, device=device) for h in net.hidden]
 
@@ -221,13 +225,25 @@ class NetRunner:
             return [(0, rows - rem), (rows - rem, rem)]
         return [(0, rows)]
 
-    def forward(self, plan, x_ptr, rows, a_mean=None, a_std=None):
+    def mask_args(self, layer, r0, cnt):
+        """Mask of the backward pass through the ReLU of `layer` for rows [r0, r0+cnt): the sign bits where the forward pass
+        of this plan wrote them (row chunks of more than 8 rows), the fp32 activations otherwise."""
+        h = self.net.hidden[layer]
+        if self._bits_valid and cnt > 8:
+            ldb = (h + 31) // 32
+            return dict(mask_bits=L.ptr(self.hb[layer]) + 4 * r0 * ldb, ldbits=ldb)
+        return dict(mask=L.ptr(self.h[layer]) + 4 * r0 * h, ldmask=h)
+
+    def forward(self, plan, x_ptr, rows, a_mean=None, a_std=None, sign_bits=False):
+        """sign_bits: also write the ReLU sign bits (forward passes that are followed by a backward pass in the same plan)."""
         net, m = self.net, self.m
+        self._bits_valid = bool(sign_bits)
         prev, ld, k = x_ptr, net.in_ld, net.in_ld
         for i, h in enumerate(net.hidden):
             for r0, cnt in self._row_chunks(rows):
+                bits = dict(relu_bits=L.ptr(self.hb[i]) + 4 * r0 * ((h + 31) // 32), ldbits=(h + 31) // 32) if sign_bits and cnt > 8 else {}
                 g = gemm(cnt, h, k, prev + 4 * r0 * ld, ld, 1, m.p(net.name, f"W{i}"), k, 1, L.ptr(self.h[i]) + 4 * r0 * h, h, L.EPI_BIAS_RELU,
-                         m.p(net.name, f"b{i}"), a_mean=a_mean if i == 0 else None, a_std=a_std if i == 0 else None)
+                         m.p(net.name, f"b{i}"), a_mean=a_mean if i == 0 else None, a_std=a_std if i == 0 else None, **bits)
                 plan.hold(g)
                 plan.add("addhip_gemm_f32", g)
             prev, ld, k = L.ptr(self.h[i]), h, h
@@ -268,7 +284,7 @@ class NetRunner:
                     plan.add("addhip_fill_zero", m.g(net.name, f"b{i - 1}"), prev_d)
                 for r0, cnt in self._row_chunks(rows):
                     g3 = gemm(cnt, prev_d, out_d, L.ptr(self.dz[i]) + 4 * r0 * out_d, out_d, 1, m.p(net.name, f"W{i}"), prev_d, 0,
-                              L.ptr(self.dz[i - 1]) + 4 * r0 * prev_d, prev_d, L.EPI_MASK, mask=L.ptr(self.h[i - 1]) + 4 * r0 * prev_d, ldmask=prev_d,
-                              colsum=m.g(net.name, f"b{i - 1}"))
+                              L.ptr(self.dz[i - 1]) + 4 * r0 * prev_d, prev_d, L.EPI_MASK, colsum=m.g(net.name, f"b{i - 1}"),
+                              **self.mask_args(i - 1, r0, cnt))
                     plan.hold(g3)
                     plan.add("addhip_gemm_f32", g3)

@@ -177,6 +177,12 @@ typedef struct {
   float* colsum;            /* optional, MASK epilogue only: colsum[n] += sum_m C[m,n] (the bias gradient of the layer
                                whose pre-activation gradient this GEMM produces; atomics, caller zeroes) */
   int32_t precision;        /* ADDHIP_PREC_*: how the fp32 products are formed (operands and results are fp32 either way) */
+  /* ReLU sign bits, 1 bit per element instead of re-reading the fp32 activations as the mask of the backward pass:
+   * word [m*ldbits + n/32], bit n%32 = (C[m,n] > 0).  relu_bits: written by the BIAS_RELU epilogue (optional).
+   * mask_bits: read by the MASK epilogue instead of `mask` (optional; M > 8 only).  ldbits >= ceil(N/32). */
+  uint32_t* relu_bits;
+  const uint32_t* mask_bits;
+  int32_t ldbits;
 } addhip_gemm_t;
 int addhip_gemm_f32(const addhip_gemm_t* g, void* stream);
 

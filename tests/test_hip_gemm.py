@@ -177,3 +177,42 @@ def test_col_sum_and_slab_reduce():
     o2 = torch.ones(1000, device="cuda")
     L.call("addhip_slab_reduce", P(T(S)), 6, 1000, L.ptr(o2), 1000, 0.5, 1, L.current_stream())
     np.testing.assert_allclose(o2.cpu().numpy(), 1 + 0.5 * S.sum(0), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("precision", [0, 3])
+@pytest.mark.parametrize("N", [1024, 272, 96])
+def test_relu_sign_bits_roundtrip(N, precision):
+    """BIAS_RELU writes 1 sign bit per element next to the activations; the MASK epilogue fed with those bits gives the
+    same result, bit for bit, as with the fp32 activations as its mask (ragged M, N not a multiple of 32 or 128)."""
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import gemm
+
+    M, K = 16384 + 7, 128
+    rng = np.random.RandomState(5)
+    A, B, bias = rng.uniform(-1, 1, (M, K)).astype(F), rng.uniform(-1, 1, (N, K)).astype(F), rng.uniform(-1, 1, N).astype(F)
+    dA, dB, dbias = T(A), T(B), T(bias)
+    ldb = (N + 31) // 32
+    H = torch.zeros(M, N, device="cuda")
+    bits = torch.full((M, ldb), -1, dtype=torch.int32, device="cuda")
+    st = L.current_stream()
+    L.call("addhip_gemm_f32", gemm(M, N, K, L.ptr(dA), K, 1, L.ptr(dB), K, 1, L.ptr(H), N, 2, L.ptr(dbias), precision=precision,
+                                   relu_bits=L.ptr(bits), ldbits=ldb), st)
+    torch.cuda.synchronize()
+    h = H.cpu().numpy()
+    w = bits.cpu().numpy().astype(np.uint32)
+    got = ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(M, ldb * 32)
+    assert np.array_equal(got[:, :N], (h > 0).astype(np.uint32)) and np.all(got[:, N:] == 0)
+    assert 0.3 < got[:, :N].mean() < 0.7
+    # backward through that ReLU: dX = (dY @ W) masked, W n-contiguous like the weights of the next layer
+    K2 = 256
+    dY, W2 = T(rng.uniform(-1, 1, (M, K2)).astype(F)), T(rng.uniform(-1, 1, (K2, N)).astype(F))
+    out_f, out_b = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda")
+    cs_f, cs_b = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    L.call("addhip_gemm_f32", gemm(M, N, K2, L.ptr(dY), K2, 1, L.ptr(W2), N, 0, L.ptr(out_f), N, 3, mask=L.ptr(H), ldmask=N, colsum=L.ptr(cs_f),
+                                   precision=precision), st)
+    L.call("addhip_gemm_f32", gemm(M, N, K2, L.ptr(dY), K2, 1, L.ptr(W2), N, 0, L.ptr(out_b), N, 3, mask_bits=L.ptr(bits), ldbits=ldb,
+                                   colsum=L.ptr(cs_b), precision=precision), st)
+    torch.cuda.synchronize()
+    assert torch.equal(out_b, out_f) and float((out_f != 0).float().mean()) > 0.3
+    torch.testing.assert_close(cs_b, cs_f, rtol=1e-4, atol=1e-3)

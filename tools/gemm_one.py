@@ -11,7 +11,7 @@ akc, bkc, epi = a[4:7] if len(a) >= 7 else (1, 1, 2)
 split = a[7] if len(a) >= 8 else 1
 A, B, C, bias = torch.randn(M*K, device="cuda"), torch.randn(N*K, device="cuda"), torch.zeros(M*N*split, device="cuda"), torch.randn(N, device="cuda")
 mask = torch.randn(M*N, device="cuda")
-g = gemm(M, N, K, L.ptr(A), K if akc else M, akc, L.ptr(B), K if bkc else N, bkc, L.ptr(C), N, epi, L.ptr(bias), L.ptr(mask), N, precision=prec, split_k=split)
+g = gemm(M, N, K, L.ptr(A), K if akc else M, akc, L.ptr(B), K if bkc else N, bkc, L.ptr(C), N, epi, L.ptr(bias), L.ptr(mask), (0 if os.environ.get('MASK_LD0') else N), precision=prec, split_k=split)
 st = torch.cuda.current_stream()
 for _ in range(3):
     L.call("addhip_gemm_f32", g, st.cuda_stream)
