@@ -78,8 +78,8 @@ def gemm_roofline(agent, precision):
     tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
     if precision == "fp32":
         peak, kern = MFMA_F32_PEAK_TFLOPS, "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all GEMM launches of one optimiser step)"
-        # PMC, profiles/r01_gemm_pmc.md: (WRITE_SIZE 1252.1 MB + 2 x FETCH_SIZE 2533.8 MB) / 33 launches of one optimiser step
-        traffic = (1252.1e6 + 2 * 2533.8e6) / 33
+        # PMC, profiles/r01_gemm_pmc.md: (WRITE_SIZE 1269.5 MB + 2 x FETCH_SIZE 2280.2 MB) / 33 launches of one optimiser step
+        traffic = (1269.5e6 + 2 * 2280.2e6) / 33
     else:
         products = {"bf16x3": 6, "bf16x2": 3, "bf16": 1}[precision]
         peak = MFMA_BF16_PEAK_TFLOPS / products
