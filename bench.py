@@ -182,6 +182,11 @@ def cpu_baseline(num_envs, steps_per_iter):
 
 def main():
     a = parse()
+    # stdout carries exactly one thing: the JSON line.  Libraries that print there (RCCL's version banner at communicator
+    # creation, for one) are sent to stderr for the whole run; the line itself goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -289,7 +294,8 @@ def main():
         if rank == 0:
             out["alt_precision"] = alts
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
