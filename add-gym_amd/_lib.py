@@ -127,6 +127,11 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.addhip_last_error.restype = C.c_char_p
     lib.addhip_version.restype = C.c_int
+    lib.addhip_abi_sizes.argtypes, lib.addhip_abi_sizes.restype = [C.POINTER(C.c_int32), C.c_int32], C.c_int
+    sizes = (C.c_int32 * 7)()
+    mine = [C.sizeof(t) for t in (MotionT, TaskT, EnvT, StepOutT, SamplerT, GemmT, GatherT)]
+    if lib.addhip_abi_sizes(sizes, 7) != 7 or list(sizes) != mine:
+        raise AddhipError(f"struct layouts of this binding {mine} do not match {LIB_PATH} {list(sizes)}: rebuild the library")
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = args

@@ -36,6 +36,9 @@ enum { ADDHIP_DONE_NULL = 0, ADDHIP_DONE_FAIL = 1, ADDHIP_DONE_SUCC = 2, ADDHIP_
 
 const char* addhip_last_error(void);
 int addhip_version(void);
+/* sizeof() of addhip_motion_t, task_t, env_t, step_out_t, sampler_t, gemm_t, gather_t (in that order) -> out[0..6]; returns the
+ * number written (7) or -1.  For bindings to verify their struct layouts against the library they loaded. */
+int addhip_abi_sizes(int32_t* out, int32_t count);
 
 /* ---- reference-motion step tables: MotionLib._step_* (anim/motion_lib.py:285-320) ---- */
 typedef struct {
