@@ -619,6 +619,9 @@ class ADDAgent:
     def reset_all_envs(self, tag=0):
         B = self._B
         self._reset_envs(True, B["obs"][0], B["disc_obs"][self.T], B["disc_demo"][self.T], tag)
+        # rows of envs that never ran into the time limit are evaluated by the critic too (and ignored): keep them ordinary
+        # observations instead of zeros, which normalise to huge inputs wherever an obs column is nearly constant
+        B["obs_timeout"].copy_(B["obs"][0])
         self._iter_started = False
 
     def train_model(self, out_model_file, int_output_dir, log_file):

@@ -395,3 +395,36 @@ def test_kinematic_playback_export(tmp_path):
     assert live.mean() > 0.5 and np.abs(arrays["sim_pose"] - arrays["ref_pose"])[live].max() < 1e-3  # fp32 clock vs recomputed time
     assert arrays["reward"][live].min() > 0.84  # all four reward terms at their maximum (0.5 + 0.1 + 0.15 + 0.1)
     export_playback(cfg, str(out), 5, source="policy")  # deterministic policy path runs too
+
+
+def test_episode_time_limit_rows_feed_the_critic():
+    """DONE_TIME samples: the step kernel parks the pre-reset obs row in obs_timeout, the critic evaluates those rows, and
+    TD(lambda) bootstraps from that value (ppo_agent.py:117-133) -- not from V(obs[t+1]), which is the reset obs."""
+    import torch
+    import add_gym_amd.learning.add_agent as A
+
+    cfg = make_cfg(256, steps_per_iter=8)
+    cfg["task"].update(motion_file="synthetic:1x600", enable_early_termination=False, max_episode_length=0.2)  # 20 steps, clip 20 s
+    ag = A.ADDAgent(cfg)
+    ag.reset_all_envs()
+    ag._init_train()
+    hits = 0
+    for it in range(3):
+        ag._B["obs"][0].copy_(ag._B["obs"][ag.T]) if it else None
+        ag._rollout_train()
+        ag._build_train_data()
+        ag._iter += 1
+        torch.cuda.synchronize()
+        B = ag._B
+        done, r, tar = B["done"][-1], B["reward"][-1], B["tar_val"][-1]   # last step of the rollout: ret = r + gamma * next value
+        t_env = (done == 3).nonzero().flatten()
+        hits += int((B["done"] == 3).sum())
+        if len(t_env):
+            want = r[t_env] + ag._discount * B["timeout_vals"][t_env]
+            torch.testing.assert_close(tar[t_env], want, rtol=1e-6, atol=1e-6)
+            other = r[t_env] + ag._discount * B["vals"][ag.T][t_env]   # what bootstrapping from the reset obs would give
+            assert (want - other).abs().max() > 1e-4
+            # the parked row is the observation of that step before the reset overwrote slot T
+            assert not torch.equal(B["obs_timeout"][t_env], B["obs"][ag.T][t_env])
+        assert torch.isfinite(B["tar_val"]).all() and torch.isfinite(B["adv"]).all() and torch.isfinite(B["timeout_vals"]).all()
+    assert hits >= 200  # nearly every env ran into the 0.2 s limit in 24 steps (a few reach the clip end first: DONE_SUCC)
