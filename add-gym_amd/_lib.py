@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libaddhip.so")
 
 MAX_TAR = 8
 HIST = 3
+DONE_NULL, DONE_FAIL, DONE_SUCC, DONE_TIME = 0, 1, 2, 3  # base_agent.py:16-20
 POSE_W = 36
 NUM_DOF = 29
 DISC_STEP_W = 9 + NUM_DOF  # pos3 + tan/norm 6 + dof 29

@@ -13,7 +13,7 @@
 //
 // Reference functions restated here: see include/addhip.h at each entry point.
 #include "common.h"
-#include "quat.cuh"
+#include "quat.h"
 
 using namespace addhip;
 

@@ -23,6 +23,7 @@ from ..envs.env import ImitationEnvironment
 from .. import hotpath as H
 from ..hotpath import gemm, make_task
 from ..util.logger import Logger
+from ..util.tb_logger import TBLogger
 from .model import Model, NetRunner, Plan
 
 
@@ -57,11 +58,11 @@ class ADDAgent:
         # agent.matmul_precision: "fp32" (fp32 MFMA, default), "bf16x3" (exact 3-way bf16 split, fp32-level error, ~2.7x the
         # MFMA rate), "bf16x2" (two leading chunks, TF32-class) or "bf16"; operands, results and every other kernel stay fp32
         # (include/addhip.h: ADDHIP_PREC_*)
-        prec = os.environ.get("ADDHIP_MATMUL_PRECISION") or str(cfg.get("matmul_precision", "fp32"))
+        prec = str(cfg.get("matmul_precision", "fp32"))
         if prec not in H.PRECISIONS:
             raise ValueError(f"agent.matmul_precision must be one of {sorted(H.PRECISIONS)}")
-        H.DEFAULT_PRECISION = H.PRECISIONS[prec]
-        self._matmul_precision = prec
+        self._matmul_precision = prec       # a property of this agent: carried by every GEMM descriptor it builds
+        self._prec = H.PRECISIONS[prec]
 
         # ---- motion library + sampler (add_motion.py:14-33)
         kin = env.robot._kin_char_model
@@ -149,8 +150,9 @@ class ADDAgent:
         self._test_state = z(3)
         self._train_state = z(3)
         self._timers = {}
+        self._test_calls = 0
         # optional externally supplied random draws (parity tests replay the reference's draws through these):
-        #   {"noise": [T][N,29], "uniforms": {tag: [3,N]}, "perms": iterator of int64 permutations, "pre_step": fn(t)}
+        #   {"noise": [T][N,29], "uniforms": {Philox stream id (stream_* below): [3,N]}, "perms": iterator of int64 permutations, "pre_step": fn(t)}
         self.inject = None
 
     # ------------------------------------------------------------------ config (base/ppo/amp agents' _load_params)
@@ -198,9 +200,9 @@ class ADDAgent:
         # split-K scratch: one per net, because the three nets' update sections run on three concurrent streams
         self._slabs_all = z(3, need)
         self._slabs = self._slabs_all[0]
-        self._run_actor = NetRunner(m, m.actor, rows, dev, self._slabs_all[0])
-        self._run_critic = NetRunner(m, m.critic, rows, dev, self._slabs_all[1])
-        self._run_disc = NetRunner(m, m.disc, rows, dev, self._slabs_all[2])
+        self._run_actor = NetRunner(m, m.actor, rows, dev, self._slabs_all[0], self._prec)
+        self._run_critic = NetRunner(m, m.critic, rows, dev, self._slabs_all[1], self._prec)
+        self._run_disc = NetRunner(m, m.disc, rows, dev, self._slabs_all[2], self._prec)
         self._side_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         OS, DS = self._task.obs_stride, self._task.disc_stride
         hd = m.disc.hidden
@@ -210,6 +212,7 @@ class ADDAgent:
                        stats=z(32), scratch=z(4096, dt=torch.float64), adv_stats=z(2), rstats=z(2), perm_idx=z(Mb, dt=torch.int64))
 
     def _gemm(self, plan, *a, **k):
+        k.setdefault("precision", self._prec)
         g = gemm(*a, **k)
         plan.hold(g)
         plan.add("addhip_gemm_f32", g)
@@ -300,6 +303,25 @@ class ADDAgent:
         self._update_schedule = [(0, 0, ea, br["actor_tail"]), (1, end_a, ec, br["critic_tail"]), (2, end_c, end_d, br["disc"]),
                                  (0, ea, end_a, None), (1, ec, end_c, None)]  # the two first layers: one bucket after the join
 
+        # ---- build-train-data: critic over the T+1 obs slots and the N obs_timeout rows, discriminator over the T*N
+        # differences, in chunks of _eval_rows rows (plans prebuilt once like the act / update plans)
+        chunk = self._eval_rows
+        self._critic_eval = []  # (plan, rows, value destination)
+        for src, dst, total in ((B["obs"], B["vals"], (T + 1) * N), (B["obs_timeout"], B["timeout_vals"], N)):
+            for r0 in range(0, total, chunk):
+                rows = min(chunk, total - r0)
+                p = Plan()
+                rc.forward(p, L.ptr(src) + 4 * r0 * OS, rows, a_mean=L.ptr(Nm["obs_mean"]), a_std=L.ptr(Nm["obs_std"]))
+                p.add("addhip_head_gemv", L.ptr(rc.h[-1]), hC, hC, rows, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(dst) + 4 * r0)
+                self._critic_eval.append(p)
+        self._disc_eval = []  # (r0, rows, forward + logits plan)
+        for r0 in range(0, T * N, chunk):
+            rows = min(chunk, T * N - r0)
+            p = Plan()
+            rd.forward(p, L.ptr(W["norm_diff"]), rows)
+            p.add("addhip_head_gemv", L.ptr(rd.h[-1]), hD, hD, rows, m.p("disc", "Wh"), m.p("disc", "bh"), L.ptr(W["logits"]))
+            self._disc_eval.append((r0, rows, p))
+
         self._gather_c = L.GatherT(L.ptr(W["perm_idx"]), Mb, L.ptr(B["obs"]), OS, tk.obs_dim, L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(B["action"]),
                                    L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), L.ptr(B["a_logp"]), L.ptr(B["adv"]), L.ptr(B["tar_val"]), L.ptr(B["rand_mask"]),
                                    L.ptr(B["disc_obs"]), L.ptr(B["disc_demo"]), DS, tk.disc_dim, L.ptr(Nm["d_abs"]), 1e-4, L.ptr(W["norm_obs"]),
@@ -320,11 +342,30 @@ class ADDAgent:
         return torch.cuda.current_stream().cuda_stream
 
     # ------------------------------------------------------------------ env reset / step
-    def _draw_uniforms(self, tag):
+    # Philox stream ids (seed = agent seed): one 2^40-wide namespace per purpose, so that no two draws of a run share a
+    # counter range: 1 actor noise, 2 masked train resets, 3 exploration mask, 4 reset-all (start / after an output
+    # iteration), 5 reset-all at the start of an evaluation, 6 masked resets inside an evaluation.
+    @staticmethod
+    def stream_train_reset(step_index):
+        return (2 << 40) + int(step_index)
+
+    @staticmethod
+    def stream_reset_all(count):
+        return (4 << 40) + int(count)
+
+    @staticmethod
+    def stream_test_reset_all(test_call):
+        return (5 << 40) + int(test_call)
+
+    @staticmethod
+    def stream_test_reset(test_call, k):
+        return (6 << 40) + (int(test_call) << 20) + int(k)
+
+    def _draw_uniforms(self, stream_id):
         if self.inject is not None and "uniforms" in self.inject:
-            self._W["u"].copy_(self.inject["uniforms"][tag])
+            self._W["u"].copy_(self.inject["uniforms"][stream_id])
             return
-        L.call("addhip_fill_uniform", L.ptr(self._W["u"]), 3 * self.N, self._seed, (2 << 40) + tag, self._stream())
+        L.call("addhip_fill_uniform", L.ptr(self._W["u"]), 3 * self.N, self._seed, stream_id, self._stream())
 
     def _sync_foreign_engine_in(self):
         """Slow path for engines without hot_state(): gather the BaseEntity getters into the packed rows."""
@@ -341,13 +382,13 @@ class ADDAgent:
             ent.set_qpos(self._S["sim_pose"][ids], envs_idx=ids)            # add_observation.py:314-322
             ent.set_dofs_velocity(self._S["sim_vel"][ids, :35], envs_idx=ids)  # :323-331
 
-    def _reset_envs(self, reset_all, obs_slot, disc_slot, demo_slot, tag):
+    def _reset_envs(self, reset_all, obs_slot, disc_slot, demo_slot, stream_id):
         """ADDAgent._reset_envs (add_agent.py:221-233), masked on device (no host nonzero)."""
         S = self._S
         mask = None
         if not self._fast_engine:
             mask = torch.ones(self.N, dtype=torch.bool, device=self._device) if reset_all else (S["done"] != 0)
-        self._draw_uniforms(tag)
+        self._draw_uniforms(stream_id)
         u = self._W["u"]
         L.call("addhip_env_reset", self._motion_lib.c_struct, self._task, self._env_c, self._smp_c, L.ptr(u[0]), L.ptr(u[1]), L.ptr(u[2]),
                L.ptr(obs_slot), L.ptr(disc_slot), L.ptr(demo_slot), int(reset_all), self._head, self._stream())
@@ -402,14 +443,8 @@ class ADDAgent:
                 self.inject["pre_step"](t)
             self._step_env(t, self._step_out[t], self._env_c)
             # obs slot t+1 already holds the post-step obs; reset envs overwrite theirs (base_agent.py:449-453)
-            self._reset_envs(False, B["obs"][t + 1], B["disc_obs"][t + 1], B["disc_demo"][t + 1], (self._iter * T + t) * 2 + 1)
+            self._reset_envs(False, B["obs"][t + 1], B["disc_obs"][t + 1], B["disc_demo"][t + 1], self.stream_train_reset(self._iter * T + t))
         self._total_samples += T * self.N
-
-    def _forward_rows(self, runner, src, rows, normalize, stream=None):
-        p = Plan()
-        Nm = self._Nrm
-        runner.forward(p, src, rows, a_mean=L.ptr(Nm["obs_mean"]) if normalize else None, a_std=L.ptr(Nm["obs_std"]) if normalize else None)
-        p.run(self._stream() if stream is None else stream)
 
     def _build_train_data(self):
         """add_agent.py:110-139 then ppo_agent.py:111-159."""
@@ -418,8 +453,6 @@ class ADDAgent:
         rows_total = T * N
         st = self._stream()
         W["rstats"].zero_()
-        chunk = self._eval_rows
-        hD, hC = m.disc.hidden[-1], m.critic.hidden[-1]
         record = self._need_normalizer_update()
         # the critic pass (side stream) and the discriminator pass (this stream) are independent until TD(lambda)
         main, side = torch.cuda.current_stream(), self._side_streams[0]
@@ -432,24 +465,17 @@ class ADDAgent:
         # every sample whose env was not reset (the reference evaluates next_obs separately, ppo_agent.py:117-126; the
         # rows are identical, so are the values).  Reset envs: SUCC/FAIL take the terminal values, TIME takes V of the
         # pre-reset row the step kernel parked in obs_timeout.
-        def critic_rows(src, dst, total):
-            for r0 in range(0, total, chunk):
-                rows = min(chunk, total - r0)
-                self._forward_rows(self._run_critic, src + 4 * r0 * tk.obs_stride, rows, True, cs)
-                L.call("addhip_head_gemv", L.ptr(self._run_critic.h[-1]), hC, hC, rows, m.p("critic", "Wh"), m.p("critic", "bh"), dst + 4 * r0, cs)
-        critic_rows(L.ptr(B["obs"]), L.ptr(B["vals"]), (T + 1) * N)
-        critic_rows(L.ptr(B["obs_timeout"]), L.ptr(B["timeout_vals"]), N)
+        for p in self._critic_eval:
+            p.run(cs)
         joined = torch.cuda.Event()
         joined.record(side)
-        for r0 in range(0, rows_total, chunk):
-            rows = min(chunk, rows_total - r0)
+        for r0, rows, plan in self._disc_eval:
             do = L.ptr(B["disc_obs"]) + 4 * r0 * tk.disc_stride
             dd = L.ptr(B["disc_demo"]) + 4 * r0 * tk.disc_stride
             L.call("addhip_disc_prep", do, dd, tk.disc_stride, tk.disc_dim, rows, L.ptr(Nm["d_abs"]), 1e-4, L.ptr(W["norm_diff"]),
                    L.ptr(B["motion_id"]) + 4 * r0, L.ptr(B["motion_time"]) + 4 * r0, self._smp_c, self._num_clips,
                    L.ptr(Nm["d_sum"]) if record else None, st)
-            self._forward_rows(self._run_disc, L.ptr(W["norm_diff"]), rows, False)
-            L.call("addhip_head_gemv", L.ptr(self._run_disc.h[-1]), hD, hD, rows, m.p("disc", "Wh"), m.p("disc", "bh"), L.ptr(W["logits"]), st)
+            plan.run(st)
             L.call("addhip_disc_reward", L.ptr(W["logits"]), L.ptr(B["reward"]) + 4 * r0, rows, self._disc_reward_scale, self._task_reward_weight,
                    self._disc_reward_weight, L.ptr(W["rstats"]), st)
         main.wait_event(joined)
@@ -518,8 +544,9 @@ class ADDAgent:
         fork.record(main)
         # stream-ordered asynchronous collectives are an nccl (RCCL) property; any other backend (gloo in rehearsals) gets one
         # blocking all-reduce of the whole gradient after the join
-        # (ADDHIP_EXERCISE_EXCHANGE=1: take the multi-rank code path in a 1-rank nccl group, to rehearse it on a single GPU)
-        exchange = self._world > 1 or (self._distributed and os.environ.get("ADDHIP_EXERCISE_EXCHANGE") == "1")
+        # (a 1-rank process group takes the same path: the collectives are identities there, which is how the single-GPU
+        # tests exercise the issue order, the bucket ranges and the stream joins)
+        exchange = self._distributed
         overlap = exchange and torch.distributed.get_backend() == "nccl"
         pending = []
         for s in self._side_streams:
@@ -606,6 +633,16 @@ class ADDAgent:
         }
         return info
 
+    def _build_logger(self, log_file):
+        """base_agent.py:322-333: rank 0 logs to log.txt + TensorBoard (step key "Samples"); the other ranks keep a file-less
+        Logger, which still takes part in the cross-rank mean of print_log / write_log."""
+        if self._distributed and self._rank != 0:
+            return Logger()
+        log = TBLogger()
+        log.set_step_key("Samples")
+        log.configure_output_file(log_file)
+        return log
+
     def _init_train(self):
         if not self._is_restored:
             self._iter, self._sample_count = 0, 0
@@ -616,9 +653,9 @@ class ADDAgent:
         self._S["ret_acc"].zero_()
         self._S["len_acc"].zero_()
 
-    def reset_all_envs(self, tag=0):
+    def reset_all_envs(self, stream_id=None):
         B = self._B
-        self._reset_envs(True, B["obs"][0], B["disc_obs"][self.T], B["disc_demo"][self.T], tag)
+        self._reset_envs(True, B["obs"][0], B["disc_obs"][self.T], B["disc_demo"][self.T], self.stream_reset_all(0) if stream_id is None else stream_id)
         # rows of envs that never ran into the time limit are evaluated by the critic too (and ignored): keep them ordinary
         # observations instead of zeros, which normalise to huge inputs wherever an obs column is nearly constant
         B["obs_timeout"].copy_(B["obs"][0])
@@ -628,7 +665,7 @@ class ADDAgent:
         """base_agent.py:79-114."""
         start = time.time()
         self.reset_all_envs()
-        self._logger = Logger(log_file if self._rank == 0 else None, world=self._world)
+        self._logger = self._build_logger(log_file)
         self._init_train()
         test_info = {"mean_return": 0.0, "mean_ep_len": 0.0, "num_eps": 0}
         # everything built so far is long-lived: take it out of the cyclic GC's view so a full collection (tens of ms with
@@ -652,39 +689,56 @@ class ADDAgent:
                 self._train_state.zero_()
                 self._S["ret_acc"].zero_()
                 self._S["len_acc"].zero_()
-                self.reset_all_envs(tag=self._iter + 1)
+                self.reset_all_envs(self.stream_reset_all(self._iter + 1))
             self._iter += 1
 
     def test_model(self, num_episodes):
-        """base_agent.py:116-126, 393-425: deterministic actions until every env has finished its quota of episodes.
-        (Host-synchronous by design: it is outside the throughput path.)"""
+        """base_agent.py:116-126, 393-425: deterministic (mode) actions until every env has finished its quota of episodes.
+        (Host-synchronous by design: it is outside the throughput path.)
+
+        task.reference_compat (default on) reproduces what the reference does here: Environment.set_mode(TEST) sets
+        env.num_envs = 1 (envs/env.py:142-148), so the reset at the start touches env 0 only -- the other envs carry on from
+        wherever training left them -- and the quota is ceil(num_episodes / 1) = num_episodes finished episodes for EVERY env.
+        Corrected mode: all envs start from a fresh reset and the quota is ceil(num_episodes / num_envs) per env."""
         self.set_mode(AgentMode.TEST)
         if int(num_episodes) == 0:
             self.set_mode(AgentMode.TRAIN)
             return {"mean_return": 0.0, "mean_ep_len": 0.0, "num_eps": 0}
         B, S = self._B, self._S
-        self.reset_all_envs(tag=(7 << 20) + self._iter)
+        compat = bool(self._task_cfg.get("reference_compat", True))
+        call = self._test_calls
+        self._test_calls += 1
+        if compat:
+            S["done"].zero_()
+            S["done"][0] = L.DONE_FAIL  # any non-NULL flag: the masked reset then re-samples exactly env 0
+            self._reset_envs(False, B["obs"][0], B["disc_obs"][self.T], B["disc_demo"][self.T], self.stream_test_reset_all(call))
+            min_eps = int(num_episodes)
+        else:
+            self.reset_all_envs(self.stream_test_reset_all(call))
+            min_eps = int(np.ceil(num_episodes / self.N))
         S["ret_acc_test"].zero_()
         S["len_acc_test"].zero_()
         self._test_state.zero_()
         eps_per_env = torch.zeros(self.N, dtype=torch.long, device=self._device)
-        min_eps = int(np.ceil(num_episodes / self.N))
         ep = torch.zeros(1, 3, device=self._device)
         out = L.StepOutT(L.ptr(B["obs"][0]), None, None, L.ptr(B["disc_obs"][self.T]), L.ptr(B["disc_demo"][self.T]), None, None, None, None, L.ptr(ep))
         k = 0
         while True:
             self._decide_action(0, 0, True)
+            if self.inject is not None and "pre_step" in self.inject:
+                self.inject["pre_step"](k)
             ep.zero_()
             self._step_env(0, out, self._env_c_test)
             eps_per_env += (S["done"] != 0).long()
             L.call("addhip_return_tracker_fold", L.ptr(ep), 1, L.ptr(self._test_state), self._stream())
-            self._reset_envs(False, B["obs"][0], B["disc_obs"][self.T], B["disc_demo"][self.T], (9 << 20) + k)
+            self._reset_envs(False, B["obs"][0], B["disc_obs"][self.T], B["disc_demo"][self.T], self.stream_test_reset(call, k))
             k += 1
             if bool(torch.all(eps_per_env > min_eps - 1)):
                 break
         st = self._test_state.cpu().numpy()
         self.set_mode(AgentMode.TRAIN)
         self._iter_started = False
+        self._test_steps = k
         return {"mean_return": float(st[1]), "mean_ep_len": float(st[2]), "num_eps": int(st[0])}
 
     # ------------------------------------------------------------------ logging / checkpoints
@@ -692,18 +746,56 @@ class ADDAgent:
         """base_agent.py:482-520 + ppo_agent.py:277-279: same keys, same order."""
         lg = self._logger
         ti = dict(train_info)
-        lg.log("Iteration", self._iter, collection="1_Info")
+        lg.log("Iteration", int(self._iter), collection="1_Info")
         lg.log("Wall_Time", (time.time() - start_time) / 3600.0, collection="1_Info")
-        lg.log("Samples", self._sample_count, collection="1_Info")
+        lg.log("Samples", int(self._sample_count), collection="1_Info")
         lg.log("Test_Return", test_info["mean_return"], collection="0_Main")
         lg.log("Test_Episode_Length", test_info["mean_ep_len"], collection="0_Main", quiet=True)
-        lg.log("Test_Episodes", test_info["num_eps"], collection="1_Info", quiet=True)
+        lg.log("Test_Episodes", int(test_info["num_eps"]), collection="1_Info", quiet=True)
         lg.log("Train_Return", ti.pop("mean_return"), collection="0_Main")
         lg.log("Train_Episode_Length", ti.pop("mean_ep_len"), collection="0_Main", quiet=True)
-        lg.log("Train_Episodes", ti.pop("num_eps"), collection="1_Info", quiet=True)
+        lg.log("Train_Episodes", int(ti.pop("num_eps")), collection="1_Info", quiet=True)
         for k, v in ti.items():
-            lg.log(k.title(), v)
-        lg.log("Exp_Prob", self._get_exp_prob())
+            lg.log(k.title(), float(v))
+        for k, v in self._env.get_diagnostics().items():  # base_agent.py:515-519
+            lg.log(k.title(), float(v), collection="2_Env", quiet=True)
+        lg.log("Exp_Prob", float(self._get_exp_prob()))  # ppo_agent.py:277-279
+        if self._iter % self._iters_per_output == 0:  # add_agent.py:235-238
+            self._log_sampler_distribution()
+
+    def _log_sampler_distribution(self):
+        """add_agent.py:240-265: bar charts of the per-segment mean error and mean start probability as a TensorBoard image
+        (tag Sampler/Distribution, step = iteration).  Needs matplotlib; skipped silently without it, like any viewer extra."""
+        lg = self._logger
+        if not isinstance(lg, TBLogger) or lg._writer is None:
+            return
+        try:
+            import io
+
+            import matplotlib
+
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except Exception:
+            return
+        err = self._smp["errors"]
+        temp = self._smp_c.temperature
+        tau = float(err.max()) + 1e-6 if temp <= 0 else temp  # sampler.py:57-73 over all clips
+        probs = torch.softmax(err / tau, dim=-1)
+        x = np.arange(self._num_segments)
+        fig, (ax1, ax2) = plt.subplots(1, 2, figsize=(10, 3))
+        ax1.bar(x, err.mean(dim=0).cpu().numpy())
+        ax1.set_title("Mean Error per Segment")
+        ax1.set_xlabel("Segment")
+        ax2.bar(x, probs.mean(dim=0).cpu().numpy())
+        ax2.set_title("Mean Prob per Segment")
+        ax2.set_xlabel("Segment")
+        fig.tight_layout()
+        buf = io.BytesIO()
+        fig.savefig(buf, format="png", dpi=100)
+        plt.close(fig)
+        w, h = fig.get_size_inches() * 100
+        lg.add_image_png("Sampler/Distribution", int(h), int(w), buf.getvalue(), self._iter)
 
     def state_dict(self):
         Nm, tk = self._Nrm, self._task

@@ -153,8 +153,9 @@ class Model:
                 v = v[:shape[0], :shape[1]]
             else:
                 v = v[:shape[0]]
+            if name == "_model._action_dist._mean_net.weight":  # the reference's registration order: logstd precedes the mean head
+                out["_model._action_dist._logstd_net"] = torch.full((L.NUM_DOF,), float(math.log(self.action_std)), dtype=torch.float32)
             out[name] = v.detach().clone().cpu()
-        out["_model._action_dist._logstd_net"] = torch.full((L.NUM_DOF,), float(math.log(self.action_std)), dtype=torch.float32)
         return out
 
     def load(self, state, buf=None):
@@ -206,8 +207,9 @@ class Plan:
 class NetRunner:
     """Forward / backward call recording for one Mlp over `rows` rows with its own activation buffers."""
 
-    def __init__(self, model, net, rows, device, slabs):
+    def __init__(self, model, net, rows, device, slabs, precision=L.PREC_F32):
         self.m, self.net, self.rows, self.slabs = model, net, rows, slabs
+        self.precision = precision  # ADDHIP_PREC_* of every GEMM this runner records (agent.matmul_precision)
         self.early_mark = None
         self._bits_valid = False
         # ReLU sign bits of the hidden activations (1 bit per element): what the backward GEMMs read as their mask instead of
@@ -243,7 +245,7 @@ class NetRunner:
             for r0, cnt in self._row_chunks(rows):
                 bits = dict(relu_bits=L.ptr(self.hb[i]) + 4 * r0 * ((h + 31) // 32), ldbits=(h + 31) // 32) if sign_bits and cnt > 8 else {}
                 g = gemm(cnt, h, k, prev + 4 * r0 * ld, ld, 1, m.p(net.name, f"W{i}"), k, 1, L.ptr(self.h[i]) + 4 * r0 * h, h, L.EPI_BIAS_RELU,
-                         m.p(net.name, f"b{i}"), a_mean=a_mean if i == 0 else None, a_std=a_std if i == 0 else None, **bits)
+                         m.p(net.name, f"b{i}"), a_mean=a_mean if i == 0 else None, a_std=a_std if i == 0 else None, precision=self.precision, **bits)
                 plan.hold(g)
                 plan.add("addhip_gemm_f32", g)
             prev, ld, k = L.ptr(self.h[i]), h, h
@@ -261,13 +263,13 @@ class NetRunner:
             inp = x_ptr if i == 0 else L.ptr(self.h[i - 1])
             s = split_k_for(out_d, in_ld, rows)
             slab = out_d * in_ld
-            g = gemm(out_d, in_ld, rows, L.ptr(self.dz[i]), out_d, 0, inp, in_ld, 0, L.ptr(self.slabs), in_ld, split_k=s)
+            g = gemm(out_d, in_ld, rows, L.ptr(self.dz[i]), out_d, 0, inp, in_ld, 0, L.ptr(self.slabs), in_ld, split_k=s, precision=self.precision)
             plan.hold(g)
             plan.add("addhip_gemm_f32", g)
             total = s
             if extra_dw and i in extra_dw:
                 a_ptr, lda, b_ptr, ldb, erows = extra_dw[i]
-                g2 = gemm(out_d, in_ld, erows, a_ptr, lda, 0, b_ptr, ldb, 0, L.ptr(self.slabs) + 4 * s * slab, in_ld, split_k=s)
+                g2 = gemm(out_d, in_ld, erows, a_ptr, lda, 0, b_ptr, ldb, 0, L.ptr(self.slabs) + 4 * s * slab, in_ld, split_k=s, precision=self.precision)
                 plan.hold(g2)
                 plan.add("addhip_gemm_f32", g2)
                 total = 2 * s
@@ -284,7 +286,7 @@ class NetRunner:
                     plan.add("addhip_fill_zero", m.g(net.name, f"b{i - 1}"), prev_d)
                 for r0, cnt in self._row_chunks(rows):
                     g3 = gemm(cnt, prev_d, out_d, L.ptr(self.dz[i]) + 4 * r0 * out_d, out_d, 1, m.p(net.name, f"W{i}"), prev_d, 0,
-                              L.ptr(self.dz[i - 1]) + 4 * r0 * prev_d, prev_d, L.EPI_MASK, colsum=m.g(net.name, f"b{i - 1}"),
+                              L.ptr(self.dz[i - 1]) + 4 * r0 * prev_d, prev_d, L.EPI_MASK, colsum=m.g(net.name, f"b{i - 1}"), precision=self.precision,
                               **self.mask_args(i - 1, r0, cnt))
                     plan.hold(g3)
                     plan.add("addhip_gemm_f32", g3)

@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=1536, help="envs of the CPU-oracle sample (one iteration; about 10 s of host time)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement after the headline run")
+    ap.add_argument("--exercise-exchange", action="store_true",
+                    help="N=1 only: join a 1-rank RCCL group so that the multi-rank exchange path (async gradient buckets) runs; rehearsal, not a headline")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x2", "bf16"],
                     help="agent.matmul_precision: how addhip_gemm_f32 forms its fp32 products (include/addhip.h ADDHIP_PREC_*)")
     return ap.parse_args()
@@ -196,7 +198,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path is HIP-only)")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    distributed = world > 1 or os.environ.get("ADDHIP_EXERCISE_EXCHANGE") == "1"  # the latter: 1-rank RCCL group, rehearsal only
+    distributed = world > 1 or a.exercise_exchange
     if distributed and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29655")

@@ -115,7 +115,7 @@ typedef struct {
  * compute_disc_obs x2 (add_observation.py:231-306, 356-419, 422-717); compute_reward
  * (add_reward.py:103-177); compute_done (add_done.py:96-147); ReturnTracker.update
  * (base_agent.py:596-621).  `head` = ring slot that receives the new state.
- * Two launches: observations + ring push + reference rows, then reward / done / return tracker.
+ * One launch (env_step_kernel): observations, ring push, reference rows, reward, done flags and return tracker.
  * task.enable_vel_obs adds the velocity terms of compute_char_obs / compute_vel_obs
  * (add_observation.py:445-452, 502-517; needs e->hist_vel); task.enable_phase_obs adds
  * compute_phase_obs (:557-575). */

@@ -11,6 +11,29 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+MODEL_CFG = dict(actor_net="fc_3layers_1024units", critic_net="fc_3layers_1024units", disc_net="fc_2layers_1024units", action_std=0.05,
+                 actor_init_output_scale=0.01, actor_std_type="FIXED")  # configs/agent/add_g1.yaml: model
+
+
+def test_bucket_ranges_tile_the_flat_parameter_buffer():
+    """The four exchange buckets are contiguous, disjoint and cover [0, count): every gradient element is all-reduced exactly once."""
+    sys.path.insert(0, ROOT)
+    import add_gym_amd  # noqa: F401
+    from add_gym_amd.learning.model import Model
+
+    m = Model(MODEL_CFG, 264, 272, 114, 128, torch.device("cpu"))
+    spans = sorted(m.bucket_ranges.values())
+    assert spans[0][0] == 0 and spans[-1][1] == m.count
+    assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+    covered = np.zeros(m.count, np.int32)
+    for (net, key), (off, shape) in m.offsets.items():
+        covered[off:off + int(np.prod(shape))] += 1
+    assert covered.max() == 1  # tensors do not overlap (gaps are 4-float alignment padding only)
+    first = {("actor", "W0"), ("actor", "b0"), ("critic", "W0"), ("critic", "b0")}
+    a, b = m.bucket_ranges["first_layers"]
+    assert all((a <= off < b) == ((net, key) in first) for (net, key), (off, _) in m.offsets.items())
+
+
 def _small_params(seed):
     from oracle import learn as OL
 
@@ -46,12 +69,21 @@ def _worker(rank, world, port, tmp):
     flat = torch.cat([g.reshape(-1) for g in grads])
     flat_b = flat.clone()
     D.all_reduce_mean_(flat)
-    # the agent's exchange: one asynchronous bucket per net, started in turn, one wait, one scale (add_agent._update_model)
-    third = flat_b.numel() // 3
-    cuts = [0, third, 2 * third, flat_b.numel()]
-    pending = [D.all_reduce_sum_async(flat_b[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    # the agent's exchange (add_agent._run_update_sections): the product's own flat layout and bucket ranges, one asynchronous
+    # all-reduce per bucket in the order the buckets become final, one wait
+    from add_gym_amd.learning.model import Model
+
+    pm = Model(MODEL_CFG, 264, 272, 114, 128, torch.device("cpu"))
+    pm.load({n: g for n, g in zip(names, grads)}, pm.grads)
+    ref_flat = pm.grads.clone()
+    D.all_reduce_mean_(ref_flat)
+    br = pm.bucket_ranges
+    pending = [D.all_reduce_sum_async(pm.grads[a:b]) for a, b in (br["actor_tail"], br["critic_tail"], br["disc"], br["first_layers"])]
     D.wait_all(pending)
-    flat_b.mul_(1.0 / world)
+    pm.grads.mul_(1.0 / world)
+    ex = pm.export(pm.grads)
+    flat_b = torch.cat([ex[n].reshape(-1) for n in names])  # back to the oracle's tensor order
+    bucket_ok = bool(torch.equal(pm.grads, ref_flat))
     # normaliser sums
     x = torch.tensor(rng.standard_normal((2, 50, 9)).astype(np.float32))[rank]
     s1, s2 = x.sum(0), (x * x).sum(0)
@@ -59,7 +91,7 @@ def _worker(rank, world, port, tmp):
     b = torch.full((5,), float(rank))
     D.broadcast_(b, 0)
     if rank == 0:
-        torch.save(dict(flat=flat, flat_b=flat_b, s1=s1, s2=s2, w=w, b=b), tmp)
+        torch.save(dict(flat=flat, flat_b=flat_b, bucket_ok=bucket_ok, s1=s1, s2=s2, w=w, b=b), tmp)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -86,7 +118,8 @@ def test_two_rank_gradient_mean_and_normaliser_sums(tmp_path):
     # the zero-difference "positive" sample enters every rank's loss once: mean over ranks == single-process value as well
     scale = ref.abs().max()
     assert (got["flat"] - ref).abs().max() <= 2e-5 * scale
-    assert torch.equal(got["flat_b"], got["flat"])  # bucketed asynchronous exchange == one flat all-reduce
+    assert got["bucket_ok"]                          # bucketed asynchronous exchange of the product's ranges == one flat all-reduce
+    assert torch.equal(got["flat_b"], got["flat"])  # ... and, read back by tensor name, == the mean of the oracle's gradients
     x = torch.tensor(rng.standard_normal((2, 50, 9)).astype(np.float32)).reshape(100, 9)
     assert got["w"] == 2
     torch.testing.assert_close(got["s1"], x.sum(0), rtol=1e-5, atol=1e-5)

@@ -45,13 +45,23 @@ def T(x, dtype=None):
     return torch.tensor(np.ascontiguousarray(x), dtype=dtype, device="cuda")
 
 
-def test_minibatch_loss_gradients_and_adamw_match_reference():
+PRECISIONS = ["fp32", "bf16x3", "bf16x2"]  # agent.matmul_precision product modes with fp32-class error bounds (include/addhip.h)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_minibatch_loss_gradients_and_adamw_match_reference(precision):
+    minibatch_loss_gradients_and_adamw(precision)
+
+
+def minibatch_loss_gradients_and_adamw(precision="fp32"):
+    """(At this fixture's 256 rows every GEMM is below the size from which the bf16-MFMA kernels are dispatched, so the three
+    modes run the same kernels here; the modes themselves are pinned at full size in tests/test_hip_fullsize.py.)"""
     import torch
     import add_gym_amd._lib as L
 
     g = gload("losses")
     M = g["in.obs"].shape[0]
-    cfg = make_cfg(M // 4, steps_per_iter=8)
+    cfg = make_cfg(M // 4, steps_per_iter=8, matmul_precision=precision)
     ag = make_agent(cfg, [gload("motion_small")["frames"]], [1.0])
     assert ag.Mb == M
     params = OL.synth_params(int(g["seed"]))
@@ -142,7 +152,8 @@ def _mid(cdf, k):
     return F(0.5 * (lo + float(cdf[k])))
 
 
-def test_one_full_iteration_matches_reference_and_oracle():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_one_full_iteration_matches_reference_and_oracle(precision):
     """BASELINE config 1 stand-in: the reference's own iteration (fake kinematic engine, recorded draws) replayed
     through the HIP engine."""
     import torch
@@ -152,7 +163,7 @@ def test_one_full_iteration_matches_reference_and_oracle():
 
     g = gload("loop_1iter")
     Tn, n = g["noise"].shape[:2]
-    cfg = make_cfg(n, steps_per_iter=Tn)
+    cfg = make_cfg(n, steps_per_iter=Tn, matmul_precision=precision)
     ag = make_agent(cfg, [gload("motion_small")["frames"]], [1.0])
     ag._model.load({k: torch.tensor(v) for k, v in OL.synth_params(int(g["seed"])).items()})
 
@@ -176,13 +187,13 @@ def test_one_full_iteration_matches_reference_and_oracle():
             u[2, e] = draw["jitter"][j]
         return T(u)
 
-    inj_u = {0: uniforms(np.arange(n), init)}
+    inj_u = {ag.stream_reset_all(0): uniforms(np.arange(n), init)}
     orc.init(init)
     orc_info = orc.train_iter(LP.Draws(g["noise"], resets, g["perms"]), [(plan[t] >= 0) for t in range(Tn)])
     for t in range(Tn):
         ids = np.nonzero(orc.buf["done"][t] != 0)[0]
         # sampler errors do not change during the rollout, so probabilities computed after the fact are the ones in effect
-        inj_u[(0 * Tn + t) * 2 + 1] = uniforms(ids, resets[t])
+        inj_u[ag.stream_train_reset(0 * Tn + t)] = uniforms(ids, resets[t])
     # the oracle updated its sampler errors at the end of the iteration; the draws above must use the initial (all-ones) table
     assert np.all(g["reset_count"] == [(orc.buf["done"][t] != 0).sum() for t in range(Tn)])
 
@@ -194,7 +205,7 @@ def test_one_full_iteration_matches_reference_and_oracle():
 
     perms = iter([torch.tensor(p) for p in g["perms"]])
     ag.inject = dict(noise=T(g["noise"]), uniforms=inj_u, perms=perms, pre_step=pre_step)
-    ag.reset_all_envs(tag=0)
+    ag.reset_all_envs()
     ag._init_train()
     info = ag._train_iter()
     torch.cuda.synchronize()
@@ -244,6 +255,20 @@ def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
         assert tuple(ck["model"][n].shape) == shape, n
     assert {"_obs_norm._count", "_obs_norm._mean", "_obs_norm._std", "_a_norm._mean", "_disc_obs_norm._mean_abs", "_model._action_dist._logstd_net"} <= set(ck["model"])
     assert len(ck["optimizer"]["state"]) == 22
+    # ... and against the reference agent's own checkpoint (fixture generated from the imported reference): every tensor name,
+    # shape and dtype of state_dict(), the optimizer state layout and its param-group keys
+    import json
+
+    meta = json.loads(bytes(gload("state_dict")["meta"]).decode())
+    assert [k for k, _, _ in meta["model"]] == list(ck["model"].keys())  # same names in the same order
+    for k, shape, dt in meta["model"]:
+        assert list(ck["model"][k].shape) == shape and str(ck["model"][k].dtype) == dt, k
+    for i, st in meta["opt_state"]:
+        got = ck["optimizer"]["state"][i]
+        assert set(got) == set(st) and list(got["exp_avg"].shape) == st["exp_avg"] and list(got["exp_avg_sq"].shape) == st["exp_avg_sq"], i
+        assert got["step"].shape == torch.Size([])
+    assert set(ck["optimizer"]["param_groups"][0]) == set(meta["opt_group"])
+    assert sorted(ck) == meta["top"] and type(ck["iter"]).__name__ == meta["iter_type"] and type(ck["sample_count"]).__name__ == meta["sample_count_type"]
     before = ag._model.params.clone()
     ag._model.params.zero_()
     ag.load(path)
@@ -300,8 +325,9 @@ def test_foreign_engine_slow_path_matches_in_place_path():
 
 
 def test_test_model_runs_episode_quota_with_deterministic_policy():
+    """Corrected mode (task.reference_compat=false): fresh reset of all envs, ceil(n / num_envs) episodes per env."""
     cfg = make_cfg(64, steps_per_iter=8)
-    cfg["task"]["motion_file"] = "synthetic:1x90"  # 3 s clip -> episodes end (SUCC) within 300 steps
+    cfg["task"].update(motion_file="synthetic:1x90", reference_compat=False)  # 3 s clip -> episodes end (SUCC) within 300 steps
     import add_gym_amd.learning.add_agent as A
 
     ag = A.ADDAgent(cfg)
@@ -309,6 +335,67 @@ def test_test_model_runs_episode_quota_with_deterministic_policy():
     assert info["num_eps"] >= 128
     assert 0 < info["mean_ep_len"] <= 300 and np.isfinite(info["mean_return"])
     assert ag._mode == A.AgentMode.TRAIN
+
+
+def test_test_model_matches_the_reference_rollout():
+    """BaseAgent.test_model / _rollout_test (base_agent.py:116-126, 393-425) replayed with the reference's recorded reset draws
+    (fixture test_rollout.npz, generated from the imported reference on its fake engine): the same number of steps, bit-identical
+    done flags for every env and step, per-step rewards, mean return / episode length / episode count.  Includes the
+    reference's TEST-mode behaviour: only env 0 is reset at the start, every env runs `num_episodes` episodes."""
+    import torch
+
+    g = gload("test_rollout")
+    n, episodes, steps = int(g["num_envs"]), int(g["episodes"]), int(g["steps"])
+    cfg = make_cfg(n, steps_per_iter=8)
+    ag = make_agent(cfg, [gload("motion_small")["frames"][:int(g["clip_frames"])]], [1.0])
+    ag._model.load({k: torch.tensor(v) for k, v in OL.synth_params(int(g["seed"])).items()})
+    probs = np.full(20, 1.0 / 20, F)  # sampler errors are all ones: uniform segment probabilities (sampler.py:57-73)
+    cdf = np.cumsum(probs)
+
+    def uniforms(env_ids, segs, jit):
+        u = np.zeros((3, n), F)
+        for j, e in enumerate(env_ids):
+            u[0, e], u[1, e], u[2, e] = 0.5, _mid(cdf, int(segs[j])), jit[j]
+        return T(u)
+
+    done_ref = g["done"]
+    inj = {ag.stream_reset_all(0): uniforms(np.arange(n), g["init_segments"], g["init_jitter"]),
+           ag.stream_test_reset_all(0): uniforms([0], g["first_segments"], g["first_jitter"])}
+    for t in range(steps):
+        k = int(g["reset_count"][t])
+        inj[ag.stream_test_reset(0, t)] = uniforms(np.nonzero(done_ref[t] != 0)[0], g["reset_segments"][t, :k], g["reset_jitter"][t, :k])
+    for t in range(steps, steps + 64):  # (only reached if the rollout ran longer than the reference's: fails below)
+        inj[ag.stream_test_reset(0, t)] = uniforms([], [], [])
+    dones, ep = [], {}
+    # record done flags per step: the reset kernel clears them, so snapshot between the step and the reset
+    orig_reset = ag._reset_envs
+
+    def reset_spy(reset_all, *a):
+        if not reset_all and len(dones) < steps + 64 and ep.get("live"):
+            dones.append(ag._S["done"].clone())
+        return orig_reset(reset_all, *a)
+
+    ag._reset_envs = reset_spy
+    ag.inject = dict(uniforms=inj)
+    ag.reset_all_envs()      # train_model's reset before the loop (TRAIN mode: all envs)
+    ag._init_train()
+    ep["live"] = False
+    # the first masked reset inside test_model is the "reset env 0" one: start recording after it
+    orig_decide = ag._decide_action
+
+    def decide_spy(*a):
+        ep["live"] = True
+        return orig_decide(*a)
+
+    ag._decide_action = decide_spy
+    info = ag.test_model(episodes)
+    torch.cuda.synchronize()
+    got = torch.stack(dones).cpu().numpy()
+    assert ag._test_steps == steps
+    assert np.array_equal(got, done_ref)
+    assert info["num_eps"] == int(g["num_eps"])
+    np.testing.assert_allclose(info["mean_ep_len"], float(g["mean_ep_len"]), rtol=1e-6)
+    np.testing.assert_allclose(info["mean_return"], float(g["mean_return"]), rtol=2e-5)
 
 
 def test_multi_clip_library_and_corrected_offsets():

@@ -1,0 +1,186 @@
+"""Full-size agent-level parity on the GPU (BASELINE configs[1] and configs[2] shapes):
+
+* the recorded update plan of a 4096-env agent (16 384-row minibatch: split-K slabs, ReLU sign bits, the three-stream
+  schedule, the Mb+1 row-chunk split) run once, all 22 parameter gradients against the CPU oracle's autograd
+  (oracle.learn.compute_loss; restates ppo_agent.py:171-275 and add_agent.py:141-202), under every matmul precision;
+* one rollout + build-train-data of a 16 384-env agent on a 5-clip library under bf16x3, a 256-env subset compared with
+  oracle/loop.py run on exactly those envs with the same draws (obs / reward / done / clocks / TD(lambda) targets).
+"""
+import numpy as np
+import pytest
+
+from oracle import learn as OL
+from tests.test_hip_agent import T, make_cfg
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+# gradient tolerance per precision, as a fraction of each tensor's largest gradient element: the fp32 MFMA and the exact
+# bf16x3 split share the fp32 bound (summation order only); bf16x2 keeps 16 significant bits per operand (2^-15 |a||b| per
+# product); plain bf16 operands (8 bits) are checked in the aggregate (relative L2 error), not element by element
+GRAD_TOL = {"fp32": 2e-4, "bf16x3": 2e-4, "bf16x2": 1.5e-3}
+
+
+def _fill_minibatch(ag, model, seed):
+    """A plausible minibatch written straight into the agent's gathered-minibatch buffers; returns the oracle's view."""
+    rng = np.random.RandomState(seed)
+    M = ag.Mb
+    obs = rng.standard_normal((M, 264)).astype(F)
+    import torch
+
+    with torch.no_grad():
+        mean = model.actor_mean(OL.t32(obs))
+        act = (mean + 0.05 * torch.tensor(rng.standard_normal((M, 29)).astype(F))).numpy()
+        logp = model.log_prob(mean, OL.t32(act)).numpy()
+    mb = dict(norm_obs=obs, norm_action=act, a_logp=(logp + 0.1 * rng.standard_normal(M)).astype(F),
+              adv=np.clip(rng.standard_normal(M), -4, 4).astype(F), tar_val=rng.standard_normal(M).astype(F),
+              rand_action_mask=(rng.rand(M) < 0.95).astype(F), norm_diff=(0.5 * rng.standard_normal((M, 114))).astype(F))
+    W = ag._W
+    W["norm_obs"].zero_()
+    W["norm_obs"][:, :264] = T(mb["norm_obs"])
+    W["norm_act"].zero_()
+    W["norm_act"][:, :29] = T(mb["norm_action"])
+    W["mb_logp"].copy_(T(mb["a_logp"]))
+    W["mb_adv"].copy_(T(mb["adv"]))
+    W["mb_tar"].copy_(T(mb["tar_val"]))
+    W["mb_mask"].copy_(T(mb["rand_action_mask"]))
+    W["norm_diff"].zero_()
+    W["norm_diff"][:M, :114] = T(mb["norm_diff"])
+    return mb
+
+
+_ORACLE_GRADS = {}  # CPU autograd gradients of the minibatch, shared by the precision parametrisation
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x2"])
+def test_update_plan_at_4096_envs_all_gradients_match_oracle(precision):
+    import torch
+    import add_gym_amd.learning.add_agent as A
+
+    cfg = make_cfg(4096, steps_per_iter=32, matmul_precision=precision)
+    cfg["task"]["motion_file"] = "synthetic:1x300"
+    ag = A.ADDAgent(cfg)
+    assert ag.Mb == 16384
+    seed = 11
+    params = OL.synth_params(seed)
+    ag._model.load({k: torch.tensor(v) for k, v in params.items()})
+    if hasattr(ag._model, "refresh_shadow"):
+        ag._model.refresh_shadow()
+    torch.set_num_threads(16)
+    model = OL.Model(params)
+    mb = _fill_minibatch(ag, model, 5)
+    ag._W["stats"].zero_()
+    ag._run_update_sections()  # zero_grad + the actor / critic / discriminator sections on their three streams
+    torch.cuda.synchronize()
+    m = ag._model
+    grads_hip = {k: v.numpy() for k, v in m.export(m.grads).items() if k != "_model._action_dist._logstd_net"}
+    key = ("grads", seed)
+    if key not in _ORACLE_GRADS:
+        loss, info = OL.compute_loss(model, OL.LossCfg(), mb)
+        names = model.names()
+        gs = torch.autograd.grad(loss, [model.p[n] for n in names])
+        _ORACLE_GRADS[key] = ({n: g.numpy() for n, g in zip(names, gs)}, info)
+    grads_orc, info = _ORACLE_GRADS[key]
+    assert set(grads_orc) == set(grads_hip) and len(grads_orc) == 22
+    for k, go in grads_orc.items():
+        gh = grads_hip[k]
+        scale = np.abs(go).max() + 1e-12
+        if precision == "bf16":
+            rel = np.linalg.norm((gh - go).ravel()) / (np.linalg.norm(go.ravel()) + 1e-30)
+            assert rel <= 3e-2, (k, float(rel))
+        else:
+            err = np.abs(gh - go).max()
+            assert err <= GRAD_TOL[precision] * scale + 1e-9, (precision, k, float(err), float(scale))
+    # logged scalars of the step
+    ag._total_samples = ag.T * ag.N
+    stats = ag._collect_info(1)
+    tol = 2e-2 if precision == "bf16" else 1e-3
+    for k in ("critic_loss", "actor_loss", "disc_loss", "disc_grad_penalty", "disc_logit_loss", "disc_neg_logit", "clip_frac", "imp_ratio"):
+        np.testing.assert_allclose(stats[k], info[k], rtol=tol, atol=tol, err_msg=k)
+    # padded rows / columns of the device layout never receive gradient
+    assert float(m.view("actor", "Wh", m.grads)[29:].abs().max()) == 0
+    assert float(m.view("disc", "W0", m.grads)[:, 114:].abs().max()) == 0
+    assert float(m.view("actor", "W0", m.grads)[:, 264:].abs().max()) == 0
+
+
+def test_16384_envs_five_clips_bf16x3_subset_matches_oracle():
+    """BASELINE configs[2] composition: 16 384 envs, a multi-clip library (reference-compatible raw-frame offsets),
+    agent.matmul_precision=bf16x3, one rollout + build-train-data; envs 0, 64, 128, ... (256 of them) against the oracle."""
+    import torch
+    import add_gym_amd.learning.add_agent as A
+    from oracle import loop as LP
+    from oracle import task as OT
+    from oracle.motion import MotionLib as OracleLib
+    from tests.util import oracle_kin
+    from add_gym_amd.anim.synth import synth_clip
+
+    N, Tn, C, NF = 16384, 32, 5, 240
+    cfg = make_cfg(N, steps_per_iter=Tn, matmul_precision="bf16x3")
+    cfg["task"]["motion_file"] = f"synthetic:{C}x{NF}"
+    ag = A.ADDAgent(cfg)
+    seed = 21
+    params = OL.synth_params(seed)
+    ag._model.load({k: torch.tensor(v) for k, v in params.items()})
+    lib_p = ag._motion_lib
+    order = list(cfg["task"]["motion_joint_order"])
+    kin_p = ag._env.robot._kin_char_model
+    frames = [synth_clip(kin_p, order, c, NF) for c in range(C)]
+    lib = OracleLib(frames, [1.0] * C, order, oracle_kin(), 0.01, True)
+    # identical table rows on both sides (the product's host ingest is pinned bit for bit in tests/test_host_ingest.py)
+    hp, hv = lib_p.host_pose.numpy(), lib_p.host_vel.numpy()
+    lib.step = dict(root_pos=hp[:, 0:3].copy(), root_rot=hp[:, 3:7].copy(), dof_pos=hp[:, 7:36].copy(), root_vel=hv[:, 0:3].copy(),
+                    root_ang_vel=hv[:, 3:6].copy(), dof_vel=hv[:, 6:35].copy())
+    assert lib.total_steps == lib_p.total_steps
+
+    rng = np.random.RandomState(4)
+    sub = np.arange(0, N, 64)
+    n = len(sub)
+    # draws for every env and step: clip, segment, jitter (consumed only where a reset happens)
+    clip = rng.randint(0, C, (Tn + 1, N))
+    seg = rng.randint(0, 20, (Tn + 1, N))
+    jit = rng.rand(Tn + 1, N).astype(F)
+    noise = rng.standard_normal((Tn, N, 29)).astype(F)
+    cdf = np.cumsum(np.full(C, 1.0 / C, F), dtype=F)
+    u_clip = np.where(clip == 0, 0.5 * cdf[0], 0.5 * (cdf[np.maximum(clip - 1, 0)] + cdf[clip])).astype(F)
+    u_seg = ((seg + 0.5) / 20.0).astype(F)  # sampler errors are all ones during the first iteration: uniform segments
+
+    def uni(k):
+        return T(np.stack([u_clip[k], u_seg[k], jit[k]]))
+
+    inj = {ag.stream_reset_all(0): uni(0)}
+    for t in range(Tn):
+        inj[ag.stream_train_reset(t)] = uni(t + 1)
+    ag.inject = dict(noise=T(noise), uniforms=inj)
+    ag.reset_all_envs()
+    ag._init_train()
+    ag._rollout_train()
+    ag._build_train_data()
+    torch.cuda.synchronize()
+
+    orc = LP.Agent(LP.AgentCfg(steps_per_iter=Tn), OT.TaskCfg(), lib, n, params)
+    orc.init(dict(ids=clip[0][sub], segments=seg[0][sub], jitter=jit[0][sub]))
+    draws = LP.Draws(noise[:, sub], lambda t, ids: dict(ids=clip[t + 1][sub[ids]], segments=seg[t + 1][sub[ids]], jitter=jit[t + 1][sub[ids]]), None)
+    orc.rollout(draws)
+    ob = orc.buf
+    task_reward = ob["reward"].copy()
+    orc.build_train_data()
+    B = ag._B
+    s = torch.tensor(sub, device="cuda")
+    done = B["done"][:, s].cpu().numpy()
+    assert np.array_equal(done, ob["done"])  # bit-exact flags over the whole rollout of the subset
+    assert (done != 0).sum() > 50 and len(np.unique(done)) >= 3
+    assert np.array_equal(B["motion_time"][:, s].cpu().numpy(), ob["motion_times"])  # bit-exact clocks / reset start times
+    assert np.array_equal(B["motion_id"][:, s].cpu().numpy(), ob["motion_ids"])
+    obs = B["obs"][:, s].cpu().numpy()
+    np.testing.assert_allclose(obs[:Tn, :, :264], ob["obs"], rtol=0, atol=5e-5)
+    # next_obs[t] is obs[t+1] wherever the env was not reset at step t
+    keep = done == 0
+    np.testing.assert_allclose(obs[1:, :, :264][keep], ob["next_obs"][keep], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(B["disc_obs"][:Tn, s].cpu().numpy()[..., :114], ob["disc_obs"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(B["disc_demo"][:Tn, s].cpu().numpy()[..., :114], ob["disc_obs_demo"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(B["action"][:Tn, s].cpu().numpy()[..., :29], ob["action"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(B["a_logp"][:Tn, s].cpu().numpy(), ob["a_logp"], rtol=1e-4, atol=1e-3)
+    # after build-train-data the reward buffer holds the discriminator reward (task_reward_weight 0), tar_val the TD(lambda) target
+    np.testing.assert_allclose(B["reward"][:, s].cpu().numpy(), ob["reward"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(B["tar_val"][:, s].cpu().numpy(), ob["tar_val"], rtol=2e-3, atol=2e-3)
+    assert np.isfinite(task_reward).all()

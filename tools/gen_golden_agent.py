@@ -436,5 +436,124 @@ def gen_loop_1iter():
     _save("loop_1iter", **out)
 
 
-AGENT_GENS = dict(obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
+def gen_logger():
+    """log.txt bytes and console lines of the reference's Logger / TBLogger (util/logger.py, util/tb_logger.py) for a fixed set of
+    rows with the value types BaseAgent._log_train_info produces (ints for Iteration / Samples / *_Episodes, floats otherwise)."""
+    import contextlib
+    import io
+    import json
+    import tempfile
+
+    from add_gym.util import tb_logger
+
+    rows = [
+        [("Iteration", 0, "1_Info", False), ("Wall_Time", 0.00012345678, "1_Info", False), ("Samples", 131072, "1_Info", False),
+         ("Test_Return", 0.0, "0_Main", False), ("Test_Episode_Length", 0.0, "0_Main", True), ("Test_Episodes", 0, "1_Info", True),
+         ("Train_Return", 12.3456789012, "0_Main", False), ("Train_Episode_Length", 33.25, "0_Main", True), ("Train_Episodes", 417, "1_Info", True),
+         ("Loss", -0.00123456789, None, False), ("Clip_Frac", 1e-05, None, False), ("Disc_Pos_Acc", 1.0, None, False), ("Exp_Prob", 1.0, None, False)],
+        [("Iteration", 100, "1_Info", False), ("Wall_Time", 1.5, "1_Info", False), ("Samples", 13238272, "1_Info", False),
+         ("Test_Return", 123456.789, "0_Main", False), ("Test_Episode_Length", 1999.5, "0_Main", True), ("Test_Episodes", 4096, "1_Info", True),
+         ("Train_Return", 1e-12, "0_Main", False), ("Train_Episode_Length", 2000.0, "0_Main", True), ("Train_Episodes", 1234567, "1_Info", True),
+         ("Loss", 3.0e+20, None, False), ("Clip_Frac", 0.3333333333333333, None, False), ("Disc_Pos_Acc", 0.5, None, False), ("Exp_Prob", 0.2, None, False)],
+    ]
+    d = tempfile.mkdtemp(prefix="addgym_log_")
+    path = os.path.join(d, "log.txt")
+    lg = tb_logger.TBLogger()
+    lg.set_step_key("Samples")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        lg.configure_output_file(path)
+    console = []
+    for row in rows:
+        for key, val, col, quiet in row:
+            lg.log(key, val, collection=col, quiet=quiet)
+        b = io.StringIO()
+        with contextlib.redirect_stdout(b):
+            lg.print_log()
+        console.append(b.getvalue())
+        lg.write_log()
+    lg.output_file.flush()
+    with open(path, "rb") as f:
+        raw = f.read()
+    tags = lg._build_key_tags()
+    _save("logger", rows=np.frombuffer(json.dumps(rows).encode(), np.uint8), log_txt=np.frombuffer(raw, np.uint8),
+          console=np.frombuffer(json.dumps(console).encode(), np.uint8), tags=np.frombuffer(json.dumps(tags).encode(), np.uint8))
+
+
+def gen_state_dict():
+    """Names, shapes and dtypes of the reference agent's checkpoint: state_dict() (base_agent.py:148-155) and the optimizer's."""
+    import json
+
+    ag, cfg = build_agent(8, clip_frames=60)
+    sd = ag.state_dict()
+    model = [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()]
+    ag._optimizer._optimizer.zero_grad()
+    # one optimiser step so that the AdamW state exists
+    loss = sum((p ** 2).sum() for p in ag._model.parameters() if p.requires_grad)
+    ag._optimizer.step(loss)
+    osd = ag._optimizer._optimizer.state_dict()
+    opt_state = [[int(i), {k: (list(v.shape) if torch.is_tensor(v) else None) for k, v in st.items()}] for i, st in osd["state"].items()]
+    group = {k: (v if not isinstance(v, (list, tuple)) or k == "betas" else len(v)) for k, v in osd["param_groups"][0].items()}
+    import tempfile
+
+    path = os.path.join(tempfile.mkdtemp(prefix="addgym_ck_"), "model.pt")
+    ag.save(path)
+    ck = torch.load(path, weights_only=True)
+    top = sorted(ck.keys())
+    blob = dict(model=model, opt_state=opt_state, opt_group=group, top=top, iter_type=type(ck["iter"]).__name__, sample_count_type=type(ck["sample_count"]).__name__)
+    _save("state_dict", meta=np.frombuffer(json.dumps(blob, default=str).encode(), np.uint8))
+
+
+def gen_test_rollout():
+    """BaseAgent.test_model -> _rollout_test (base_agent.py:116-126, 393-425) on the fake engine, as train_model reaches it on an
+    output iteration: reset of all envs (TRAIN mode), then test_model(n): deterministic (mode) actions, every reset draw
+    recorded.  NB Environment.set_mode(TEST) sets env.num_envs = 1 (envs/env.py:142-148), so (i) the reset at the start of
+    test_model touches env 0 only and (ii) the quota is ceil(n / 1) = n finished episodes for EVERY env."""
+    n, episodes = 16, 3
+    ag, cfg = build_agent(n, clip_frames=40, seed=9)  # 1.3 s clip: episodes end by SUCC after at most ~130 steps
+    load_synth(ag, 404)
+    log0 = DrawLog()
+    with log0.recording():
+        ag._curr_obs, ag._curr_info = ag._reset_envs()
+    dones, rewards = [], []
+    orig_step = ag._step_env
+
+    def step_env(action):
+        out = orig_step(action)
+        rewards.append(out[1].clone())
+        dones.append(out[2].clone())
+        return out
+
+    ag._step_env = step_env
+    log = DrawLog()
+    with log.recording():
+        info = ag.test_model(episodes)
+    calls = log.calls
+    assert [c[0] for c in calls[:3]] == ["multinomial", "multinomial", "rand"] and len(calls[0][1]) == 1
+    first = (calls[0][1], calls[1][1].squeeze(-1), calls[2][1])
+    steps = len(dones)
+    resets, i = [], 3
+    for t in range(steps):
+        k = int((dones[t] != 0).sum())
+        if k > 0:
+            assert calls[i][0] == "multinomial" and len(calls[i][1]) == k
+            resets.append((calls[i][1], calls[i + 1][1].squeeze(-1), calls[i + 2][1]))
+            i += 3
+        else:
+            resets.append((torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), torch.zeros(0)))
+    assert i == len(calls), (i, len(calls))
+    kmax = max(len(r[0]) for r in resets)
+    pad = lambda x, fill, dt: torch.cat([x.to(dt), torch.full((kmax - len(x),), fill, dtype=dt)])
+    _save("test_rollout", seed=404, num_envs=n, episodes=episodes, clip_frames=40, steps=steps,
+          init_ids=log0.take("multinomial")[0], init_segments=log0.take("multinomial")[1].squeeze(-1), init_jitter=log0.take("rand")[0],
+          first_ids=first[0], first_segments=first[1], first_jitter=first[2],
+          reset_count=np.asarray([len(r[0]) for r in resets]),
+          reset_ids=torch.stack([pad(r[0], 0, torch.long) for r in resets]),
+          reset_segments=torch.stack([pad(r[1], 0, torch.long) for r in resets]),
+          reset_jitter=torch.stack([pad(r[2], 0.0, torch.float32) for r in resets]),
+          done=torch.stack(dones), reward=torch.stack(rewards),
+          mean_return=float(info["mean_return"]), mean_ep_len=float(info["mean_ep_len"]), num_eps=int(info["num_eps"]))
+
+
+AGENT_GENS = dict(logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
                   td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
