@@ -67,6 +67,14 @@ class GatherT(C.Structure):
                 ("o_tar_val", f32p), ("o_mask", f32p), ("norm_diff", f32p)]
 
 
+class RigidModelT(C.Structure):
+    _fields_ = [("num_bodies", C.c_int32), ("num_points", C.c_int32), ("body", f32p), ("topo", f32p), ("points", f32p), ("dt", C.c_float),
+                ("substeps", C.c_int32), ("gravity", C.c_float), ("contact_stiffness", C.c_float), ("contact_damping", C.c_float),
+                ("friction", C.c_float), ("friction_vel_eps", C.c_float), ("limit_stiffness", C.c_float), ("max_torque", C.c_float),
+                ("limit_margin", C.c_float), ("termination_mask", C.c_uint32)]
+
+
+RIGID_BODY_W, RIGID_TOPO_W = 32, 8
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
 PREC_F32, PREC_BF16, PREC_BF16X2, PREC_BF16X3 = 0, 1, 2, 3
 
@@ -79,6 +87,7 @@ SIGNATURES = {
     "addhip_env_reset": [P(MotionT), P(TaskT), P(EnvT), P(SamplerT), vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "addhip_motion_lookup": [P(MotionT), vp, vp, i32, vp, vp, vp, vp],
     "addhip_kin_engine_step": [vp, vp, vp, i32, i32, f32, f32, vp],
+    "addhip_rigid_step": [P(RigidModelT), vp, vp, vp, i32, i32, vp, vp, vp],
     "addhip_gemm_f32": [P(GemmT), vp],
     "addhip_slab_reduce": [vp, i32, i64, vp, i64, f32, i32, vp],
     "addhip_col_sum": [vp, i32, i32, i32, vp, f32, i32, vp],
@@ -129,9 +138,9 @@ def load():
     lib.addhip_last_error.restype = C.c_char_p
     lib.addhip_version.restype = C.c_int
     lib.addhip_abi_sizes.argtypes, lib.addhip_abi_sizes.restype = [C.POINTER(C.c_int32), C.c_int32], C.c_int
-    sizes = (C.c_int32 * 7)()
-    mine = [C.sizeof(t) for t in (MotionT, TaskT, EnvT, StepOutT, SamplerT, GemmT, GatherT)]
-    if lib.addhip_abi_sizes(sizes, 7) != 7 or list(sizes) != mine:
+    sizes = (C.c_int32 * 8)()
+    mine = [C.sizeof(t) for t in (MotionT, TaskT, EnvT, StepOutT, SamplerT, GemmT, GatherT, RigidModelT)]
+    if lib.addhip_abi_sizes(sizes, 8) != 8 or list(sizes) != mine:
         raise AddhipError(f"struct layouts of this binding {mine} do not match {LIB_PATH} {list(sizes)}: rebuild the library")
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

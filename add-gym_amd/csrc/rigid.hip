@@ -1,0 +1,461 @@
+// Rigid-body step of the articulated robot behind the engine plugin API (BaseScene.step + BaseEntity.control_dofs_position,
+// add_gym/engine/base_engine.py:93-455): one launch per CONTROL step, `substeps` physics steps inside.
+//
+// The reference delegates this to Genesis / MuJoCo-Warp (engine/genesis_engine.py, engine/mjwarp_engine.py:807-851,
+// 1554-1611); the algorithm here is this repo's own (oracle/rigid.py is its float64 restatement, parity is pinned to that
+// and to physical invariants, not to the reference: DESIGN.md).
+//
+// Per substep h:  articulated-body algorithm (Featherstone) over the kinematic tree with a floating base, in body
+// coordinates, with every stiff term folded into the inertia it acts on so that ONE O(bodies) sweep per substep is stable at
+// millisecond steps and no constraint solver iterates:
+//   * joint PD + damping + armature:  D_i += armature + h (kv + damping) + h^2 kp   (stable PD; plain clamp when saturated)
+//   * ground contacts of the body's collision spheres (spring-damper normal, regularised Coulomb friction), linearly
+//     implicit:  IA_i += J^T (h^2 K + h C) J,   pA_i -= J^T (f0 - h K v_p)
+// then semi-implicit Euler.
+//
+// Mapping to gfx950: one LANE per environment, one 64-lane workgroup per CU.  The tree is walked in depth-first order, so
+// the inward pass only ever holds the current chain's articulated inertia in registers plus one accumulator per BRANCH body
+// (pelvis, torso) in LDS.  Every lane of a wave visits the same body at the same time: body constants and the traversal
+// tables are wave-uniform scalar loads, LDS arrays are [field][lane] (conflict-free), the state rows are staged through LDS
+// with coalesced loads/stores.  Per-lane LDS: pose 36 + velocity 36 + target 32 + sin/cos 64 + U 192 + 1/D, u 64 +
+// 4 branch accumulators x 27 floats = 532 floats (133 KB per workgroup); body velocities / up-vectors live in private (scratch)
+// arrays that stay in L2.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXB = 32;       // bodies
+constexpr int WG = 64;         // environments (lanes) per workgroup
+constexpr int BW = ADDHIP_RIGID_BODY_W;
+constexpr int TW = ADDHIP_RIGID_TOPO_W;
+constexpr int MAX_SLOTS = 4;   // branch bodies (more than one child)
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+// general 3x3, row major
+struct M3 { float m[9]; };
+// symmetric 3x3: xx xy xz yy yz zz
+struct S3 { float xx, xy, xz, yy, yz, zz; };
+
+__device__ __forceinline__ V3 mul(const M3& a, V3 v) {
+  return {a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z, a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z};
+}
+__device__ __forceinline__ V3 mulT(const M3& a, V3 v) {
+  return {a.m[0] * v.x + a.m[3] * v.y + a.m[6] * v.z, a.m[1] * v.x + a.m[4] * v.y + a.m[7] * v.z, a.m[2] * v.x + a.m[5] * v.y + a.m[8] * v.z};
+}
+__device__ __forceinline__ V3 mul(const S3& a, V3 v) {
+  return {a.xx * v.x + a.xy * v.y + a.xz * v.z, a.xy * v.x + a.yy * v.y + a.yz * v.z, a.xz * v.x + a.yz * v.y + a.zz * v.z};
+}
+__device__ __forceinline__ M3 matmul(const M3& a, const M3& b) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+  return r;
+}
+__device__ __forceinline__ M3 transpose(const M3& a) { return {{a.m[0], a.m[3], a.m[6], a.m[1], a.m[4], a.m[7], a.m[2], a.m[5], a.m[8]}}; }
+__device__ __forceinline__ M3 full(const S3& s) { return {{s.xx, s.xy, s.xz, s.xy, s.yy, s.yz, s.xz, s.yz, s.zz}}; }
+// skew(r) * M   (rows: r x (column-wise))
+__device__ __forceinline__ M3 skew_mul(V3 r, const M3& a) {
+  M3 o;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const V3 c = cross(r, V3{a.m[j], a.m[3 + j], a.m[6 + j]});
+    o.m[j] = c.x; o.m[3 + j] = c.y; o.m[6 + j] = c.z;
+  }
+  return o;
+}
+// M * skew(r)   (row i of the result = row_i(M) x r ... as  (row x r)?  row * skew(r) = -(r x row)^T = (row x r)
+__device__ __forceinline__ M3 mul_skew(const M3& a, V3 r) {
+  M3 o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const V3 c = cross(V3{a.m[3 * i], a.m[3 * i + 1], a.m[3 * i + 2]}, r);
+    // (row * skew(r))_j = sum_k row_k skew(r)_{kj};  skew(r) v = r x v  =>  row * skew(r) = (skew(r)^T row)^T = -(r x row) = row x r
+    o.m[3 * i] = c.x; o.m[3 * i + 1] = c.y; o.m[3 * i + 2] = c.z;
+  }
+  return o;
+}
+// R S R^T for symmetric S (result symmetric)
+__device__ __forceinline__ S3 rot_sym(const M3& R, const S3& s) {
+  const M3 t = matmul(R, full(s));
+  S3 o;
+  o.xx = t.m[0] * R.m[0] + t.m[1] * R.m[1] + t.m[2] * R.m[2];
+  o.xy = t.m[0] * R.m[3] + t.m[1] * R.m[4] + t.m[2] * R.m[5];
+  o.xz = t.m[0] * R.m[6] + t.m[1] * R.m[7] + t.m[2] * R.m[8];
+  o.yy = t.m[3] * R.m[3] + t.m[4] * R.m[4] + t.m[5] * R.m[5];
+  o.yz = t.m[3] * R.m[6] + t.m[4] * R.m[7] + t.m[5] * R.m[8];
+  o.zz = t.m[6] * R.m[6] + t.m[7] * R.m[7] + t.m[8] * R.m[8];
+  return o;
+}
+
+// articulated inertia [[A, B], [B^T, C]] (A, C symmetric) and bias force [n; f]
+struct ArtI { S3 A; M3 B; S3 C; };
+struct Sp6 { V3 a, l; };  // angular / linear part of a spatial vector
+
+__device__ __forceinline__ float comp(V3 v, int ax) { return ax == 0 ? v.x : (ax == 1 ? v.y : v.z); }
+__device__ __forceinline__ V3 unit(int ax) { return {ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f}; }
+
+// child -> parent rotation  R = Rfix * Rot(axis, theta)
+__device__ __forceinline__ M3 joint_rot(const float* __restrict__ rf, int ax, float s, float c) {
+  M3 R;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float a = rf[3 * i], b = rf[3 * i + 1], d = rf[3 * i + 2];
+    if (ax == 0) { R.m[3 * i] = a; R.m[3 * i + 1] = c * b + s * d; R.m[3 * i + 2] = c * d - s * b; }
+    else if (ax == 1) { R.m[3 * i] = c * a - s * d; R.m[3 * i + 1] = b; R.m[3 * i + 2] = s * a + c * d; }
+    else { R.m[3 * i] = c * a + s * b; R.m[3 * i + 1] = c * b - s * a; R.m[3 * i + 2] = d; }
+  }
+  return R;
+}
+
+// LDS field offsets (floats per lane)
+constexpr int F_POSE = 0, F_VEL = 36, F_TGT = 72, F_SIN = 104, F_COS = 136, F_U = 168, F_DINV = 360, F_UU = 392, F_SLOT = 424;
+constexpr int F_TOTAL = F_SLOT + MAX_SLOTS * 27;
+
+__device__ __forceinline__ void store_art(float* p, const ArtI& I, const Sp6& f) {  // p points at lds[...][lane], stride WG
+  const float v[27] = {I.A.xx, I.A.xy, I.A.xz, I.A.yy, I.A.yz, I.A.zz, I.B.m[0], I.B.m[1], I.B.m[2], I.B.m[3], I.B.m[4], I.B.m[5], I.B.m[6], I.B.m[7], I.B.m[8],
+                       I.C.xx, I.C.xy, I.C.xz, I.C.yy, I.C.yz, I.C.zz, f.a.x, f.a.y, f.a.z, f.l.x, f.l.y, f.l.z};
+#pragma unroll
+  for (int i = 0; i < 27; ++i) p[i * WG] = v[i];
+}
+__device__ __forceinline__ void add_art(const float* p, ArtI& I, Sp6& f) {
+  I.A.xx += p[0]; I.A.xy += p[WG]; I.A.xz += p[2 * WG]; I.A.yy += p[3 * WG]; I.A.yz += p[4 * WG]; I.A.zz += p[5 * WG];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) I.B.m[i] += p[(6 + i) * WG];
+  I.C.xx += p[15 * WG]; I.C.xy += p[16 * WG]; I.C.xz += p[17 * WG]; I.C.yy += p[18 * WG]; I.C.yz += p[19 * WG]; I.C.zz += p[20 * WG];
+  f.a.x += p[21 * WG]; f.a.y += p[22 * WG]; f.a.z += p[23 * WG]; f.l.x += p[24 * WG]; f.l.y += p[25 * WG]; f.l.z += p[26 * WG];
+}
+
+__global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, float* __restrict__ sim_pose, float* __restrict__ sim_vel,
+                                                        const float* __restrict__ target, int tstride, int n, unsigned char* __restrict__ contact_flag,
+                                                        unsigned* __restrict__ contact_bits) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int env0 = blockIdx.x * WG;
+  const int env = env0 + lane;
+  const int live = min(WG, n - env0);
+#define LD(f, i) lds[((f) + (i)) * WG + lane]
+
+  // ---- stage the state rows through LDS: coalesced global access, [field][lane] in LDS
+  for (int idx = lane; idx < live * 36; idx += WG) {
+    const int row = idx / 36, col = idx - row * 36;
+    lds[(F_POSE + col) * WG + row] = sim_pose[(size_t)env0 * 36 + idx];
+    lds[(F_VEL + col) * WG + row] = sim_vel[(size_t)env0 * 36 + idx];
+  }
+  for (int idx = lane; idx < live * 32; idx += WG) {
+    const int row = idx >> 5, col = idx & 31;
+    lds[(F_TGT + col) * WG + row] = col < 29 ? target[(size_t)(env0 + row) * tstride + col] : 0.f;
+  }
+  __syncthreads();
+  const bool on = lane < live;  // lanes past the last env run on zeros (kept in step: no divergence, never written back)
+  if (!on) {
+    for (int c = 0; c < 36; ++c) { LD(F_POSE, c) = (c == 3) ? 1.f : 0.f; LD(F_VEL, c) = 0.f; }
+    LD(F_POSE, 2) = 10.f;
+    for (int c = 0; c < 32; ++c) LD(F_TGT, c) = 0.f;
+  }
+
+  const int nb = M.num_bodies;
+  const float h = M.dt / (float)M.substeps;
+  const float kc = M.contact_stiffness, cn = M.contact_damping, mu = M.friction, veps = M.friction_vel_eps;
+  // private per-body arrays (scratch): spatial velocity, then (pass 3) spatial acceleration; world up-vector in body coords; height
+  float bv[MAXB][6], bnz[MAXB][3], bh[MAXB];
+  unsigned touch = 0;
+
+  V3 pos{LD(F_POSE, 0), LD(F_POSE, 1), LD(F_POSE, 2)};
+  float qw = LD(F_POSE, 3), qx = LD(F_POSE, 4), qy = LD(F_POSE, 5), qz = LD(F_POSE, 6);
+  V3 vw{LD(F_VEL, 0), LD(F_VEL, 1), LD(F_VEL, 2)}, ww{LD(F_VEL, 3), LD(F_VEL, 4), LD(F_VEL, 5)};
+
+  for (int sub = 0; sub < M.substeps; ++sub) {
+    touch = 0;
+    // root rotation (body -> world)
+    M3 R0 = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+              2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
+              2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)}};
+    // ---------------- pass 1 (outward): velocities, up-vector, height
+    {
+      const V3 w0 = mulT(R0, ww), v0 = mulT(R0, vw);
+      bv[0][0] = w0.x; bv[0][1] = w0.y; bv[0][2] = w0.z; bv[0][3] = v0.x; bv[0][4] = v0.y; bv[0][5] = v0.z;
+      bnz[0][0] = R0.m[6]; bnz[0][1] = R0.m[7]; bnz[0][2] = R0.m[8];
+      bh[0] = pos.z;
+    }
+    for (int k = 1; k < nb; ++k) {
+      const float* __restrict__ bc = M.body + k * BW;
+      const int* __restrict__ tp = M.topo + k * TW;
+      const int par = tp[0], ax = tp[1], dof = tp[2];
+      const float q = LD(F_POSE, 7 + dof), qd = LD(F_VEL, 6 + dof);
+      float s, c;
+      sincosf(q, &s, &c);
+      LD(F_SIN, k) = s; LD(F_COS, k) = c;
+      const M3 R = joint_rot(bc + 3, ax, s, c);
+      const V3 r{bc[0], bc[1], bc[2]};
+      const V3 wp{bv[par][0], bv[par][1], bv[par][2]}, vp{bv[par][3], bv[par][4], bv[par][5]};
+      V3 w = mulT(R, wp);
+      const V3 vl = mulT(R, vp - cross(r, wp));
+      if (ax == 0) w.x += qd; else if (ax == 1) w.y += qd; else w.z += qd;
+      bv[k][0] = w.x; bv[k][1] = w.y; bv[k][2] = w.z; bv[k][3] = vl.x; bv[k][4] = vl.y; bv[k][5] = vl.z;
+      const V3 nzp{bnz[par][0], bnz[par][1], bnz[par][2]};
+      const V3 nz = mulT(R, nzp);
+      bnz[k][0] = nz.x; bnz[k][1] = nz.y; bnz[k][2] = nz.z;
+      bh[k] = bh[par] + dot(nzp, r);
+    }
+    // ---------------- pass 2 (inward, reverse depth-first order)
+    ArtI carryI; Sp6 carryP;  // contribution of body k+1 to its chain parent k, in k's coordinates
+    for (int s = 0; s < MAX_SLOTS * 27; ++s) LD(F_SLOT, s) = 0.f;
+    for (int k = nb - 1; k >= 0; --k) {
+      const float* __restrict__ bc = M.body + k * BW;
+      const int* __restrict__ tp = M.topo + k * TW;
+      const int par = tp[0], ax = tp[1], dof = tp[2], nchild = tp[3], slot = tp[4], pt0 = tp[5], npt = tp[6], link = tp[7];
+      const float mass = bc[12];
+      const V3 mc{bc[13], bc[14], bc[15]};
+      const V3 w{bv[k][0], bv[k][1], bv[k][2]}, vl{bv[k][3], bv[k][4], bv[k][5]};
+      const V3 nz{bnz[k][0], bnz[k][1], bnz[k][2]};
+      // rigid-body inertia and bias:  pA = v x* (I v) - I a_g
+      ArtI I;
+      I.A = {bc[16], bc[17], bc[18], bc[19], bc[20], bc[21]};
+      I.B = {{0.f, -mc.z, mc.y, mc.z, 0.f, -mc.x, -mc.y, mc.x, 0.f}};
+      I.C = {mass, 0.f, 0.f, mass, 0.f, mass};
+      Sp6 p;
+      {
+        const V3 hn = mul(I.A, w) + cross(mc, vl);        // angular momentum about the body origin
+        const V3 hl = mass * vl - cross(mc, w);           // linear momentum
+        const V3 gl = (-M.gravity) * nz;
+        p.a = cross(w, hn) + cross(vl, hl) - cross(mc, gl);
+        p.l = cross(w, hl) - mass * gl;
+      }
+      if (nchild == 1 && slot < 0) {
+        I.A.xx += carryI.A.xx; I.A.xy += carryI.A.xy; I.A.xz += carryI.A.xz; I.A.yy += carryI.A.yy; I.A.yz += carryI.A.yz; I.A.zz += carryI.A.zz;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) I.B.m[i] += carryI.B.m[i];
+        I.C.xx += carryI.C.xx; I.C.xy += carryI.C.xy; I.C.xz += carryI.C.xz; I.C.yy += carryI.C.yy; I.C.yz += carryI.C.yz; I.C.zz += carryI.C.zz;
+        p.a = p.a + carryP.a; p.l = p.l + carryP.l;
+      } else if (slot >= 0) {
+        add_art(&LD(F_SLOT, slot * 27), I, p);
+      }
+      // ground contacts of this body's collision spheres
+      for (int j = 0; j < npt; ++j) {
+        const float* __restrict__ pt = M.points + (pt0 + j) * 4;
+        const V3 r{pt[0], pt[1], pt[2]};
+        const float d = pt[3] - (bh[k] + dot(nz, r));
+        if (d > 0.f) {
+          touch |= 1u << link;
+          const V3 vp = vl + cross(w, r);
+          const float vn = dot(nz, vp);
+          const V3 vt = vp - vn * nz;
+          const float fn0 = fmaxf(kc * d - cn * vn, 0.f);
+          const float ct = mu * fn0 / fmaxf(sqrtf(dot(vt, vt)), veps);
+          const float fne = fmaxf(fn0 - h * kc * vn, 0.f);
+          const V3 f = fne * nz - ct * vt;
+          const float an = h * h * kc + h * cn - h * ct, at = h * ct;   // A = an nz nz^T + at 1
+          const S3 Am{an * nz.x * nz.x + at, an * nz.x * nz.y, an * nz.x * nz.z, an * nz.y * nz.y + at, an * nz.y * nz.z, an * nz.z * nz.z + at};
+          const M3 rA = skew_mul(r, full(Am));          // B += r x A
+          const M3 rArT = mul_skew(rA, V3{-r.x, -r.y, -r.z});  // (r x A) skew(r)^T
+#pragma unroll
+          for (int i = 0; i < 9; ++i) I.B.m[i] += rA.m[i];
+          I.A.xx += rArT.m[0]; I.A.xy += rArT.m[1]; I.A.xz += rArT.m[2]; I.A.yy += rArT.m[4]; I.A.yz += rArT.m[5]; I.A.zz += rArT.m[8];
+          I.C.xx += Am.xx; I.C.xy += Am.xy; I.C.xz += Am.xz; I.C.yy += Am.yy; I.C.yz += Am.yz; I.C.zz += Am.zz;
+          p.a = p.a - cross(r, f);
+          p.l = p.l - f;
+        }
+      }
+      if (k == 0) { carryI = I; carryP = p; break; }
+      // joint: PD torque with the implicit diagonal (stable PD unless the torque clamp is active), limit spring
+      const float q = LD(F_POSE, 7 + dof), qd = LD(F_VEL, 6 + dof);
+      const float lo = bc[22], hi = bc[23], damp = bc[24], arm = bc[25], flim = fminf(bc[26], M.max_torque), kp = bc[27], kv = bc[28];
+      const float tgt = fminf(fmaxf(LD(F_TGT, dof), lo + M.limit_margin), hi - M.limit_margin);
+      const float tpd = kp * (tgt - q) - kv * qd;
+      float tau, dadd;
+      if (fabsf(tpd) > flim) { tau = fminf(fmaxf(tpd, -flim), flim) - damp * qd; dadd = arm + h * damp; }
+      else { tau = kp * (tgt - q - h * qd) - (kv + damp) * qd; dadd = arm + h * (kv + damp) + h * h * kp; }
+      if (q < lo) { tau += M.limit_stiffness * (lo - q - h * qd); dadd += h * h * M.limit_stiffness; }
+      if (q > hi) { tau += M.limit_stiffness * (hi - q - h * qd); dadd += h * h * M.limit_stiffness; }
+      // U = IA S (S = angular unit axis), D, u
+      V3 Ua, Ul;
+      if (ax == 0) { Ua = {I.A.xx, I.A.xy, I.A.xz}; Ul = {I.B.m[0], I.B.m[1], I.B.m[2]}; }
+      else if (ax == 1) { Ua = {I.A.xy, I.A.yy, I.A.yz}; Ul = {I.B.m[3], I.B.m[4], I.B.m[5]}; }
+      else { Ua = {I.A.xz, I.A.yz, I.A.zz}; Ul = {I.B.m[6], I.B.m[7], I.B.m[8]}; }
+      const float Dinv = 1.f / (comp(Ua, ax) + dadd);
+      const float u = tau - comp(p.a, ax);
+      LD(F_U, 6 * k) = Ua.x; LD(F_U, 6 * k + 1) = Ua.y; LD(F_U, 6 * k + 2) = Ua.z; LD(F_U, 6 * k + 3) = Ul.x; LD(F_U, 6 * k + 4) = Ul.y; LD(F_U, 6 * k + 5) = Ul.z;
+      LD(F_DINV, k) = Dinv; LD(F_UU, k) = u;
+      // Ia = IA - U U^T / D
+      I.A.xx -= Dinv * Ua.x * Ua.x; I.A.xy -= Dinv * Ua.x * Ua.y; I.A.xz -= Dinv * Ua.x * Ua.z; I.A.yy -= Dinv * Ua.y * Ua.y; I.A.yz -= Dinv * Ua.y * Ua.z; I.A.zz -= Dinv * Ua.z * Ua.z;
+      I.C.xx -= Dinv * Ul.x * Ul.x; I.C.xy -= Dinv * Ul.x * Ul.y; I.C.xz -= Dinv * Ul.x * Ul.z; I.C.yy -= Dinv * Ul.y * Ul.y; I.C.yz -= Dinv * Ul.y * Ul.z; I.C.zz -= Dinv * Ul.z * Ul.z;
+      {
+        const float ua[3] = {Ua.x, Ua.y, Ua.z}, ul[3] = {Ul.x, Ul.y, Ul.z};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) I.B.m[3 * i + j] -= Dinv * ua[i] * ul[j];
+      }
+      // pa = pA + Ia c + U u / D,   c = [w x e; vl x e] qd
+      const V3 e = unit(ax);
+      const V3 ca = qd * cross(w, e), cl = qd * cross(vl, e);
+      const float ud = u * Dinv;
+      p.a = p.a + mul(I.A, ca) + mul(I.B, cl) + ud * Ua;
+      p.l = p.l + mulT(I.B, ca) + mul(I.C, cl) + ud * Ul;
+      // to the parent's coordinates:  X^T Ia X,  X^T pa   (X = rot(R^T) xlt(r))
+      const M3 R = joint_rot(bc + 3, ax, LD(F_SIN, k), LD(F_COS, k));
+      const V3 r{bc[0], bc[1], bc[2]};
+      ArtI P;
+      P.A = rot_sym(R, I.A);
+      P.C = rot_sym(R, I.C);
+      const M3 Bp = matmul(matmul(R, I.B), transpose(R));
+      const M3 rC = skew_mul(r, full(P.C));
+      M3 Bn;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Bn.m[i] = Bp.m[i] + rC.m[i];             // B_p = B' + r x C'
+      const M3 t1 = skew_mul(r, transpose(Bn));                             // r x B_p^T
+      const M3 t2 = mul_skew(Bp, r);                                        // B' skew(r)
+      P.A.xx += t1.m[0] - t2.m[0]; P.A.xy += t1.m[1] - t2.m[1]; P.A.xz += t1.m[2] - t2.m[2];
+      P.A.yy += t1.m[4] - t2.m[4]; P.A.yz += t1.m[5] - t2.m[5]; P.A.zz += t1.m[8] - t2.m[8];
+      P.B = Bn;
+      Sp6 pp;
+      pp.l = mul(R, p.l);
+      pp.a = mul(R, p.a) + cross(r, pp.l);
+      const int pslot = M.topo[par * TW + 4];
+      if (pslot >= 0) {
+        float* sp = &LD(F_SLOT, pslot * 27);
+        ArtI Z; Sp6 z0;
+        Z.A = {0, 0, 0, 0, 0, 0}; Z.C = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Z.B.m[i] = 0.f;
+        z0.a = {0, 0, 0}; z0.l = {0, 0, 0};
+        add_art(sp, Z, z0);
+        Z.A.xx += P.A.xx; Z.A.xy += P.A.xy; Z.A.xz += P.A.xz; Z.A.yy += P.A.yy; Z.A.yz += P.A.yz; Z.A.zz += P.A.zz;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Z.B.m[i] += P.B.m[i];
+        Z.C.xx += P.C.xx; Z.C.xy += P.C.xy; Z.C.xz += P.C.xz; Z.C.yy += P.C.yy; Z.C.yz += P.C.yz; Z.C.zz += P.C.zz;
+        z0.a = z0.a + pp.a; z0.l = z0.l + pp.l;
+        store_art(sp, Z, z0);
+      } else {
+        carryI = P; carryP = pp;
+      }
+    }
+    // ---------------- floating base: a0 = -IA0^-1 pA0 (6x6 SPD, Cholesky)
+    float a0[6];
+    {
+      const ArtI& I = carryI;
+      float A[6][6];
+      A[0][0] = I.A.xx; A[0][1] = I.A.xy; A[0][2] = I.A.xz; A[1][1] = I.A.yy; A[1][2] = I.A.yz; A[2][2] = I.A.zz;
+      A[3][3] = I.C.xx; A[3][4] = I.C.xy; A[3][5] = I.C.xz; A[4][4] = I.C.yy; A[4][5] = I.C.yz; A[5][5] = I.C.zz;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) A[i][3 + j] = I.B.m[3 * i + j];
+      float b[6] = {-carryP.a.x, -carryP.a.y, -carryP.a.z, -carryP.l.x, -carryP.l.y, -carryP.l.z};
+      // upper-triangular Cholesky A = L L^T stored in the upper part as L^T
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+          float sum = A[i][j];
+#pragma unroll
+          for (int t = 0; t < i; ++t) sum -= A[t][i] * A[t][j];
+          A[i][j] = (j == i) ? sqrtf(fmaxf(sum, 1e-20f)) : sum / A[i][i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {  // L y = b
+        float sum = b[i];
+#pragma unroll
+        for (int t = 0; t < i; ++t) sum -= A[t][i] * b[t];
+        b[i] = sum / A[i][i];
+      }
+#pragma unroll
+      for (int i = 5; i >= 0; --i) {  // L^T x = y
+        float sum = b[i];
+#pragma unroll
+        for (int t = i + 1; t < 6; ++t) sum -= A[i][t] * b[t];
+        b[i] = sum / A[i][i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) a0[i] = b[i];
+    }
+    // ---------------- pass 3 (outward): accelerations; joints are integrated as they are visited
+    // bv[k] is overwritten with the body's acceleration once its own velocity has been used
+    float root_a[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { root_a[i] = a0[i]; bv[0][i] = a0[i]; }
+    for (int k = 1; k < nb; ++k) {
+      const float* __restrict__ bc = M.body + k * BW;
+      const int* __restrict__ tp = M.topo + k * TW;
+      const int par = tp[0], ax = tp[1], dof = tp[2];
+      const M3 R = joint_rot(bc + 3, ax, LD(F_SIN, k), LD(F_COS, k));
+      const V3 r{bc[0], bc[1], bc[2]};
+      const V3 apa{bv[par][0], bv[par][1], bv[par][2]}, apl{bv[par][3], bv[par][4], bv[par][5]};
+      const V3 w{bv[k][0], bv[k][1], bv[k][2]}, vl{bv[k][3], bv[k][4], bv[k][5]};
+      const float qd = LD(F_VEL, 6 + dof);
+      const V3 e = unit(ax);
+      V3 aa = mulT(R, apa) + qd * cross(w, e);
+      const V3 al = mulT(R, apl - cross(r, apa)) + qd * cross(vl, e);
+      const V3 Ua{LD(F_U, 6 * k), LD(F_U, 6 * k + 1), LD(F_U, 6 * k + 2)}, Ul{LD(F_U, 6 * k + 3), LD(F_U, 6 * k + 4), LD(F_U, 6 * k + 5)};
+      const float qdd = (LD(F_UU, k) - dot(Ua, aa) - dot(Ul, al)) * LD(F_DINV, k);
+      if (ax == 0) aa.x += qdd; else if (ax == 1) aa.y += qdd; else aa.z += qdd;
+      bv[k][0] = aa.x; bv[k][1] = aa.y; bv[k][2] = aa.z; bv[k][3] = al.x; bv[k][4] = al.y; bv[k][5] = al.z;
+      const float qdn = qd + h * qdd;
+      LD(F_VEL, 6 + dof) = qdn;
+      LD(F_POSE, 7 + dof) = LD(F_POSE, 7 + dof) + h * qdn;
+    }
+    // ---------------- root: semi-implicit Euler (classical linear acceleration = R a_lin + w x v)
+    {
+      const V3 aw = mul(R0, V3{root_a[0], root_a[1], root_a[2]});
+      const V3 al = mul(R0, V3{root_a[3], root_a[4], root_a[5]}) + cross(ww, vw);
+      ww = ww + h * aw;
+      vw = vw + h * al;
+      pos = pos + h * vw;
+      const float wn = sqrtf(dot(ww, ww));
+      const float half = 0.5f * h * wn;
+      const float kq = wn > 1e-12f ? sinf(half) / wn : 0.5f * h;
+      const float dw = cosf(half), dx = kq * ww.x, dy = kq * ww.y, dz = kq * ww.z;
+      const float nw = dw * qw - dx * qx - dy * qy - dz * qz;
+      const float nx = dw * qx + dx * qw + dy * qz - dz * qy;
+      const float ny = dw * qy - dx * qz + dy * qw + dz * qx;
+      const float nzq = dw * qz + dx * qy - dy * qx + dz * qw;
+      const float inv = rsqrtf(nw * nw + nx * nx + ny * ny + nzq * nzq);
+      qw = nw * inv; qx = nx * inv; qy = ny * inv; qz = nzq * inv;
+    }
+  }
+  // ---- write back
+  LD(F_POSE, 0) = pos.x; LD(F_POSE, 1) = pos.y; LD(F_POSE, 2) = pos.z;
+  LD(F_POSE, 3) = qw; LD(F_POSE, 4) = qx; LD(F_POSE, 5) = qy; LD(F_POSE, 6) = qz;
+  LD(F_VEL, 0) = vw.x; LD(F_VEL, 1) = vw.y; LD(F_VEL, 2) = vw.z; LD(F_VEL, 3) = ww.x; LD(F_VEL, 4) = ww.y; LD(F_VEL, 5) = ww.z;
+  LD(F_VEL, 35) = 0.f;
+  if (on) {
+    if (contact_bits) contact_bits[env] = touch;
+    if (contact_flag) contact_flag[env] = (touch & M.termination_mask) ? 1 : 0;
+  }
+  __syncthreads();
+  for (int idx = lane; idx < live * 36; idx += WG) {
+    const int row = idx / 36, col = idx - row * 36;
+    sim_pose[(size_t)env0 * 36 + idx] = lds[(F_POSE + col) * WG + row];
+    sim_vel[(size_t)env0 * 36 + idx] = lds[(F_VEL + col) * WG + row];
+  }
+#undef LD
+}
+
+}  // namespace
+
+extern "C" int addhip_rigid_step(const addhip_rigid_model_t* m, float* sim_pose, float* sim_vel, const float* target, int32_t target_stride,
+                                 int32_t num_envs, uint8_t* contact_flag, uint32_t* contact_bits, void* stream) {
+  ADDHIP_REQUIRE(m && sim_pose && sim_vel && target, "rigid_step: null argument");
+  ADDHIP_REQUIRE(num_envs > 0 && target_stride >= ADDHIP_NUM_DOF, "rigid_step: bad sizes");
+  ADDHIP_REQUIRE(m->num_bodies == ADDHIP_NUM_DOF + 1, "rigid_step: the packed state rows hold %d hinge dofs", ADDHIP_NUM_DOF);
+  ADDHIP_REQUIRE(m->body && m->topo && (m->points || m->num_points == 0), "rigid_step: model tables missing");
+  ADDHIP_REQUIRE(m->substeps >= 1 && m->substeps <= 64 && m->dt > 0.f, "rigid_step: bad dt / substeps");
+  static bool attr_set = false;
+  const size_t shmem = sizeof(float) * F_TOTAL * WG;
+  if (!attr_set) {
+    ADDHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(rigid_step_kernel, dim3((num_envs + WG - 1) / WG), dim3(WG), shmem, (hipStream_t)stream, *m, sim_pose, sim_vel, target,
+                     target_stride, num_envs, contact_flag, contact_bits);
+  return addhip::check_launch("rigid_step_kernel");
+}

@@ -95,6 +95,8 @@ class ADDAgent:
         ent = env.robot.entity
         self._fast_engine = hasattr(ent, "hot_state")
         if self._fast_engine:
+            if hasattr(ent, "set_termination_links"):  # the engine evaluates the non-foot ground-contact predicate itself
+                ent.set_termination_links(list(task.get("contact_bodies", [])))
             sim_pose, sim_vel, contact = ent.hot_state()
         else:
             sim_pose, sim_vel, contact = z(N, L.POSE_W), z(N, L.POSE_W), z(N, dt=torch.uint8)

@@ -36,8 +36,8 @@ enum { ADDHIP_DONE_NULL = 0, ADDHIP_DONE_FAIL = 1, ADDHIP_DONE_SUCC = 2, ADDHIP_
 
 const char* addhip_last_error(void);
 int addhip_version(void);
-/* sizeof() of addhip_motion_t, task_t, env_t, step_out_t, sampler_t, gemm_t, gather_t (in that order) -> out[0..6]; returns the
- * number written (7) or -1.  For bindings to verify their struct layouts against the library they loaded. */
+/* sizeof() of addhip_motion_t, task_t, env_t, step_out_t, sampler_t, gemm_t, gather_t, rigid_model_t (in that order) -> out[0..7];
+ * returns the number written (8) or -1.  For bindings to verify their struct layouts against the library they loaded. */
 int addhip_abi_sizes(int32_t* out, int32_t count);
 
 /* ---- reference-motion step tables: MotionLib._step_* (anim/motion_lib.py:285-320) ---- */
@@ -156,6 +156,40 @@ int addhip_motion_lookup(const addhip_motion_t* m, const int32_t* ids, const flo
  * control_dofs_position + scene.step): dof += lag*(target-dof), dof_vel = delta/dt */
 int addhip_kin_engine_step(float* sim_pose, float* sim_vel, const float* target, int32_t target_stride,
                            int32_t num_envs, float lag, float dt, void* stream);
+
+/* ---- rigid-body engine behind the plugin API: BaseScene.step() + BaseEntity.control_dofs_position / get_contacts
+ *      (engine/base_engine.py:93-455; the reference delegates to Genesis or MuJoCo-Warp: engine/mjwarp_engine.py:807-851 PD
+ *      torque loop, :896-986 contacts, :1554-1611 substepped step).  Articulated-body algorithm over the kinematic tree with a
+ *      floating base; joint PD (stable-PD form), joint damping / armature, and penalty ground contacts of per-body collision
+ *      spheres are integrated linearly-implicitly; semi-implicit Euler.  Build-defined dynamics (parity is against
+ *      oracle/rigid.py and physical invariants, not against the reference's simulators). ---- */
+#define ADDHIP_RIGID_BODY_W 32
+#define ADDHIP_RIGID_TOPO_W 8
+typedef struct {
+  int32_t num_bodies;      /* root + one hinge body per dof (== ADDHIP_NUM_DOF + 1 for the packed state rows) */
+  int32_t num_points;
+  /* per body, in TRAVERSAL order (depth-first pre-order: a single child directly follows its parent), ADDHIP_RIGID_BODY_W floats:
+   *   0-2 offset in the parent frame | 3-11 child->parent rotation at q=0 (row major) | 12 mass | 13-15 mass*com |
+   *   16-21 inertia about the body origin xx xy xz yy yz zz | 22 lo 23 hi | 24 damping 25 armature 26 |torque| limit | 27 kp 28 kv */
+  const float* body;
+  /* per body, traversal order, ADDHIP_RIGID_TOPO_W ints: parent (traversal index) | hinge axis 0/1/2 (x/y/z of the body frame) |
+   *   dof column (breadth-first: column 7+dof of the pose row) | number of children | branch accumulator slot (-1 unless the
+   *   body has more than one child; at most 4 branch bodies) | first collision point | number of points | link index
+   *   (breadth-first body index, bit position in contact_bits) */
+  const int32_t* topo;
+  const float* points;     /* [num_points,4] x y z radius in the body frame, grouped by body */
+  float dt;                /* control step */
+  int32_t substeps;
+  float gravity;           /* 9.81 */
+  float contact_stiffness, contact_damping, friction, friction_vel_eps;
+  float limit_stiffness, max_torque, limit_margin;
+  uint32_t termination_mask; /* bit b: a ground contact of link b raises contact_flag (robot.py:221-231 with add_done.py:36-45) */
+} addhip_rigid_model_t;
+/* One control step for every env, in place on the packed state rows (pose[N,36], vel[N,36]); target [N,target_stride] = joint
+ * position targets (breadth-first dof order).  contact_flag [N] (or NULL): 1 if a link selected by termination_mask touched
+ * the ground in the last substep; contact_bits [N] (or NULL): one bit per link. */
+int addhip_rigid_step(const addhip_rigid_model_t* m, float* sim_pose, float* sim_vel, const float* target, int32_t target_stride,
+                      int32_t num_envs, uint8_t* contact_flag, uint32_t* contact_bits, void* stream);
 
 /* ---- dense layers: torch.nn.Linear(+ReLU) stacks of PPOModel/ADDModel (ppo_model.py:13-21,
  *      add_model.py:12-15, nets/fc_*layers_1024units.py) on fp32 MFMA ---- */

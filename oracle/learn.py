@@ -155,10 +155,11 @@ class Model:
     """actor 264-1024-1024-512-29, critic ..-1, disc 114-1024-512-1, ReLU."""
 
     def __init__(self, params, action_std=0.05):
-        self.p = {k: torch.tensor(np.asarray(v, F)).requires_grad_(True) for k, v in params.items()}
+        self.p = {k: torch.tensor(np.asarray(v, F)).to(_DTYPE).requires_grad_(True) for k, v in params.items()}
         # distribution_gaussian_diag.py:24-31, 63-67: fixed fp32 logstd vector, std = exp(logstd)
         self.logstd = torch.full((29,), float(np.log(action_std)), dtype=torch.float32)
-        self.std = torch.exp(self.logstd)
+        self.std = torch.exp(self.logstd).to(_DTYPE)
+        self.logstd = self.logstd.to(_DTYPE)
 
     def names(self):
         return [n for n, _ in PARAM_SHAPES]
@@ -188,8 +189,24 @@ class Model:
         return logp
 
 
+_DTYPE = torch.float32
+
+
+class float64_mode:
+    """with float64_mode(): Model(...) / compute_loss(...) run the same fp32 inputs in double precision -- the exact-arithmetic
+    reference against which fp32 rounding (the HIP kernels' and torch-CPU's alike) is measured."""
+
+    def __enter__(self):
+        global _DTYPE
+        _DTYPE = torch.float64
+
+    def __exit__(self, *a):
+        global _DTYPE
+        _DTYPE = torch.float32
+
+
 def t32(x):
-    return torch.tensor(np.asarray(x, F))
+    return torch.tensor(np.asarray(x, F)).to(_DTYPE)
 
 
 def actor_step(model, obs_norm, a_norm, obs, noise, rand_mask=None):
@@ -246,7 +263,7 @@ def compute_loss(model, cfg, batch):
     info["action_bound_loss"] = bound.item()
     # discriminator (add_agent.py:141-202)
     nd = t32(batch["norm_diff"]).requires_grad_(True)
-    pos_logit = model.disc(torch.zeros(1, nd.shape[1]))
+    pos_logit = model.disc(torch.zeros(1, nd.shape[1], dtype=nd.dtype))
     neg_logit = model.disc(nd)
     bce = torch.nn.functional.binary_cross_entropy_with_logits
     loss_pos = bce(pos_logit, torch.full_like(pos_logit, 0.9))  # amp_agent.py:182-185

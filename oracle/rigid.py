@@ -1,0 +1,423 @@
+"""Rigid-body step of the G1 behind the engine boundary -- CPU restatement (numpy, float64) of the algorithm the
+HIP kernel in add-gym_amd/csrc/rigid.hip runs.  TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py's cpu_baseline).
+
+PARITY UNPINNED against the reference: add-gym delegates physics to Genesis (genesis-world==0.3.10, pyproject.toml:8; wrapped at
+add_gym/engine/genesis_engine.py) or MuJoCo-Warp (engine/mjwarp_engine.py); neither is installable here and the reference holds
+no physics fixtures.  What IS followed from the reference is the engine seam and its semantics:
+  * state/command layout of BaseEntity (engine/base_engine.py:93-376): qpos = root xyz | root quat wxyz | 29 hinge angles in
+    breadth-first body order, dofs velocity = world linear | world angular | 29 hinge rates;
+  * position-controlled joints: tau = kp (target - q) - kv qdot re-evaluated every substep, torque clamp, targets clamped to the
+    joint range shrunk by a margin (engine/mjwarp_engine.py:807-851, 1554-1611); gains from robot.py:133-163;
+  * `substeps` physics steps per control step (configs/engine/mjwarp.yaml: substeps 4);
+  * ground contacts reported per link (mjwarp_engine.py:896-986) for the done predicate (robot.py:221-231).
+The dynamics themselves are this repo's own design, pinned by invariants (tests/test_oracle_rigid.py): inverse dynamics
+(RNEA) of the ABA result, momentum and energy balance, free-fall closed form, static stand.
+
+Algorithm per substep h (all spatial quantities in body coordinates, Featherstone's conventions):
+  1. outward: X_i(q), v_i = X_i v_parent + S_i qd_i, c_i = v_i x S_i qd_i, world z-row nz_i = R_i^T z and height of each body;
+  2. forces: gravity I_i [0; -g nz_i]; ground contact at the body's collision spheres: spring-damper normal force and
+     regularised Coulomb friction, LINEARLY IMPLICIT -- the contact's stiffness/damping enter the body's articulated inertia as
+     J^T (h^2 K + h C) J, its force as J^T (f0 - h K v_p) -- so no contact solver iterations and no tiny substeps;
+  3. joints: PD torque with the implicit ("stable PD") diagonal  armature + h (kv + damping) + h^2 kp  added to D_i unless the
+     torque clamp is active; joint-limit spring likewise;
+  4. inward articulated-body pass, 6x6 solve at the floating base, outward accelerations;
+  5. semi-implicit Euler: velocities first, then positions with the new velocities; quaternion by the exponential map.
+"""
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+GRAVITY = 9.81
+
+
+# ---------------------------------------------------------------- small math helpers (batched over leading dims)
+def skew(v):
+    z = np.zeros(v.shape[:-1])
+    return np.stack([np.stack([z, -v[..., 2], v[..., 1]], -1), np.stack([v[..., 2], z, -v[..., 0]], -1),
+                     np.stack([-v[..., 1], v[..., 0], z], -1)], -2)
+
+
+def quat_to_mat(q):
+    """wxyz -> rotation matrix mapping body coordinates to parent/world coordinates."""
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+                     np.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
+                     np.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)], -2)
+
+
+def quat_mul(a, b):
+    aw, ax, ay, az = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bw, bx, by, bz = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], -1)
+
+
+def axis_rot(axis_id, theta):
+    """Rotation by theta about coordinate axis axis_id (0 x, 1 y, 2 z): maps child coordinates to the joint's parent side."""
+    c, s = np.cos(theta), np.sin(theta)
+    o, z = np.ones_like(c), np.zeros_like(c)
+    if axis_id == 0:
+        rows = [[o, z, z], [z, c, -s], [z, s, c]]
+    elif axis_id == 1:
+        rows = [[c, z, s], [z, o, z], [-s, z, c]]
+    else:
+        rows = [[c, -s, z], [s, c, z], [z, z, o]]
+    return np.stack([np.stack(r, -1) for r in rows], -2)
+
+
+def crm(v):
+    """spatial motion cross product matrix: crm(v) m = v x m"""
+    w, u = v[..., :3], v[..., 3:]
+    out = np.zeros(v.shape[:-1] + (6, 6))
+    out[..., :3, :3] = skew(w)
+    out[..., 3:, :3] = skew(u)
+    out[..., 3:, 3:] = skew(w)
+    return out
+
+
+def crf(v):
+    """spatial force cross product: crf(v) f = v x* f = -crm(v)^T f"""
+    return -np.swapaxes(crm(v), -1, -2)
+
+
+# ---------------------------------------------------------------- model
+class RigidModel:
+    """Constant tables of the articulated body, bodies in breadth-first order (= link / dof order of the engine API)."""
+
+    def __init__(self, xml_path):
+        body0 = ET.parse(xml_path).getroot().find("worldbody").find("body")
+        names, parent, pos, quat, axis, rng, mass, com, iquat, idiag, damping, armature, frc, pts = ([] for _ in range(14))
+        todo = [(body0, -1)]
+        while todo:
+            node, par = todo.pop(0)
+            me = len(names)
+            names.append(node.attrib["name"])
+            parent.append(par)
+            f = lambda s, d: np.array([float(x) for x in node.attrib.get(s, d).split()])
+            pos.append(f("pos", "0 0 0"))
+            quat.append(f("quat", "1 0 0 0"))
+            ine = node.find("inertial")
+            g = lambda s, d: np.array([float(x) for x in ine.attrib.get(s, d).split()])
+            mass.append(float(ine.attrib["mass"]))
+            com.append(g("pos", "0 0 0"))
+            iquat.append(g("quat", "1 0 0 0"))
+            idiag.append(g("diaginertia", "0 0 0"))
+            hinges = [j for j in node.findall("joint") if j.attrib.get("type", "hinge") == "hinge"]
+            if par >= 0:
+                (j,) = hinges
+                a = [float(x) for x in j.attrib["axis"].split()]
+                assert sorted(np.abs(a)) == [0, 0, 1] and max(a) == 1, "hinge axes must be +x, +y or +z of the body frame"
+                axis.append(int(np.argmax(a)))
+                rng.append([float(x) for x in j.attrib["range"].split()])
+                damping.append(float(j.attrib.get("damping", 0)))
+                armature.append(float(j.attrib.get("armature", 0)))
+                frc.append(max(abs(float(x)) for x in j.attrib["actuatorfrcrange"].split()))
+            for geom in node.findall("geom"):
+                pts.append((me, [float(x) for x in geom.attrib["pos"].split()], float(geom.attrib["size"].split()[0])))
+            todo += [(c, me) for c in node.findall("body")]
+        self.names, self.parent = names, np.asarray(parent)
+        self.nb = len(names)
+        self.pos, self.quat = np.asarray(pos), np.asarray(quat)
+        self.quat /= np.linalg.norm(self.quat, axis=1, keepdims=True)
+        self.axis = np.asarray([-1] + axis)
+        self.range = np.asarray(rng)
+        self.damping, self.armature, self.frc_limit = np.asarray(damping), np.asarray(armature), np.asarray(frc)
+        self.mass, self.com = np.asarray(mass), np.asarray(com)
+        iq = np.asarray(iquat)
+        iq /= np.linalg.norm(iq, axis=1, keepdims=True)
+        Rq = quat_to_mat(iq)
+        self.inertia_com = Rq @ (np.asarray(idiag)[:, :, None] * np.swapaxes(Rq, -1, -2))  # about the COM, body axes
+        # 6x6 spatial inertia about the body origin (Featherstone 2.63)
+        cx = skew(self.com)
+        self.I = np.zeros((self.nb, 6, 6))
+        self.I[:, :3, :3] = self.inertia_com + self.mass[:, None, None] * (cx @ np.swapaxes(cx, -1, -2))
+        self.I[:, :3, 3:] = self.mass[:, None, None] * cx
+        self.I[:, 3:, :3] = self.mass[:, None, None] * np.swapaxes(cx, -1, -2)
+        self.I[:, 3:, 3:] = self.mass[:, None, None] * np.eye(3)
+        self.R_fix = quat_to_mat(self.quat)  # child -> parent coordinates at q = 0
+        self.pt_body = np.asarray([p[0] for p in pts])
+        self.pt_pos = np.asarray([p[1] for p in pts])
+        self.pt_rad = np.asarray([p[2] for p in pts])
+        self.total_mass = float(self.mass.sum())
+
+
+class RigidParams:
+    """Engine options (defaults of add-gym_amd/configs/engine/rigid.yaml)."""
+
+    def __init__(self, **kw):
+        self.dt = 0.01
+        self.substeps = 4
+        self.contact_stiffness = 2.0e4   # N/m per collision sphere
+        self.contact_damping = 3.0e2     # N s/m per sphere, while penetrating
+        self.friction = 1.0
+        self.friction_vel_eps = 0.01     # m/s: below this slip speed friction is viscous (regularised Coulomb)
+        self.limit_stiffness = 2.0e3     # N m/rad beyond the joint range
+        self.max_torque = 200.0          # clamp on |tau_pd| (mjwarp.yaml: max_torque), combined with the MJCF's actuatorfrcrange
+        self.position_limit_margin = 1e-4
+        for k, v in kw.items():
+            assert hasattr(self, k), k
+            setattr(self, k, v)
+
+
+def gains(model, gain_scale=1.2):
+    """robot.py:133-163: kp by joint family x gain_scale, kv = 2 sqrt(kp)."""
+    fam = (("ankle", 120.0), ("knee", 120.0), ("hip", 80.0), ("waist", 50.0), ("torso", 50.0), ("shoulder", 50.0), ("elbow", 50.0), ("wrist", 50.0),
+           ("hand", 20.0))
+    kp = np.full(model.nb - 1, 100.0)
+    for i, n in enumerate(model.names[1:]):
+        for key, val in fam:
+            if key in n:
+                kp[i] = val
+                break
+    kp *= gain_scale
+    return kp, 2.0 * np.sqrt(kp)
+
+
+# ---------------------------------------------------------------- kinematics
+def body_transforms(model, q):
+    """E[i]: parent -> body-i coordinates (3x3), for i >= 1.  q: [n, 29]"""
+    n = q.shape[0]
+    E = np.zeros((n, model.nb, 3, 3))
+    for i in range(1, model.nb):
+        R = model.R_fix[i] @ axis_rot(model.axis[i], q[:, i - 1])  # child -> parent
+        E[:, i] = np.swapaxes(R, -1, -2)
+    return E
+
+
+def xform_motion(E, r, v):
+    """v_child = X v_parent with X = rot(E) xlt(r)"""
+    w, u = v[..., :3], v[..., 3:]
+    return np.concatenate([np.einsum("...ij,...j->...i", E, w), np.einsum("...ij,...j->...i", E, u - np.cross(r, w))], -1)
+
+
+def xform_force_T(E, r, f):
+    """f_parent = X^T f_child (X^T maps child forces to the parent)"""
+    n, fl = f[..., :3], f[..., 3:]
+    fl_p = np.einsum("...ji,...j->...i", E, fl)
+    return np.concatenate([np.einsum("...ji,...j->...i", E, n) + np.cross(r, fl_p), fl_p], -1)
+
+
+def xmat(E, r):
+    X = np.zeros(E.shape[:-2] + (6, 6))
+    X[..., :3, :3] = E
+    X[..., 3:, 3:] = E
+    X[..., 3:, :3] = -E @ skew(np.broadcast_to(r, E.shape[:-2] + (3,)))
+    return X
+
+
+def forward_kinematics(model, root_pos, root_quat, q):
+    """World rotation (body -> world) and origin of every body."""
+    n = q.shape[0]
+    E = body_transforms(model, q)
+    R = np.zeros((n, model.nb, 3, 3))
+    p = np.zeros((n, model.nb, 3))
+    R[:, 0], p[:, 0] = quat_to_mat(root_quat), root_pos
+    for i in range(1, model.nb):
+        lam = model.parent[i]
+        R[:, i] = R[:, lam] @ np.swapaxes(E[:, i], -1, -2)
+        p[:, i] = p[:, lam] + np.einsum("nij,j->ni", R[:, lam], model.pos[i])
+    return R, p, E
+
+
+# ---------------------------------------------------------------- one substep
+class State:
+    """root_pos [n,3], root_quat [n,4 wxyz], q [n,29], root_vel [n,3] world, root_ang [n,3] world, qd [n,29]"""
+
+    def __init__(self, root_pos, root_quat, q, root_vel, root_ang, qd):
+        f = lambda x: np.array(x, np.float64)
+        self.root_pos, self.root_quat, self.q, self.root_vel, self.root_ang, self.qd = map(f, (root_pos, root_quat, q, root_vel, root_ang, qd))
+
+    def copy(self):
+        return State(self.root_pos, self.root_quat, self.q, self.root_vel, self.root_ang, self.qd)
+
+    @staticmethod
+    def from_packed(pose, vel):
+        """hot-path rows: pose[n,36] = pos3|quat4|dof29, vel[n,36] = lin3|ang3|dofvel29|0"""
+        return State(pose[:, 0:3], pose[:, 3:7], pose[:, 7:36], vel[:, 0:3], vel[:, 3:6], vel[:, 6:35])
+
+    def packed(self):
+        z = np.zeros((self.q.shape[0], 1))
+        return (np.concatenate([self.root_pos, self.root_quat, self.q], -1), np.concatenate([self.root_vel, self.root_ang, self.qd, z], -1))
+
+
+def body_velocities(model, st, E):
+    n = st.q.shape[0]
+    R0 = quat_to_mat(st.root_quat)
+    v = np.zeros((n, model.nb, 6))
+    v[:, 0, :3] = np.einsum("nji,nj->ni", R0, st.root_ang)
+    v[:, 0, 3:] = np.einsum("nji,nj->ni", R0, st.root_vel)
+    for i in range(1, model.nb):
+        v[:, i] = xform_motion(E[:, i], model.pos[i], v[:, model.parent[i]])
+        v[:, i, model.axis[i]] += st.qd[:, i - 1]
+    return v
+
+
+def pd_torque(model, prm, kp, kv, st, target, h):
+    """(tau, dadd): joint torque at the start of the substep and the implicit diagonal added to D_i."""
+    lo = model.range[:, 0] + prm.position_limit_margin
+    hi = model.range[:, 1] - prm.position_limit_margin
+    tgt = np.clip(target, lo, hi)  # mjwarp_engine.py:828-836
+    tau_pd = kp * (tgt - st.q) - kv * st.qd
+    lim = np.minimum(model.frc_limit, prm.max_torque)
+    sat = np.abs(tau_pd) > lim
+    tau = np.where(sat, np.clip(tau_pd, -lim, lim) - model.damping * st.qd, kp * (tgt - st.q - h * st.qd) - (kv + model.damping) * st.qd)
+    dadd = np.where(sat, model.armature + h * model.damping, model.armature + h * (kv + model.damping) + h * h * kp)
+    below, above = st.q < model.range[:, 0], st.q > model.range[:, 1]
+    kl = prm.limit_stiffness
+    tau = tau + np.where(below, kl * (model.range[:, 0] - st.q - h * st.qd), 0.0) + np.where(above, kl * (model.range[:, 1] - st.q - h * st.qd), 0.0)
+    dadd = dadd + np.where(below | above, h * h * kl, 0.0)
+    return tau, dadd
+
+
+def contact_terms(model, prm, nz, height, v, h):
+    """Per body: spatial force [n,nb,6] (body coords, to be SUBTRACTED from pA), implicit inertia [n,nb,6,6], in-contact flag [n,nb]."""
+    n = nz.shape[0]
+    F = np.zeros((n, model.nb, 6))
+    A6 = np.zeros((n, model.nb, 6, 6))
+    touching = np.zeros((n, model.nb), bool)
+    k, cn, mu, veps = prm.contact_stiffness, prm.contact_damping, prm.friction, prm.friction_vel_eps
+    for b, r, rad in zip(model.pt_body, model.pt_pos, model.pt_rad):
+        nb_ = nz[:, b]                                   # world z axis in body coordinates
+        z = height[:, b] + nb_ @ r
+        d = rad - z
+        act = d > 0
+        if not act.any():
+            continue
+        vp = v[:, b, 3:] + np.cross(v[:, b, :3], r)      # point velocity, body coordinates
+        vn = np.einsum("ni,ni->n", nb_, vp)
+        vt = vp - vn[:, None] * nb_
+        fn0 = np.maximum(k * d - cn * vn, 0.0)
+        ct = mu * fn0 / np.maximum(np.linalg.norm(vt, axis=-1), veps)
+        fn_eff = np.maximum(fn0 - h * k * vn, 0.0)
+        f = fn_eff[:, None] * nb_ - ct[:, None] * vt
+        nn = nb_[:, :, None] * nb_[:, None, :]
+        A = (h * h * k + h * cn) * nn + (h * ct)[:, None, None] * (np.eye(3) - nn)
+        J = np.concatenate([-skew(r), np.eye(3)], -1)    # point velocity = J @ spatial velocity
+        m = act[:, None]
+        F[:, b] += np.where(m, np.concatenate([np.cross(r, f), f], -1), 0.0)
+        A6[:, b] += np.where(act[:, None, None], np.einsum("ia,nij,jb->nab", J, A, J), 0.0)
+        touching[:, b] |= act
+    return F, A6, touching
+
+
+def accelerations(model, prm, kp, kv, st, target, h, gravity=GRAVITY, contacts=True):
+    """Articulated-body algorithm with the implicit joint / contact terms.  Returns (a0 [n,6] spatial acceleration of the
+    root in root coordinates, qdd [n,29], info dict)."""
+    n, nb = st.q.shape[0], model.nb
+    R, p, E = forward_kinematics(model, st.root_pos, st.root_quat, st.q)
+    v = body_velocities(model, st, E)
+    nz = R[:, :, 2, :]            # R_i^T z: row z of the body -> world rotation
+    height = p[:, :, 2]
+    tau, dadd = pd_torque(model, prm, kp, kv, st, target, h)
+    if contacts:
+        Fc, Ac, touching = contact_terms(model, prm, nz, height, v, h)
+    else:
+        Fc, Ac, touching = np.zeros((n, nb, 6)), np.zeros((n, nb, 6, 6)), np.zeros((n, nb), bool)
+    IA = np.broadcast_to(model.I, (n, nb, 6, 6)).copy() + Ac
+    ag = np.concatenate([np.zeros((n, nb, 3)), -gravity * nz], -1)
+    Iv = np.einsum("bij,nbj->nbi", model.I, v)
+    pA = np.einsum("nbij,nbj->nbi", crf(v), Iv) - np.einsum("bij,nbj->nbi", model.I, ag) - Fc
+    c = np.zeros((n, nb, 6))
+    for i in range(1, nb):
+        S = np.zeros(6)
+        S[model.axis[i]] = 1.0
+        c[:, i] = np.einsum("nij,j->ni", crm(v[:, i]), S) * st.qd[:, i - 1, None]
+    U = np.zeros((n, nb, 6))
+    D = np.zeros((n, nb))
+    u = np.zeros((n, nb))
+    for i in range(nb - 1, 0, -1):
+        ax = model.axis[i]
+        U[:, i] = IA[:, i, :, ax]
+        D[:, i] = U[:, i, ax] + dadd[:, i - 1]
+        u[:, i] = tau[:, i - 1] - pA[:, i, ax]
+        Ia = IA[:, i] - U[:, i, :, None] * U[:, i, None, :] / D[:, i, None, None]
+        pa = pA[:, i] + np.einsum("nij,nj->ni", Ia, c[:, i]) + U[:, i] * (u[:, i] / D[:, i])[:, None]
+        X = xmat(E[:, i], model.pos[i])
+        lam = model.parent[i]
+        IA[:, lam] += np.swapaxes(X, -1, -2) @ Ia @ X
+        pA[:, lam] += np.einsum("nji,nj->ni", X, pa)
+    a = np.zeros((n, nb, 6))
+    a[:, 0] = -np.linalg.solve(IA[:, 0], pA[:, 0][..., None])[..., 0]
+    qdd = np.zeros((n, nb - 1))
+    for i in range(1, nb):
+        ap = xform_motion(E[:, i], model.pos[i], a[:, model.parent[i]]) + c[:, i]
+        qdd[:, i - 1] = (u[:, i] - np.einsum("ni,ni->n", U[:, i], ap)) / D[:, i]
+        a[:, i] = ap
+        a[:, i, model.axis[i]] += qdd[:, i - 1]
+    return a[:, 0], qdd, dict(touching=touching, tau=tau, dadd=dadd, a=a, v=v, E=E, R=R, p=p, Fc=Fc, Ac=Ac, nz=nz)
+
+
+def integrate(st, a0, qdd, h):
+    """Semi-implicit Euler.  a0 is the SPATIAL acceleration of the root (root coordinates): classical linear acceleration of the
+    origin = R a_lin + omega x v."""
+    R0 = quat_to_mat(st.root_quat)
+    out = st.copy()
+    out.root_ang = st.root_ang + h * np.einsum("nij,nj->ni", R0, a0[:, :3])
+    out.root_vel = st.root_vel + h * (np.einsum("nij,nj->ni", R0, a0[:, 3:]) + np.cross(st.root_ang, st.root_vel))
+    out.qd = st.qd + h * qdd
+    out.q = st.q + h * out.qd
+    out.root_pos = st.root_pos + h * out.root_vel
+    w = out.root_ang
+    ang = np.linalg.norm(w, axis=-1) * h
+    half = 0.5 * ang
+    k = np.where(ang > 1e-12, np.sin(half) / np.maximum(ang, 1e-300) * h, 0.5 * h)  # sin(|w|h/2)/|w|
+    dq = np.concatenate([np.cos(half)[:, None], k[:, None] * w], -1)
+    qn = quat_mul(dq, st.root_quat)  # world-frame angular velocity: left multiplication
+    out.root_quat = qn / np.linalg.norm(qn, axis=-1, keepdims=True)
+    return out
+
+
+def step(model, prm, kp, kv, st, target, gravity=GRAVITY, contacts=True):
+    """One CONTROL step = prm.substeps physics steps; returns (new state, per-body in-contact flags of the last substep)."""
+    h = prm.dt / prm.substeps
+    touching = None
+    for _ in range(prm.substeps):
+        a0, qdd, info = accelerations(model, prm, kp, kv, st, target, h, gravity, contacts)
+        st = integrate(st, a0, qdd, h)
+        touching = info["touching"]
+    return st, touching
+
+
+# ---------------------------------------------------------------- independent checks (inverse dynamics, momentum, energy)
+def inverse_dynamics(model, st, a0, qdd, Fext, gravity=GRAVITY):
+    """Recursive Newton-Euler: the joint torques and the root wrench that produce (a0, qdd).  Fext [n,nb,6]: external spatial
+    force on each body (body coordinates).  Returns (tau [n,29], root wrench [n,6])."""
+    n, nb = st.q.shape[0], model.nb
+    R, p, E = forward_kinematics(model, st.root_pos, st.root_quat, st.q)
+    v = body_velocities(model, st, E)
+    nz = R[:, :, 2, :]
+    a = np.zeros((n, nb, 6))
+    a[:, 0] = a0
+    f = np.zeros((n, nb, 6))
+    for i in range(nb):
+        if i > 0:
+            S = np.zeros(6)
+            S[model.axis[i]] = 1.0
+            a[:, i] = xform_motion(E[:, i], model.pos[i], a[:, model.parent[i]]) + S * qdd[:, i - 1, None] \
+                + np.einsum("nij,j->ni", crm(v[:, i]), S) * st.qd[:, i - 1, None]
+        ag = np.concatenate([np.zeros((n, 3)), -gravity * nz[:, i]], -1)
+        f[:, i] = np.einsum("ij,nj->ni", model.I[i], a[:, i] - ag) + np.einsum("nij,nj->ni", crf(v[:, i]), np.einsum("ij,nj->ni", model.I[i], v[:, i])) - Fext[:, i]
+    tau = np.zeros((n, nb - 1))
+    for i in range(nb - 1, 0, -1):
+        tau[:, i - 1] = f[:, i, model.axis[i]]
+        f[:, model.parent[i]] += xform_force_T(E[:, i], model.pos[i], f[:, i])
+    return tau, f[:, 0]
+
+
+def momentum_and_energy(model, st, gravity=GRAVITY):
+    """(linear momentum [n,3], angular momentum about the world origin [n,3], kinetic energy [n], potential energy [n], COM [n,3])"""
+    R, p, E = forward_kinematics(model, st.root_pos, st.root_quat, st.q)
+    v = body_velocities(model, st, E)
+    w_w = np.einsum("nbij,nbj->nbi", R, v[:, :, :3])
+    vo_w = np.einsum("nbij,nbj->nbi", R, v[:, :, 3:])
+    com_w = p + np.einsum("nbij,bj->nbi", R, model.com)
+    vc_w = vo_w + np.cross(w_w, com_w - p)
+    m = model.mass[None, :, None]
+    P = (m * vc_w).sum(1)
+    Ic_w = R @ model.inertia_com @ np.swapaxes(R, -1, -2)
+    Lsp = np.einsum("nbij,nbj->nbi", Ic_w, w_w)
+    Lw = (np.cross(com_w, m * vc_w) + Lsp).sum(1)
+    ke = 0.5 * (model.mass[None] * (vc_w ** 2).sum(-1) + np.einsum("nbi,nbi->nb", w_w, Lsp)).sum(1)
+    pe = gravity * (model.mass[None] * com_w[..., 2]).sum(1)
+    com = (m * com_w).sum(1) / model.total_mass
+    return P, Lw, ke, pe, com
