@@ -96,54 +96,64 @@ class MotionLib:
             return [e["file"] for e in entries], [e["weight"] for e in entries]
         return [motion_file], [1.0]
 
+    def _ingest_clip(self, frames, col, fps=30):
+        """One clip: raw 30 fps frames -> (pose rows, velocity rows, number of frames, length) of its 100 Hz step table
+        (motion_lib.py:164-320 for one motion; same torch ops in the same order as the reference, so bit-identical)."""
+        kin = self._kin
+        root_pos = torch.tensor(frames[:, 0:3], dtype=torch.float32)
+        root_rot = torch.tensor(frames[:, [6, 3, 4, 5]], dtype=torch.float32)  # xyzw -> wxyz
+        joint_rot = kin.dof_to_rot(torch.tensor(frames[:, 7:], dtype=torch.float32)[:, col])
+        root_vel = torch.zeros_like(root_pos)
+        root_vel[:-1] = fps * (root_pos[1:] - root_pos[:-1])
+        root_vel[-1] = root_vel[-2]
+        root_ang = torch.zeros_like(root_pos)
+        root_ang[:-1] = fps * Q.exp_map(Q.mul(root_rot[1:], Q.conj(root_rot[:-1])))
+        root_ang[-1] = root_ang[-2]
+        dof_vel = kin.compute_frame_dof_vel(joint_rot, 1.0 / fps)
+        nframes = frames.shape[0]
+        length = torch.tensor(1.0 / fps * (nframes - 1), dtype=torch.float32)  # motion_lib.py:202, 252-254
+        n = int(np.ceil(float(length) / self._dt))
+        t = torch_cpu_arange(n, self._dt)
+        phase = torch.clip(t / length, 0.0, 1.0)  # CLAMP clips (motion_lib.py:361-372)
+        nf1 = torch.tensor(nframes - 1, dtype=torch.long)
+        i0 = (phase * nf1).long()
+        i1 = torch.min(i0 + 1, nf1)
+        blend = phase * nf1 - i0
+        b = blend.unsqueeze(-1)
+        pos = (1.0 - b) * root_pos[i0] + b * root_pos[i1]
+        rot = Q.slerp(root_rot[i0], root_rot[i1], blend)
+        dof = kin.rot_to_dof(Q.slerp(joint_rot[i0], joint_rot[i1], b))
+        pose = torch.cat([pos, rot, dof], dim=-1)
+        # velocities are not blended (motion_lib.py:70-76)
+        vel = torch.cat([root_vel[i0], root_ang[i0], dof_vel[i0], torch.zeros(n, 1)], dim=-1)
+        return pose, vel, nframes, float(1.0 / fps * (nframes - 1))
+
     def _build(self, frames_list, weights, order):
+        """Clips are independent: they are ingested by a pool of host threads (torch releases the GIL inside its ops), in clip
+        order in the tables.  The arithmetic per clip is untouched, so the tables stay bit-identical to the reference's."""
+        import time
+        from concurrent.futures import ThreadPoolExecutor
+
         kin = self._kin
         col = torch.tensor([order.index(n) for n in kin.get_joint_order()[1:]], dtype=torch.long)  # motion_lib.py:102-111
-        fps = 30
-        per_clip, lengths, nframes = [], [], []
-        for frames in frames_list:
-            root_pos = torch.tensor(frames[:, 0:3], dtype=torch.float32)
-            root_rot = torch.tensor(frames[:, [6, 3, 4, 5]], dtype=torch.float32)  # xyzw -> wxyz
-            joint_rot = kin.dof_to_rot(torch.tensor(frames[:, 7:], dtype=torch.float32)[:, col])
-            root_vel = torch.zeros_like(root_pos)
-            root_vel[:-1] = fps * (root_pos[1:] - root_pos[:-1])
-            root_vel[-1] = root_vel[-2]
-            root_ang = torch.zeros_like(root_pos)
-            root_ang[:-1] = fps * Q.exp_map(Q.mul(root_rot[1:], Q.conj(root_rot[:-1])))
-            root_ang[-1] = root_ang[-2]
-            dof_vel = kin.compute_frame_dof_vel(joint_rot, 1.0 / fps)
-            per_clip.append((root_pos, root_rot, root_vel, root_ang, joint_rot, dof_vel))
-            nframes.append(frames.shape[0])
-            lengths.append(1.0 / fps * (frames.shape[0] - 1))
-        self._motion_num_frames = torch.tensor(nframes, dtype=torch.long)
-        self._motion_lengths = torch.tensor(lengths, dtype=torch.float32)
-        self._motion_loop_modes = torch.zeros(len(nframes), dtype=torch.int32)
+        t0 = time.perf_counter()
+        workers = max(1, min(len(frames_list), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4, 16))
+        if workers > 1:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                clips = list(pool.map(lambda f: self._ingest_clip(f, col), frames_list))
+        else:
+            clips = [self._ingest_clip(f, col) for f in frames_list]
+        self.ingest_seconds = time.perf_counter() - t0
+        self._motion_num_frames = torch.tensor([c[2] for c in clips], dtype=torch.long)
+        self._motion_lengths = torch.tensor([c[3] for c in clips], dtype=torch.float32)
+        self._motion_loop_modes = torch.zeros(len(clips), dtype=torch.int32)
         w = torch.tensor(weights, dtype=torch.float32)
         self._motion_weights = w / w.sum()
         raw_start = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(self._motion_num_frames, 0)[:-1]])
-
-        pose_rows, vel_rows, step_counts = [], [], []
-        for m, (root_pos, root_rot, root_vel, root_ang, joint_rot, dof_vel) in enumerate(per_clip):
-            length = self._motion_lengths[m]
-            n = int(np.ceil(float(length) / self._dt))
-            t = torch_cpu_arange(n, self._dt)
-            phase = torch.clip(t / length, 0.0, 1.0)  # CLAMP clips (motion_lib.py:361-372)
-            nf1 = self._motion_num_frames[m] - 1
-            i0 = (phase * nf1).long()
-            i1 = torch.min(i0 + 1, nf1)
-            blend = phase * nf1 - i0
-            b = blend.unsqueeze(-1)
-            pos = (1.0 - b) * root_pos[i0] + b * root_pos[i1]
-            rot = Q.slerp(root_rot[i0], root_rot[i1], blend)
-            dof = kin.rot_to_dof(Q.slerp(joint_rot[i0], joint_rot[i1], b))
-            pose_rows.append(torch.cat([pos, rot, dof], dim=-1))
-            # velocities are not blended (motion_lib.py:70-76)
-            vel_rows.append(torch.cat([root_vel[i0], root_ang[i0], dof_vel[i0], torch.zeros(n, 1)], dim=-1))
-            step_counts.append(n)
-        self._step_counts = torch.tensor(step_counts, dtype=torch.long)
+        self._step_counts = torch.tensor([c[0].shape[0] for c in clips], dtype=torch.long)
         step_start = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(self._step_counts, 0)[:-1]])
-        self.host_pose = torch.cat(pose_rows, 0).contiguous()
-        self.host_vel = torch.cat(vel_rows, 0).contiguous()
+        self.host_pose = torch.cat([c[0] for c in clips], 0).contiguous()
+        self.host_vel = torch.cat([c[1] for c in clips], 0).contiguous()
         self._raw_start, self._step_start = raw_start, step_start
         self.total_steps = int(self._step_counts.sum())
         self._upload()

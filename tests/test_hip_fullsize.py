@@ -15,10 +15,13 @@ from tests.test_hip_agent import T, make_cfg
 pytestmark = pytest.mark.gpu
 F = np.float32
 
-# gradient tolerance per precision, as a fraction of each tensor's largest gradient element: the fp32 MFMA and the exact
-# bf16x3 split share the fp32 bound (summation order only); bf16x2 keeps 16 significant bits per operand (2^-15 |a||b| per
-# product); plain bf16 operands (8 bits) are checked in the aggregate (relative L2 error), not element by element
-GRAD_TOL = {"fp32": 2e-4, "bf16x3": 2e-4, "bf16x2": 1.5e-3}
+# Gradient tolerances.  The yardstick is the SAME minibatch evaluated in float64 (oracle.learn.float64_mode): at 16 384 rows the
+# gradients are sums with heavy cancellation, and torch-CPU's own fp32 autograd is 1e-5 .. 2e-3 away from it (relative L2 per tensor,
+# profiles/r02_grad_error_table.log).  fp32 MFMA and the exact bf16x3 split must be as close to float64 as torch's fp32 is, give or
+# take summation order (factor 8, floor 2e-4); bf16x2 keeps 16 significant bits per operand (2^-15 |a||b| per product).
+L2_FACTOR, L2_FLOOR = {"fp32": 8.0, "bf16x3": 8.0}, 2e-4
+L2_ABS = {"bf16x2": 1.5e-2}
+MAX_ABS = {"fp32": 4e-2, "bf16x3": 4e-2, "bf16x2": 1e-1}   # largest element error / largest gradient element, per tensor (torch-CPU fp32 itself: up to 3e-2)
 
 
 def _fill_minibatch(ag, model, seed):
@@ -32,7 +35,11 @@ def _fill_minibatch(ag, model, seed):
         mean = model.actor_mean(OL.t32(obs))
         act = (mean + 0.05 * torch.tensor(rng.standard_normal((M, 29)).astype(F))).numpy()
         logp = model.log_prob(mean, OL.t32(act)).numpy()
-    mb = dict(norm_obs=obs, norm_action=act, a_logp=(logp + 0.1 * rng.standard_normal(M)).astype(F),
+    # old log-probabilities: offsets from the current ones that keep every importance ratio well away from the PPO clip
+    # boundaries 0.8 / 1.2 (the clipped objective's gradient is discontinuous there: a sample within rounding of a boundary
+    # would make ANY two implementations disagree by that sample's whole contribution)
+    off = rng.choice(np.array([-0.4, -0.1, 0.05, 0.1, 0.3], F), M)
+    mb = dict(norm_obs=obs, norm_action=act, a_logp=(logp + off).astype(F),
               adv=np.clip(rng.standard_normal(M), -4, 4).astype(F), tar_val=rng.standard_normal(M).astype(F),
               rand_action_mask=(rng.rand(M) < 0.95).astype(F), norm_diff=(0.5 * rng.standard_normal((M, 114))).astype(F))
     W = ag._W
@@ -76,25 +83,29 @@ def test_update_plan_at_4096_envs_all_gradients_match_oracle(precision):
     grads_hip = {k: v.numpy() for k, v in m.export(m.grads).items() if k != "_model._action_dist._logstd_net"}
     key = ("grads", seed)
     if key not in _ORACLE_GRADS:
-        loss, info = OL.compute_loss(model, OL.LossCfg(), mb)
         names = model.names()
-        gs = torch.autograd.grad(loss, [model.p[n] for n in names])
-        _ORACLE_GRADS[key] = ({n: g.numpy() for n, g in zip(names, gs)}, info)
-    grads_orc, info = _ORACLE_GRADS[key]
-    assert set(grads_orc) == set(grads_hip) and len(grads_orc) == 22
-    for k, go in grads_orc.items():
-        gh = grads_hip[k]
-        scale = np.abs(go).max() + 1e-12
-        if precision == "bf16":
-            rel = np.linalg.norm((gh - go).ravel()) / (np.linalg.norm(go.ravel()) + 1e-30)
-            assert rel <= 3e-2, (k, float(rel))
-        else:
-            err = np.abs(gh - go).max()
-            assert err <= GRAD_TOL[precision] * scale + 1e-9, (precision, k, float(err), float(scale))
+        loss, info = OL.compute_loss(model, OL.LossCfg(), mb)
+        g32 = {n: g.numpy().astype(np.float64) for n, g in zip(names, torch.autograd.grad(loss, [model.p[n] for n in names]))}
+        with OL.float64_mode():
+            m64 = OL.Model(params)
+            loss64, _ = OL.compute_loss(m64, OL.LossCfg(), mb)
+            g64 = {n: g.numpy() for n, g in zip(names, torch.autograd.grad(loss64, [m64.p[n] for n in names]))}
+        _ORACLE_GRADS[key] = (g32, g64, info)
+    g32, g64, info = _ORACLE_GRADS[key]
+    assert set(g64) == set(grads_hip) and len(g64) == 22
+    for k, ref in g64.items():
+        gh = grads_hip[k].astype(np.float64)
+        l2 = np.linalg.norm(ref) + 1e-300
+        err = np.linalg.norm(gh - ref) / l2
+        err32 = np.linalg.norm(g32[k] - ref) / l2
+        bound = L2_ABS[precision] if precision in L2_ABS else max(L2_FACTOR[precision] * err32, L2_FLOOR)
+        assert err <= bound, (precision, k, float(err), float(err32))
+        emax = np.abs(gh - ref).max() / (np.abs(ref).max() + 1e-300)
+        assert emax <= MAX_ABS[precision], (precision, k, float(emax))
     # logged scalars of the step
     ag._total_samples = ag.T * ag.N
     stats = ag._collect_info(1)
-    tol = 2e-2 if precision == "bf16" else 1e-3
+    tol = 1e-3
     for k in ("critic_loss", "actor_loss", "disc_loss", "disc_grad_penalty", "disc_logit_loss", "disc_neg_logit", "clip_frac", "imp_ratio"):
         np.testing.assert_allclose(stats[k], info[k], rtol=tol, atol=tol, err_msg=k)
     # padded rows / columns of the device layout never receive gradient
