@@ -56,7 +56,7 @@ class GemmT(C.Structure):
                 ("B", f32p), ("ldb", C.c_int32), ("b_kcontig", C.c_int32), ("C", f32p), ("ldc", C.c_int32), ("epilogue", C.c_int32),
                 ("bias", f32p), ("mask", f32p), ("ldmask", C.c_int32), ("a_mean", f32p), ("a_std", f32p), ("split_k", C.c_int32),
                 ("alpha", C.c_float), ("colsum", f32p), ("precision", C.c_int32),
-                ("relu_bits", f32p), ("mask_bits", f32p), ("ldbits", C.c_int32)]
+                ("relu_bits", f32p), ("mask_bits", f32p), ("ldbits", C.c_int32), ("accumulate", C.c_int32)]
 
 
 class GatherT(C.Structure):

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
 
   // epilogue: lane owns column n0+wn0+b*32+li; register x is row (x&3)+8*(x>>2)+4*lh of the 32x32 tile
   const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
-  float* C = g.C + (size_t)blockIdx.z * (size_t)g.M * g.ldc;
+  const bool accum = g.accumulate != 0;  // K slices add into one C (hardware fp32 atomics) instead of writing slabs
+  float* C = g.C + (accum ? (size_t)0 : (size_t)blockIdx.z * (size_t)g.M * g.ldc);
 #pragma unroll
   for (int b = 0; b < FN; ++b) {
     const int col = n0 + wn0 + b * 32 + li;
@@ -222,7 +223,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
         if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
         if (epi == ADDHIP_EPI_MASK) v = mk[x] > 0.f ? v : 0.f;
         if (col_ok && row < g.M) {
-          C[(size_t)row * g.ldc + col] = v;
+          if (accum) unsafeAtomicAdd(&C[(size_t)row * g.ldc + col], v);
+          else C[(size_t)row * g.ldc + col] = v;
           if (epi == ADDHIP_EPI_MASK) cs += v;
         }
         if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {  // uniform branch; lanes 0-31 hold one row, lanes 32-63 the row 4 below
@@ -401,6 +403,7 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   if (g.relu_bits) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_BIAS_RELU && g.M > SMALL_M && g.ldbits * 32 >= g.N && g.split_k <= 1,
                                   "gemm: relu_bits need the BIAS_RELU epilogue, M > 8 and ldbits >= ceil(N/32)");
   if (g.split_k > 1) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_NONE, "gemm: split-K slabs take no epilogue");
+  if (g.accumulate) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_NONE && !g.colsum, "gemm: accumulate takes no epilogue");
   if (g.a_mean || g.a_std) ADDHIP_REQUIRE(g.a_kcontig && g.a_mean && g.a_std, "gemm: fused normalisation needs a k-contiguous A and both mean/std");
   if (g.colsum) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && g.split_k <= 1, "gemm: colsum needs the MASK epilogue");
   ADDHIP_REQUIRE(g.precision == ADDHIP_PREC_F32 || g.precision == ADDHIP_PREC_BF16 || g.precision == ADDHIP_PREC_BF16X2 ||

@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
 
   // epilogue: lane owns column n0+wn0+b*32+li; register x is row (x&3)+8*(x>>2)+4*lh of the 32x32 tile
   const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
-  float* C = g.C + (size_t)blockIdx.z * (size_t)g.M * g.ldc;
+  const bool accum = g.accumulate != 0;  // K slices add into one C (hardware fp32 atomics) instead of writing slabs
+  float* C = g.C + (accum ? (size_t)0 : (size_t)blockIdx.z * (size_t)g.M * g.ldc);
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int col = n0 + wn0 + b * 32 + li;
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
         if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
         if (epi == ADDHIP_EPI_MASK) v = mk[x] > 0.f ? v : 0.f;
         if (col_ok && row < g.M) {
-          C[(size_t)row * g.ldc + col] = v;
+          if (accum) unsafeAtomicAdd(&C[(size_t)row * g.ldc + col], v);
+          else C[(size_t)row * g.ldc + col] = v;
           if (epi == ADDHIP_EPI_MASK) cs += v;
         }
         if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {  // uniform branch; lanes 0-31 hold one row, lanes 32-63 the row 4 below

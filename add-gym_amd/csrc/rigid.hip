@@ -18,8 +18,8 @@
 // (pelvis, torso) in LDS.  Every lane of a wave visits the same body at the same time: body constants and the traversal
 // tables are wave-uniform scalar loads, LDS arrays are [field][lane] (conflict-free), the state rows are staged through LDS
 // with coalesced loads/stores.  Per-lane LDS: pose 36 + velocity 36 + target 32 + sin/cos 64 + U 192 + 1/D, u 64 +
-// 4 branch accumulators x 27 floats = 532 floats (133 KB per workgroup); body velocities / up-vectors live in private (scratch)
-// arrays that stay in L2.
+// 4 branch accumulators x 27 floats = 532 floats (133 KB per workgroup) + 11 KB of model constants staged once per workgroup;
+// body velocities / up-vectors live in private (scratch) arrays that stay in L2.
 #include "common.h"
 
 namespace {
@@ -29,6 +29,7 @@ constexpr int WG = 64;         // environments (lanes) per workgroup
 constexpr int BW = ADDHIP_RIGID_BODY_W;
 constexpr int TW = ADDHIP_RIGID_TOPO_W;
 constexpr int MAX_SLOTS = 4;   // branch bodies (more than one child)
+constexpr int MAXP = 384;      // collision points
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -103,7 +104,7 @@ __device__ __forceinline__ float comp(V3 v, int ax) { return ax == 0 ? v.x : (ax
 __device__ __forceinline__ V3 unit(int ax) { return {ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f}; }
 
 // child -> parent rotation  R = Rfix * Rot(axis, theta)
-__device__ __forceinline__ M3 joint_rot(const float* __restrict__ rf, int ax, float s, float c) {
+__device__ __forceinline__ M3 joint_rot(const float* rf, int ax, float s, float c) {
   M3 R;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -118,6 +119,8 @@ __device__ __forceinline__ M3 joint_rot(const float* __restrict__ rf, int ax, fl
 // LDS field offsets (floats per lane)
 constexpr int F_POSE = 0, F_VEL = 36, F_TGT = 72, F_SIN = 104, F_COS = 136, F_U = 168, F_DINV = 360, F_UU = 392, F_SLOT = 424;
 constexpr int F_TOTAL = F_SLOT + MAX_SLOTS * 27;
+// after the per-lane fields: the model's constant tables, staged once per workgroup (wave-uniform addresses: LDS broadcasts)
+constexpr int C_BODY = F_TOTAL * WG, C_TOPO = C_BODY + MAXB * BW, C_PTS = C_TOPO + MAXB * TW, LDS_FLOATS = C_PTS + MAXP * 4;
 
 __device__ __forceinline__ void store_art(float* p, const ArtI& I, const Sp6& f) {  // p points at lds[...][lane], stride WG
   const float v[27] = {I.A.xx, I.A.xy, I.A.xz, I.A.yy, I.A.yz, I.A.zz, I.B.m[0], I.B.m[1], I.B.m[2], I.B.m[3], I.B.m[4], I.B.m[5], I.B.m[6], I.B.m[7], I.B.m[8],
@@ -153,7 +156,13 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
     const int row = idx >> 5, col = idx & 31;
     lds[(F_TGT + col) * WG + row] = col < 29 ? target[(size_t)(env0 + row) * tstride + col] : 0.f;
   }
+  for (int i = lane; i < M.num_bodies * BW; i += WG) lds[C_BODY + i] = M.body[i];
+  for (int i = lane; i < M.num_bodies * TW; i += WG) reinterpret_cast<int*>(lds)[C_TOPO + i] = M.topo[i];
+  for (int i = lane; i < M.num_points * 4; i += WG) lds[C_PTS + i] = M.points[i];
   __syncthreads();
+  const float* const cbody = lds + C_BODY;
+  const int* const ctopo = reinterpret_cast<const int*>(lds) + C_TOPO;
+  const float* const cpts = lds + C_PTS;
   const bool on = lane < live;  // lanes past the last env run on zeros (kept in step: no divergence, never written back)
   if (!on) {
     for (int c = 0; c < 36; ++c) { LD(F_POSE, c) = (c == 3) ? 1.f : 0.f; LD(F_VEL, c) = 0.f; }
@@ -178,16 +187,19 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
     M3 R0 = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
               2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
               2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)}};
-    // ---------------- pass 1 (outward): velocities, up-vector, height
+    // ---------------- pass 1 (outward): velocities, up-vector, height.  In depth-first order the parent of body k is k-1 along
+    // a chain: its state is carried in registers; only the first body of a limb re-reads its (branch) parent from scratch.
+    V3 cw, cv, cnz; float ch;  // state of body k-1
     {
-      const V3 w0 = mulT(R0, ww), v0 = mulT(R0, vw);
-      bv[0][0] = w0.x; bv[0][1] = w0.y; bv[0][2] = w0.z; bv[0][3] = v0.x; bv[0][4] = v0.y; bv[0][5] = v0.z;
-      bnz[0][0] = R0.m[6]; bnz[0][1] = R0.m[7]; bnz[0][2] = R0.m[8];
-      bh[0] = pos.z;
+      cw = mulT(R0, ww); cv = mulT(R0, vw);
+      cnz = {R0.m[6], R0.m[7], R0.m[8]}; ch = pos.z;
+      bv[0][0] = cw.x; bv[0][1] = cw.y; bv[0][2] = cw.z; bv[0][3] = cv.x; bv[0][4] = cv.y; bv[0][5] = cv.z;
+      bnz[0][0] = cnz.x; bnz[0][1] = cnz.y; bnz[0][2] = cnz.z;
+      bh[0] = ch;
     }
     for (int k = 1; k < nb; ++k) {
-      const float* __restrict__ bc = M.body + k * BW;
-      const int* __restrict__ tp = M.topo + k * TW;
+      const float* bc = cbody + k * BW;
+      const int* tp = ctopo + k * TW;
       const int par = tp[0], ax = tp[1], dof = tp[2];
       const float q = LD(F_POSE, 7 + dof), qd = LD(F_VEL, 6 + dof);
       float s, c;
@@ -195,27 +207,42 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
       LD(F_SIN, k) = s; LD(F_COS, k) = c;
       const M3 R = joint_rot(bc + 3, ax, s, c);
       const V3 r{bc[0], bc[1], bc[2]};
-      const V3 wp{bv[par][0], bv[par][1], bv[par][2]}, vp{bv[par][3], bv[par][4], bv[par][5]};
-      V3 w = mulT(R, wp);
-      const V3 vl = mulT(R, vp - cross(r, wp));
+      if (par != k - 1) {  // wave-uniform
+        cw = {bv[par][0], bv[par][1], bv[par][2]}; cv = {bv[par][3], bv[par][4], bv[par][5]};
+        cnz = {bnz[par][0], bnz[par][1], bnz[par][2]}; ch = bh[par];
+      }
+      V3 w = mulT(R, cw);
+      const V3 vl = mulT(R, cv - cross(r, cw));
       if (ax == 0) w.x += qd; else if (ax == 1) w.y += qd; else w.z += qd;
       bv[k][0] = w.x; bv[k][1] = w.y; bv[k][2] = w.z; bv[k][3] = vl.x; bv[k][4] = vl.y; bv[k][5] = vl.z;
-      const V3 nzp{bnz[par][0], bnz[par][1], bnz[par][2]};
-      const V3 nz = mulT(R, nzp);
+      const V3 nz = mulT(R, cnz);
       bnz[k][0] = nz.x; bnz[k][1] = nz.y; bnz[k][2] = nz.z;
-      bh[k] = bh[par] + dot(nzp, r);
+      ch = ch + dot(cnz, r);
+      bh[k] = ch;
+      cw = w; cv = vl; cnz = nz;
     }
     // ---------------- pass 2 (inward, reverse depth-first order)
     ArtI carryI; Sp6 carryP;  // contribution of body k+1 to its chain parent k, in k's coordinates
     for (int s = 0; s < MAX_SLOTS * 27; ++s) LD(F_SLOT, s) = 0.f;
+    // the pass-1 results of the NEXT body are fetched from scratch while the current one is worked on
+    float nx[10];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nx[i] = bv[nb - 1][i];
+    nx[6] = bnz[nb - 1][0]; nx[7] = bnz[nb - 1][1]; nx[8] = bnz[nb - 1][2]; nx[9] = bh[nb - 1];
     for (int k = nb - 1; k >= 0; --k) {
-      const float* __restrict__ bc = M.body + k * BW;
-      const int* __restrict__ tp = M.topo + k * TW;
+      const float* bc = cbody + k * BW;
+      const int* tp = ctopo + k * TW;
       const int par = tp[0], ax = tp[1], dof = tp[2], nchild = tp[3], slot = tp[4], pt0 = tp[5], npt = tp[6], link = tp[7];
       const float mass = bc[12];
       const V3 mc{bc[13], bc[14], bc[15]};
-      const V3 w{bv[k][0], bv[k][1], bv[k][2]}, vl{bv[k][3], bv[k][4], bv[k][5]};
-      const V3 nz{bnz[k][0], bnz[k][1], bnz[k][2]};
+      const V3 w{nx[0], nx[1], nx[2]}, vl{nx[3], nx[4], nx[5]};
+      const V3 nz{nx[6], nx[7], nx[8]};
+      const float hk = nx[9];
+      if (k > 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) nx[i] = bv[k - 1][i];
+        nx[6] = bnz[k - 1][0]; nx[7] = bnz[k - 1][1]; nx[8] = bnz[k - 1][2]; nx[9] = bh[k - 1];
+      }
       // rigid-body inertia and bias:  pA = v x* (I v) - I a_g
       ArtI I;
       I.A = {bc[16], bc[17], bc[18], bc[19], bc[20], bc[21]};
@@ -240,9 +267,9 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
       }
       // ground contacts of this body's collision spheres
       for (int j = 0; j < npt; ++j) {
-        const float* __restrict__ pt = M.points + (pt0 + j) * 4;
+        const float* pt = cpts + (pt0 + j) * 4;
         const V3 r{pt[0], pt[1], pt[2]};
-        const float d = pt[3] - (bh[k] + dot(nz, r));
+        const float d = pt[3] - (hk + dot(nz, r));
         if (d > 0.f) {
           touch |= 1u << link;
           const V3 vp = vl + cross(w, r);
@@ -319,7 +346,7 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
       Sp6 pp;
       pp.l = mul(R, p.l);
       pp.a = mul(R, p.a) + cross(r, pp.l);
-      const int pslot = M.topo[par * TW + 4];
+      const int pslot = ctopo[par * TW + 4];
       if (pslot >= 0) {
         float* sp = &LD(F_SLOT, pslot * 27);
         ArtI Z; Sp6 z0;
@@ -379,26 +406,29 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
       for (int i = 0; i < 6; ++i) a0[i] = b[i];
     }
     // ---------------- pass 3 (outward): accelerations; joints are integrated as they are visited
-    // bv[k] is overwritten with the body's acceleration once its own velocity has been used
+    // the parent's acceleration is carried in registers along a chain; branch bodies also park theirs in bv[] (their own
+    // velocity is no longer needed by then) for the limbs that start from them
     float root_a[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) { root_a[i] = a0[i]; bv[0][i] = a0[i]; }
+    V3 caa{a0[0], a0[1], a0[2]}, cal{a0[3], a0[4], a0[5]};
     for (int k = 1; k < nb; ++k) {
-      const float* __restrict__ bc = M.body + k * BW;
-      const int* __restrict__ tp = M.topo + k * TW;
-      const int par = tp[0], ax = tp[1], dof = tp[2];
+      const float* bc = cbody + k * BW;
+      const int* tp = ctopo + k * TW;
+      const int par = tp[0], ax = tp[1], dof = tp[2], slot = tp[4];
       const M3 R = joint_rot(bc + 3, ax, LD(F_SIN, k), LD(F_COS, k));
       const V3 r{bc[0], bc[1], bc[2]};
-      const V3 apa{bv[par][0], bv[par][1], bv[par][2]}, apl{bv[par][3], bv[par][4], bv[par][5]};
       const V3 w{bv[k][0], bv[k][1], bv[k][2]}, vl{bv[k][3], bv[k][4], bv[k][5]};
+      if (par != k - 1) { caa = {bv[par][0], bv[par][1], bv[par][2]}; cal = {bv[par][3], bv[par][4], bv[par][5]}; }
       const float qd = LD(F_VEL, 6 + dof);
       const V3 e = unit(ax);
-      V3 aa = mulT(R, apa) + qd * cross(w, e);
-      const V3 al = mulT(R, apl - cross(r, apa)) + qd * cross(vl, e);
+      V3 aa = mulT(R, caa) + qd * cross(w, e);
+      const V3 al = mulT(R, cal - cross(r, caa)) + qd * cross(vl, e);
       const V3 Ua{LD(F_U, 6 * k), LD(F_U, 6 * k + 1), LD(F_U, 6 * k + 2)}, Ul{LD(F_U, 6 * k + 3), LD(F_U, 6 * k + 4), LD(F_U, 6 * k + 5)};
       const float qdd = (LD(F_UU, k) - dot(Ua, aa) - dot(Ul, al)) * LD(F_DINV, k);
       if (ax == 0) aa.x += qdd; else if (ax == 1) aa.y += qdd; else aa.z += qdd;
-      bv[k][0] = aa.x; bv[k][1] = aa.y; bv[k][2] = aa.z; bv[k][3] = al.x; bv[k][4] = al.y; bv[k][5] = al.z;
+      if (slot >= 0) { bv[k][0] = aa.x; bv[k][1] = aa.y; bv[k][2] = aa.z; bv[k][3] = al.x; bv[k][4] = al.y; bv[k][5] = al.z; }
+      caa = aa; cal = al;
       const float qdn = qd + h * qdd;
       LD(F_VEL, 6 + dof) = qdn;
       LD(F_POSE, 7 + dof) = LD(F_POSE, 7 + dof) + h * qdn;
@@ -448,9 +478,10 @@ extern "C" int addhip_rigid_step(const addhip_rigid_model_t* m, float* sim_pose,
   ADDHIP_REQUIRE(num_envs > 0 && target_stride >= ADDHIP_NUM_DOF, "rigid_step: bad sizes");
   ADDHIP_REQUIRE(m->num_bodies == ADDHIP_NUM_DOF + 1, "rigid_step: the packed state rows hold %d hinge dofs", ADDHIP_NUM_DOF);
   ADDHIP_REQUIRE(m->body && m->topo && (m->points || m->num_points == 0), "rigid_step: model tables missing");
+  ADDHIP_REQUIRE(m->num_points >= 0 && m->num_points <= MAXP, "rigid_step: at most %d collision points", MAXP);
   ADDHIP_REQUIRE(m->substeps >= 1 && m->substeps <= 64 && m->dt > 0.f, "rigid_step: bad dt / substeps");
   static bool attr_set = false;
-  const size_t shmem = sizeof(float) * F_TOTAL * WG;
+  const size_t shmem = sizeof(float) * LDS_FLOATS;
   if (!attr_set) {
     ADDHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     attr_set = true;

@@ -220,6 +220,10 @@ typedef struct {
   uint32_t* relu_bits;
   const uint32_t* mask_bits;
   int32_t ldbits;
+  /* split_k > 1 with accumulate != 0: instead of writing split_k partial slabs, every K slice ADDS its partial product into the one
+   * C[M,ldc] with hardware fp32 atomics (no epilogue; the caller zeroes C, e.g. the flat gradient buffer at the start of an optimiser
+   * step; several GEMMs may accumulate into the same C).  Summation order is not fixed: results vary in the last bits run to run. */
+  int32_t accumulate;
 } addhip_gemm_t;
 int addhip_gemm_f32(const addhip_gemm_t* g, void* stream);
 

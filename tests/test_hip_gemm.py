@@ -31,7 +31,7 @@ def T(x):
 TOL = {0: 4e-7, 3: 4e-7, 2: 2.0 ** -14, 1: 2.0 ** -6}
 
 
-def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, seed=0, precision=0):
+def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, seed=0, precision=0, accumulate=0):
     import torch
     import add_gym_amd._lib as L
     from add_gym_amd.hotpath import gemm
@@ -48,11 +48,12 @@ def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, 
     dA = T(A if a_kc else A.T.copy())
     dB = T(B if b_kc else B.T.copy())
     ldc = (N + 3) // 4 * 4
-    dC = torch.full((max(split_k, 1), M, ldc), 9.0, device="cuda")
+    dC = torch.full((1 if accumulate else max(split_k, 1), M, ldc), 9.0, device="cuda")
     dbias, dmask, dmean, dstd = T(bias), T(mask), T(mean), T(std)
     dcs = torch.full((N,), 0.5, device="cuda")  # MASK epilogue also accumulates the column sums (bias gradient) here
     g = gemm(M, N, K, L.ptr(dA), lda, a_kc, L.ptr(dB), ldb, b_kc, L.ptr(dC), ldc, epilogue, L.ptr(dbias), L.ptr(dmask), N,
-             L.ptr(dmean) if norm else None, L.ptr(dstd) if norm else None, split_k, alpha, L.ptr(dcs) if epilogue == 3 else None, precision)
+             L.ptr(dmean) if norm else None, L.ptr(dstd) if norm else None, split_k, alpha, L.ptr(dcs) if epilogue == 3 else None, precision,
+             accumulate=accumulate)
     L.call("addhip_gemm_f32", g, L.current_stream())
     torch.cuda.synchronize()
     A64 = A.astype(np.float64)
@@ -67,7 +68,9 @@ def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, 
     if epilogue == 3:
         ref = np.where(mask > 0, ref, 0)
     out = dC.cpu().numpy().astype(np.float64)
-    got = out.sum(0)[:, :N] if split_k > 1 else out[0][:, :N]
+    got = out.sum(0)[:, :N] if split_k > 1 and not accumulate else out[0][:, :N]
+    if accumulate:  # every K slice added its partial product into the prefilled C (hardware atomics)
+        got = got - 9.0
     err = np.abs(got - ref)
     tol = TOL[precision]
     if epilogue == 3 and precision == 1:  # a sign flip of a near-zero masked value is not an error of the product
@@ -116,6 +119,15 @@ def test_gemm_split_bf16_paths(a_kc, b_kc, precision):
             run_gemm(16385, 512, 1024, 1, b_kc, epilogue=epi, precision=precision)
     if a_kc and b_kc:
         run_gemm(16384, 1024, 264, 1, 1, epilogue=2, norm=True, precision=precision)
+
+
+@pytest.mark.parametrize("precision", [0, 3])
+def test_gemm_split_k_accumulates_by_atomics(precision):
+    """accumulate=1: the K slices add into ONE C instead of writing slabs (the weight-gradient GEMMs of the update step)."""
+    run_gemm(1024, 1024, 16384, 0, 0, split_k=8, precision=precision, accumulate=1)
+    run_gemm(1024, 272, 16385, 0, 0, split_k=22, precision=precision, accumulate=1)
+    run_gemm(32, 512, 4096, 0, 0, split_k=32, precision=precision, accumulate=1)
+    run_gemm(512, 1024, 16384, 0, 0, split_k=16, alpha=0.5, precision=precision, accumulate=1)
 
 
 def test_gemm_split_error_is_at_fp32_level():
