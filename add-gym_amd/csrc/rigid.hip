@@ -31,6 +31,9 @@ constexpr int TW = ADDHIP_RIGID_TOPO_W;
 constexpr int MAX_SLOTS = 4;   // branch bodies (more than one child)
 constexpr int MAXP = 384;      // collision points
 
+typedef const float __attribute__((address_space(4))) cfloat;
+typedef const int __attribute__((address_space(4))) cint;
+
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -104,7 +107,7 @@ __device__ __forceinline__ float comp(V3 v, int ax) { return ax == 0 ? v.x : (ax
 __device__ __forceinline__ V3 unit(int ax) { return {ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f}; }
 
 // child -> parent rotation  R = Rfix * Rot(axis, theta)
-__device__ __forceinline__ M3 joint_rot(const float* rf, int ax, float s, float c) {
+__device__ __forceinline__ M3 joint_rot(const cfloat* rf, int ax, float s, float c) {
   M3 R;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -119,8 +122,7 @@ __device__ __forceinline__ M3 joint_rot(const float* rf, int ax, float s, float 
 // LDS field offsets (floats per lane)
 constexpr int F_POSE = 0, F_VEL = 36, F_TGT = 72, F_SIN = 104, F_COS = 136, F_U = 168, F_DINV = 360, F_UU = 392, F_SLOT = 424;
 constexpr int F_TOTAL = F_SLOT + MAX_SLOTS * 27;
-// after the per-lane fields: the model's constant tables, staged once per workgroup (wave-uniform addresses: LDS broadcasts)
-constexpr int C_BODY = F_TOTAL * WG, C_TOPO = C_BODY + MAXB * BW, C_PTS = C_TOPO + MAXB * TW, LDS_FLOATS = C_PTS + MAXP * 4;
+constexpr int LDS_FLOATS = F_TOTAL * WG;
 
 __device__ __forceinline__ void store_art(float* p, const ArtI& I, const Sp6& f) {  // p points at lds[...][lane], stride WG
   const float v[27] = {I.A.xx, I.A.xy, I.A.xz, I.A.yy, I.A.yz, I.A.zz, I.B.m[0], I.B.m[1], I.B.m[2], I.B.m[3], I.B.m[4], I.B.m[5], I.B.m[6], I.B.m[7], I.B.m[8],
@@ -156,13 +158,12 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
     const int row = idx >> 5, col = idx & 31;
     lds[(F_TGT + col) * WG + row] = col < 29 ? target[(size_t)(env0 + row) * tstride + col] : 0.f;
   }
-  for (int i = lane; i < M.num_bodies * BW; i += WG) lds[C_BODY + i] = M.body[i];
-  for (int i = lane; i < M.num_bodies * TW; i += WG) reinterpret_cast<int*>(lds)[C_TOPO + i] = M.topo[i];
-  for (int i = lane; i < M.num_points * 4; i += WG) lds[C_PTS + i] = M.points[i];
   __syncthreads();
-  const float* const cbody = lds + C_BODY;
-  const int* const ctopo = reinterpret_cast<const int*>(lds) + C_TOPO;
-  const float* const cpts = lds + C_PTS;
+  // the model tables are read-only for the whole launch and every lane of a wave reads the same element: address them through
+  // the constant address space, so that they arrive by scalar loads (SGPR operands, scalar cache) instead of per-lane loads
+  const cfloat* const cbody = (cfloat*)(uintptr_t)M.body;
+  const cint* const ctopo = (cint*)(uintptr_t)M.topo;
+  const cfloat* const cpts = (cfloat*)(uintptr_t)M.points;
   const bool on = lane < live;  // lanes past the last env run on zeros (kept in step: no divergence, never written back)
   if (!on) {
     for (int c = 0; c < 36; ++c) { LD(F_POSE, c) = (c == 3) ? 1.f : 0.f; LD(F_VEL, c) = 0.f; }
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
       bh[0] = ch;
     }
     for (int k = 1; k < nb; ++k) {
-      const float* bc = cbody + k * BW;
-      const int* tp = ctopo + k * TW;
+      const cfloat* bc = cbody + k * BW;
+      const cint* tp = ctopo + k * TW;
       const int par = tp[0], ax = tp[1], dof = tp[2];
       const float q = LD(F_POSE, 7 + dof), qd = LD(F_VEL, 6 + dof);
       float s, c;
@@ -230,8 +231,8 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
     for (int i = 0; i < 6; ++i) nx[i] = bv[nb - 1][i];
     nx[6] = bnz[nb - 1][0]; nx[7] = bnz[nb - 1][1]; nx[8] = bnz[nb - 1][2]; nx[9] = bh[nb - 1];
     for (int k = nb - 1; k >= 0; --k) {
-      const float* bc = cbody + k * BW;
-      const int* tp = ctopo + k * TW;
+      const cfloat* bc = cbody + k * BW;
+      const cint* tp = ctopo + k * TW;
       const int par = tp[0], ax = tp[1], dof = tp[2], nchild = tp[3], slot = tp[4], pt0 = tp[5], npt = tp[6], link = tp[7];
       const float mass = bc[12];
       const V3 mc{bc[13], bc[14], bc[15]};
@@ -265,9 +266,12 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
       } else if (slot >= 0) {
         add_art(&LD(F_SLOT, slot * 27), I, p);
       }
-      // ground contacts of this body's collision spheres
+      // ground contacts of this body's collision spheres (skipped for the whole wave while the body's bounding sphere is clear
+      // of the ground in every lane)
+      const bool near = hk < bc[29];
+      if (__any(near))
       for (int j = 0; j < npt; ++j) {
-        const float* pt = cpts + (pt0 + j) * 4;
+        const cfloat* pt = cpts + (pt0 + j) * 4;
         const V3 r{pt[0], pt[1], pt[2]};
         const float d = pt[3] - (hk + dot(nz, r));
         if (d > 0.f) {
@@ -413,8 +417,8 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
     for (int i = 0; i < 6; ++i) { root_a[i] = a0[i]; bv[0][i] = a0[i]; }
     V3 caa{a0[0], a0[1], a0[2]}, cal{a0[3], a0[4], a0[5]};
     for (int k = 1; k < nb; ++k) {
-      const float* bc = cbody + k * BW;
-      const int* tp = ctopo + k * TW;
+      const cfloat* bc = cbody + k * BW;
+      const cint* tp = ctopo + k * TW;
       const int par = tp[0], ax = tp[1], dof = tp[2], slot = tp[4];
       const M3 R = joint_rot(bc + 3, ax, LD(F_SIN, k), LD(F_COS, k));
       const V3 r{bc[0], bc[1], bc[2]};

@@ -93,6 +93,7 @@ class RigidModelTables:
             elif nch == 1 and pos_of[children[b][0]] != k + 1:
                 raise AssertionError("depth-first order broken")
             pts = [(f(g.attrib["pos"]), float(g.attrib["size"].split()[0])) for g in node.findall("geom")]
+            row[29] = max([float(np.linalg.norm(p)) + rad for p, rad in pts], default=0.0)  # bounding radius of the collision spheres
             topo[k] = [pos_of[parent[b]] if b > 0 else -1, axis, b - 1, nch, slot, len(points), len(pts), b]
             points += [[p[0], p[1], p[2], rad] for p, rad in pts]
         if slots > self.MAX_BRANCH:

@@ -29,6 +29,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix), v_mfma_
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, 32 cycles per instruction per SIMD)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy ceiling)
 ENV_STEP_BYTES = 4573         # algorithmic bytes per env-step of the fused obs/reward/done kernel
+VALU_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
+RIGID_FLOP_PER_SUBSTEP = 44000  # fp32 operations of one articulated-body sweep of the 30-body G1 (29 x ~1400 per body + root solve + contacts)
 
 
 def parse():
@@ -45,6 +47,16 @@ def parse():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x2", "bf16"],
                     help="agent.matmul_precision: how addhip_gemm_f32 forms its fp32 products (include/addhip.h ADDHIP_PREC_*)")
     return ap.parse_args()
+
+
+def traffic(key):
+    """HBM bytes per launch from the committed PMC profiles (profiles/traffic.json, written from rocprofv3 --pmc passes): (bytes, source)
+    or (None, None).  Never a constant in this file: the JSON names the profile each figure came from."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]
+        return float(e["traffic_bytes_per_launch"]), e["source"]
+    except Exception:
+        return None, None
 
 
 def time_gemms(agent, reps=3):
@@ -80,31 +92,74 @@ def gemm_roofline(agent, precision):
     tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
     if precision == "fp32":
         peak, kern = MFMA_F32_PEAK_TFLOPS, "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all GEMM launches of one optimiser step)"
-        # PMC, profiles/r01_gemm_pmc.md: (WRITE_SIZE 1269.5 MB + 2 x FETCH_SIZE 2280.2 MB) / 33 launches of one optimiser step
-        traffic = (1269.5e6 + 2 * 2280.2e6) / 33
+        tr, tr_src = traffic("gemm_fp32_step")
     else:
         products = {"bf16x3": 6, "bf16x2": 3, "bf16": 1}[precision]
         peak = MFMA_BF16_PEAK_TFLOPS / products
         kern = "gemm_split_kernel (v_mfma_f32_32x32x16_bf16 x %d per k-step; small shapes stay on gemm_kernel); all GEMM launches of one optimiser step" % products
-        traffic = None
-    return {"bound": "mfma", "kernel": kern, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic,
+        tr, tr_src = None, None
+    return {"bound": "mfma", "kernel": kern, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": tr, "traffic_source": tr_src,
             "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"],
             "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS}
 
 
-def env_step_at_scale(num_envs=65536):
+def env_step_at_scale(num_envs=65536, motion="synthetic:1x3600"):
     """The fused env step alone at a size where it is not launch-latency bound (same kernels, same task config)."""
     import add_gym_amd  # noqa: F401
     from add_gym_amd.config import load_config
     from add_gym_amd.learning.add_agent import ADDAgent
 
-    cfg = load_config("train", [f"engine.num_envs={num_envs}", "agent.steps_per_iter=2", "agent.batch_size=1", "task.motion_file=synthetic:1x3600"])
+    cfg = load_config("train", [f"engine.num_envs={num_envs}", "agent.steps_per_iter=2", "agent.batch_size=1", f"task.motion_file={motion}"])
     ag = ADDAgent(cfg)
     ag.reset_all_envs()
     ag._init_train()
     gc.collect()
     gc.freeze()
-    return time_env_step(ag, reps=50)
+    ms = time_env_step(ag, reps=50)
+    table_mb = 2 * ag._motion_lib.total_steps * 36 * 4 / 1e6
+    del ag
+    return ms, table_mb
+
+
+def rigid_step_roofline(num_envs):
+    """The rigid-body engine's control step alone (addhip_rigid_step: `substeps` articulated-body sweeps per launch) on standing
+    robots.  Neither HBM- nor MFMA-bound: one lane per env, dependent fp32 VALU chains, one wave per SIMD; reported against the
+    fp32 vector peak with the kernel's arithmetic counted from its own operation list."""
+    import torch
+    import add_gym_amd  # noqa: F401
+    from add_gym_amd.config import load_config
+    from add_gym_amd.envs.env import ImitationEnvironment
+
+    cfg = load_config("train", ["engine=rigid", f"engine.num_envs={num_envs}"])
+    env = ImitationEnvironment(cfg, torch.device("cuda", torch.cuda.current_device()))
+    ent = env.robot.entity
+    pose0 = ent.pose.clone()
+    pose0[:, 2] = 0.79
+    tgt = (torch.randn(num_envs, 32, device="cuda") * 0.1).contiguous()
+    ent.control_dofs_position(tgt)
+    st = torch.cuda.current_stream()
+    tot, cnt = 0.0, 0
+    for chunk in range(4):
+        ent.pose.copy_(pose0)
+        ent.vel.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(20):
+            env.scene.step()
+        e1.record(st)
+        e1.synchronize()
+        if chunk:
+            tot += e0.elapsed_time(e1)
+            cnt += 20
+    ms = tot / cnt
+    sub = int(ent._opts["substeps"])
+    flop = RIGID_FLOP_PER_SUBSTEP * sub * num_envs
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"bound": "valu-latency", "kernel": "rigid_step_kernel (addhip_rigid_step, %d substeps per launch)" % sub, "achieved": tf, "peak": VALU_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / VALU_F32_PEAK_TFLOPS, "traffic": None, "us_per_launch": ms * 1e3, "envs": num_envs,
+            "env_steps_per_s": num_envs / (ms * 1e-3), "flop_per_env_substep": RIGID_FLOP_PER_SUBSTEP,
+            "algorithmic_bytes_per_env_step": 2 * 2 * 36 * 4 + 29 * 4 + 5,
+            "note": "latency-bound by construction: every env is one lane walking a 30-body tree three times per substep"}
 
 
 def time_env_step(agent, reps=50, chunk=10):
@@ -221,8 +276,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_agent(precision):
-        cfg = load_config("train", [f"engine.num_envs={a.envs}", "task.motion_file=synthetic:1x3600", f"seed={1 + rank}",
+    def make_agent(precision, engine="kinematic"):
+        cfg = load_config("train", [f"engine={engine}", f"engine.num_envs={a.envs}", "task.motion_file=synthetic:1x3600", f"seed={1 + rank}",
                                     f"agent.matmul_precision={precision}"])
         ag = ADDAgent(cfg, distributed=distributed)
         ag.reset_all_envs()
@@ -272,12 +327,14 @@ def main():
                                     "envs": agent.N, "note": "launch-latency scale at this env count; see roofline_env_step_65536"}
         if world == 1:
             big = 65536
-            ms2 = env_step_at_scale(big)
-            gbs2 = ENV_STEP_BYTES * big / (ms2 * 1e-3) / 1e9
-            # PMC traffic per launch at 65536 envs (profiles/r01_env_step_pmc.md): WRITE_SIZE 148.4 MB + 2 x FETCH_SIZE 52.3 MB
-            out["roofline_env_step_65536"] = {"bound": "hbm", "kernel": "env_step_kernel (addhip_env_step)", "achieved": gbs2,
-                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs2 / HBM_PEAK_GBS, "traffic": 253.0e6,
-                                              "us_per_launch": ms2 * 1e3, "envs": big}
+            for key, motion in (("roofline_env_step_65536", "synthetic:1x3600"), ("roofline_env_step_65536_fulltable", "synthetic:43x3600")):
+                ms2, table_mb = env_step_at_scale(big, motion)
+                gbs2 = ENV_STEP_BYTES * big / (ms2 * 1e-3) / 1e9
+                tr, tr_src = traffic(key[len("roofline_"):])
+                out[key] = {"bound": "hbm", "kernel": "env_step_kernel (addhip_env_step)", "achieved": gbs2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": gbs2 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src, "us_per_launch": ms2 * 1e3, "envs": big,
+                            "motion_library": motion, "step_tables_mb": table_mb}
+            out["roofline_rigid_step"] = rigid_step_roofline(a.envs)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_envs, agent.T)
     if a.precision == "fp32" and not a.no_alt:
@@ -299,6 +356,16 @@ def main():
             del agent2
         if rank == 0:
             out["alt_precision"] = alts
+    if not a.no_alt:
+        # Same workload with the rigid-body engine (engine=rigid: articulated-body dynamics + PD + ground contact, csrc/rigid.hip)
+        # in place of the kinematic stand-in the headline uses (the headline keeps BASELINE.md's "physics excluded" protocol).
+        agent3 = make_agent(a.precision, engine="rigid")
+        dt3 = timed(agent3)
+        if rank == 0:
+            out["alt_engine"] = {"engine": "rigid (add_gym_amd.engine.rigid_engine.RigidBodyEngine, 4 substeps per control step)",
+                                 "value": env_steps / dt3, "unit": "env-steps/s", "ms_per_step": 1000.0 * dt3 / a.steps,
+                                 "matmul_precision": a.precision}
+        del agent3
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

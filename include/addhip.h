@@ -170,7 +170,8 @@ typedef struct {
   int32_t num_points;
   /* per body, in TRAVERSAL order (depth-first pre-order: a single child directly follows its parent), ADDHIP_RIGID_BODY_W floats:
    *   0-2 offset in the parent frame | 3-11 child->parent rotation at q=0 (row major) | 12 mass | 13-15 mass*com |
-   *   16-21 inertia about the body origin xx xy xz yy yz zz | 22 lo 23 hi | 24 damping 25 armature 26 |torque| limit | 27 kp 28 kv */
+   *   16-21 inertia about the body origin xx xy xz yy yz zz | 22 lo 23 hi | 24 damping 25 armature 26 |torque| limit | 27 kp 28 kv |
+   *   29 radius of the sphere about the body origin that holds all its collision spheres (0 if none) */
   const float* body;
   /* per body, traversal order, ADDHIP_RIGID_TOPO_W ints: parent (traversal index) | hinge axis 0/1/2 (x/y/z of the body frame) |
    *   dof column (breadth-first: column 7+dof of the pose row) | number of children | branch accumulator slot (-1 unless the

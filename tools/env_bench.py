@@ -5,9 +5,14 @@ import torch, add_gym_amd
 import add_gym_amd._lib as L
 from add_gym_amd.config import load_config
 from add_gym_amd.learning.add_agent import ADDAgent
-for N in [int(x) for x in (sys.argv[1:] or ["4096", "16384", "65536"])]:
-    cfg = load_config("train", [f"engine.num_envs={N}", "agent.steps_per_iter=2", "agent.batch_size=1"])
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+motion = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--motion=")), "synthetic:1x3600")
+print(f"motion library: {motion}", flush=True)
+for N in [int(x) for x in (args or ["4096", "16384", "65536"])]:
+    cfg = load_config("train", [f"engine.num_envs={N}", "agent.steps_per_iter=2", "agent.batch_size=1", f"task.motion_file={motion}"])
     ag = ADDAgent(cfg); ag.reset_all_envs(); ag._init_train()
+    lib = ag._motion_lib
+    print(f"step tables: {lib.get_num_motions()} clips, {lib.total_steps} rows, {2 * lib.total_steps * 36 * 4 / 1e6:.1f} MB", flush=True)
     st = torch.cuda.current_stream()
     gc.collect(); gc.freeze()  # a full collection inside the timed loop costs tens of ms
     out = ag._step_out[0]
