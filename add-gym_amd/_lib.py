@@ -104,7 +104,7 @@ SIGNATURES = {
     "addhip_norm_merge": [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
     "addhip_diffnorm_merge": [vp, vp, vp, i64, i32, vp],
     "addhip_gather_minibatch": [P(GatherT), vp],
-    "addhip_actor_loss": [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
+    "addhip_actor_loss": [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
     "addhip_count_mask": [vp, i32, vp, vp],
     "addhip_critic_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
     "addhip_disc_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
@@ -116,6 +116,7 @@ SIGNATURES = {
     "addhip_l2_grad": [vp, vp, i64, f32, vp, vp],
     "addhip_grad_clip": [vp, i64, f32, vp, vp, vp],
     "addhip_adamw": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
+    "addhip_sgd": [vp, vp, vp, i64, f32, f32, f32, i32, vp],
     "addhip_return_tracker_fold": [vp, i32, vp, vp],
 }
 

@@ -340,11 +340,11 @@ __global__ __launch_bounds__(256) void count_mask_kernel(const float* mask, int 
 
 __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, const float* na, const float* old_logp, const float* adv,
                                                          const float* mask, int M, float stdv, float logp_const, float clip, float bound_w,
-                                                         float loss_scale, const float* n_valid, float* d_mean, float* stats) {
+                                                         float reg_w, float loss_scale, const float* n_valid, float* d_mean, float* stats) {
   __shared__ float sh[4];
   const int lane = threadIdx.x & 63;
   const float nv = fmaxf(n_valid[0], 1.f);
-  float st_min = 0.f, st_clip = 0.f, st_ratio = 0.f, st_bound = 0.f;
+  float st_min = 0.f, st_clip = 0.f, st_ratio = 0.f, st_bound = 0.f, st_reg = 0.f;
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
     const bool valid = mask[r] == 1.0f;  // ppo_agent.py:229-233
     float mu = 0.f, d = 0.f, viol = 0.f;
@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, cons
     }
     float sq = wave_sum(d * d);
     float vs = wave_sum(viol * viol);
+    float ms = reg_w != 0.f ? wave_sum(mu * mu) : 0.f;  // DistributionGaussianDiag.param_reg (distribution_gaussian_diag.py:113-116)
     float logp = -0.5f * sq + logp_const;
     float ratio = expf(logp - old_logp[r]);
     float a = adv[r];
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, cons
     float g_logp = valid ? -(a * gsel * ratio) / nv : 0.f;
     if (lane < 32) {
       float g = 0.f;
-      if (valid && lane < ADDHIP_NUM_DOF) g = g_logp * (d / stdv) + bound_w * 2.f * viol / nv;
+      if (valid && lane < ADDHIP_NUM_DOF) g = g_logp * (d / stdv) + (bound_w * 2.f * viol + reg_w * 2.f * mu) / nv;
       d_mean[(size_t)r * 32 + lane] = loss_scale * g;
     }
     if (valid && lane == 0) {
@@ -374,11 +375,14 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, cons
       st_clip += fabsf(ratio - 1.f) > clip ? 1.f : 0.f;
       st_ratio += ratio;
       st_bound += vs;
+      st_reg += ms;
     }
   }
   float t0 = block_sum(st_min, sh), t1 = block_sum(st_clip, sh), t2 = block_sum(st_ratio, sh), t3 = block_sum(st_bound, sh);
+  float t5 = block_sum(st_reg, sh);
   if (threadIdx.x == 0) {  // per-minibatch MEANS over the exploring samples (ppo_agent.py:229-247): nv varies with exp_prob < 1
     atomicAdd(&stats[0], t0 / nv); atomicAdd(&stats[1], t1 / nv); atomicAdd(&stats[2], t2 / nv); atomicAdd(&stats[3], t3 / nv);
+    if (reg_w != 0.f) atomicAdd(&stats[5], t5 / nv);
   }
 }
 
@@ -563,6 +567,18 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long 
   }
 }
 
+// torch.optim.SGD single-tensor update with momentum (mp_optimizer.py:33-36: momentum 0.9, dampening 0, no nesterov):
+// g += wd p;  buf = first ? g : mu buf + g;  p -= lr buf
+__global__ void sgd_kernel(float* p, const float* g, float* buf, long long n, float lr, float mu, float wd, int first) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    if (wd != 0.f) gi = gi + wd * p[i];
+    const float b = first ? gi : buf[i] * mu + gi;
+    buf[i] = b;
+    p[i] = p[i] - lr * b;
+  }
+}
+
 // torch.nn.utils.clip_grad_norm_ (mp_optimizer.py:45-46): total 2-norm over the whole flat gradient, then
 // grad *= min(1, max_norm / (norm + 1e-6)).  scratch[0] receives the sum of squares (double), scratch[1] the norm (stats).
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* g, long long n, double* scratch) {
@@ -726,11 +742,11 @@ extern "C" int addhip_count_mask(const float* rand_mask, int32_t M, float* out, 
 }
 
 extern "C" int addhip_actor_loss(const float* mean, const float* norm_action, const float* old_logp, const float* adv, const float* rand_mask, int32_t M,
-                                 float stdv, float logp_const, float clip_ratio, float bound_weight, float loss_scale, const float* n_valid,
-                                 float* d_mean, float* stats, void* stream) {
+                                 float stdv, float logp_const, float clip_ratio, float bound_weight, float reg_weight, float loss_scale,
+                                 const float* n_valid, float* d_mean, float* stats, void* stream) {
   ADDHIP_REQUIRE(mean && norm_action && old_logp && adv && rand_mask && n_valid && d_mean && stats && M > 0, "actor_loss: bad arguments");
   hipLaunchKernelGGL(actor_loss_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, mean, norm_action, old_logp, adv, rand_mask, M,
-                     stdv, logp_const, clip_ratio, bound_weight, loss_scale, n_valid, d_mean, stats);
+                     stdv, logp_const, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, stats);
   return addhip::check_launch("actor_loss_kernel");
 }
 
@@ -804,6 +820,14 @@ extern "C" int addhip_adamw(float* param, const float* grad, float* exp_avg, flo
   hipLaunchKernelGGL(adamw_kernel, dim3(elem_grid(count)), dim3(256), 0, ST, param, grad, exp_avg, exp_avg_sq, (long long)count, lr, beta1, beta2, eps,
                      weight_decay, step_size, bc2_sqrt);
   return addhip::check_launch("adamw_kernel");
+}
+
+extern "C" int addhip_sgd(float* param, const float* grad, float* momentum_buf, int64_t count, float lr, float momentum, float weight_decay,
+                          int32_t step, void* stream) {
+  ADDHIP_REQUIRE(param && grad && momentum_buf && count > 0 && step >= 1, "sgd: bad arguments");
+  hipLaunchKernelGGL(sgd_kernel, dim3(elem_grid(count)), dim3(256), 0, ST, param, grad, momentum_buf, (long long)count, lr, momentum, weight_decay,
+                     step == 1 ? 1 : 0);
+  return addhip::check_launch("sgd_kernel");
 }
 
 extern "C" int addhip_grad_clip(float* grad, int64_t count, float max_norm, float* scratch, float* norm_out, void* stream) {

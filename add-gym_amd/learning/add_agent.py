@@ -136,8 +136,9 @@ class ADDAgent:
         # ---- model + optimiser state (mp_optimizer.py:25-40)
         self._model = Model(cfg["model"], tk.obs_dim, OS, tk.disc_dim, DS, dev, seed=self._seed)
         opt = cfg["optimizer"]
-        if opt["type"] != "Adam":
-            raise NotImplementedError("optimizer.type must be 'Adam' (-> AdamW like the reference's MPOptimizer)")
+        self._opt_type = str(opt["type"])  # mp_optimizer.py:32-40: "Adam" -> torch.optim.AdamW, "SGD" -> torch.optim.SGD(momentum=0.9)
+        if self._opt_type not in ("Adam", "SGD"):
+            raise ValueError("Unsupported optimizer type: " + self._opt_type)
         self._lr = float(opt["learning_rate"])
         self._wd = float(opt.get("weight_decay", 0.0))
         self._grad_clip = float(opt.get("grad_clip", 0.0))  # mp_optimizer.py:10, 42-46 (0 = off: the reference's default)
@@ -170,8 +171,8 @@ class ADDAgent:
         self._ppo_clip_ratio = float(c["ppo_clip_ratio"])
         self._norm_adv_clip = float(c["norm_adv_clip"])
         self._action_bound_weight = float(c["action_bound_weight"])
-        if float(c["action_entropy_weight"]) != 0 or float(c["action_reg_weight"]) != 0:
-            raise NotImplementedError("action_entropy_weight / action_reg_weight != 0 are not implemented (add_g1.yaml sets both to 0)")
+        self._action_entropy_weight = float(c["action_entropy_weight"])  # ppo_agent.py:262-272
+        self._action_reg_weight = float(c["action_reg_weight"])
         self._critic_loss_weight = float(c["critic_loss_weight"])
         self._exp_anneal_samples = float(c.get("exp_anneal_samples", float("inf")))  # ppo_agent.py:32-34
         self._exp_prob_beg = float(c.get("exp_prob_beg", 1.0))
@@ -250,7 +251,7 @@ class ADDAgent:
         self._gemm(p, Mb, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
         p.add("addhip_count_mask", L.ptr(W["mb_mask"]), Mb, L.ptr(W["nv"]))
         p.add("addhip_actor_loss", L.ptr(W["mean"]), L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_mask"]), Mb, m.std32,
-              m.logp_const, self._ppo_clip_ratio, self._action_bound_weight, gs, L.ptr(W["nv"]), L.ptr(W["d_mean"]), L.ptr(W["stats"]))
+              m.logp_const, self._ppo_clip_ratio, self._action_bound_weight, self._action_reg_weight, gs, L.ptr(W["nv"]), L.ptr(W["d_mean"]), L.ptr(W["stats"]))
         sA = 32
         self._gemm(p, 32, hA, Mb, L.ptr(W["d_mean"]), 32, 0, L.ptr(ra.h[-1]), hA, 0, L.ptr(self._slabs), hA, split_k=sA)
         p.add("addhip_slab_reduce", L.ptr(self._slabs), sA, 32 * hA, m.g("actor", "Wh"), 32 * hA, 1.0, 0)
@@ -527,8 +528,11 @@ class ADDAgent:
                 if self._grad_clip > 0.0:
                     L.call("addhip_grad_clip", L.ptr(m.grads), m.count, self._grad_clip, L.ptr(W["scratch"]), None, st)
                 m.opt_step += 1
-                L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, self._lr, 0.9, 0.999, 1e-8,
-                       self._wd, m.opt_step, st)
+                if self._opt_type == "SGD":
+                    L.call("addhip_sgd", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), m.count, self._lr, 0.9, self._wd, m.opt_step, st)
+                else:
+                    L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, self._lr, 0.9, 0.999, 1e-8,
+                           self._wd, m.opt_step, st)
                 steps += 1
         return steps
 
@@ -617,6 +621,14 @@ class ADDAgent:
         Mb, M1 = float(self.Mb), float(self.Mb)
         actor_min, clipf, ratio, bound = -s[0], s[1], s[2], s[3]  # already per-minibatch means over the exploring samples
         actor_loss = actor_min + self._action_bound_weight * bound
+        extra = {}
+        if self._action_entropy_weight != 0:  # fixed-std policy: the entropy is a constant (distribution_gaussian_diag.py:96-99)
+            ent = self._model.entropy
+            actor_loss += -self._action_entropy_weight * ent
+            extra["action_entropy"] = ent
+        if self._action_reg_weight != 0:
+            actor_loss += self._action_reg_weight * s[5]
+            extra["action_reg_loss"] = s[5]
         critic_loss = s[8] / Mb
         bce_neg, bce_pos = s[12] / M1, s[13]
         gp = s[20] / Mb
@@ -633,6 +645,7 @@ class ADDAgent:
             "disc_reward_mean": dr_mean, "disc_reward_std": dr_std,
             "mean_return": float(trk[1]), "mean_ep_len": float(trk[2]), "num_eps": int(trk[0]),
         }
+        info.update(extra)
         return info
 
     def _build_logger(self, log_file):
@@ -812,6 +825,11 @@ class ADDAgent:
         m = self._model
         ea, es = m.export(m.exp_avg), m.export(m.exp_avg_sq)
         keys = [k for k in ea if k != "_model._action_dist._logstd_net"]
+        if self._opt_type == "SGD":  # torch.optim.SGD.state_dict(): one momentum buffer per parameter
+            state = {i: {"momentum_buffer": ea[k]} for i, k in enumerate(keys)} if m.opt_step > 0 else {}
+            group = dict(lr=self._lr, momentum=0.9, dampening=0, weight_decay=self._wd, nesterov=False, maximize=False, foreach=None,
+                         differentiable=False, fused=None, params=list(range(len(keys))))
+            return {"state": state, "param_groups": [group]}
         state = {i: {"step": torch.tensor(float(m.opt_step)), "exp_avg": ea[k], "exp_avg_sq": es[k]} for i, k in enumerate(keys)} if m.opt_step > 0 else {}
         group = dict(lr=self._lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=self._wd, amsgrad=False, maximize=False, foreach=None, capturable=False,
                      differentiable=False, fused=None, decoupled_weight_decay=True, params=list(range(len(keys))))
@@ -839,7 +857,11 @@ class ADDAgent:
         self._obs_norm_first = True  # mean_sq is rebuilt lazily like normalizer.py:38-39
         Nm["d_cnt"].copy_(sd["_disc_obs_norm._count"])
         Nm["d_abs"][:tk.disc_dim] = sd["_disc_obs_norm._mean_abs"].to(self._device)
-        if opt is not None and opt.get("state"):
+        if opt is not None and opt.get("state") and "momentum_buffer" in opt["state"][0]:
+            keys = [k for k in m.export() if k != "_model._action_dist._logstd_net"]
+            m.load({k: opt["state"][i]["momentum_buffer"] for i, k in enumerate(keys)}, m.exp_avg)
+            m.opt_step = max(m.opt_step, 1)  # (torch's SGD keeps no step count: any value > 0 means "buffers are live")
+        elif opt is not None and opt.get("state"):
             keys = [k for k in m.export() if k != "_model._action_dist._logstd_net"]
             ea = {k: opt["state"][i]["exp_avg"] for i, k in enumerate(keys)}
             es = {k: opt["state"][i]["exp_avg_sq"] for i, k in enumerate(keys)}

@@ -85,6 +85,7 @@ class Model:
         logstd = torch.full((L.NUM_DOF,), float(math.log(self.action_std)), dtype=torch.float32)
         self.std32 = float(torch.exp(logstd)[0].item())
         self.logp_const = float((-0.5 * L.NUM_DOF * math.log(2.0 * math.pi) - torch.sum(logstd)).item())
+        self.entropy = float((torch.sum(logstd) + 0.5 * L.NUM_DOF * math.log(2.0 * math.pi * math.e)).item())  # :96-99
 
     # ---- views
     def view(self, net, key, buf=None):

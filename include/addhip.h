@@ -305,11 +305,14 @@ typedef struct {
 int addhip_gather_minibatch(const addhip_gather_t* g, void* stream);
 
 /* ---- losses (forward value + gradient w.r.t. the head outputs) ---- */
-/* PPOAgent._compute_actor_loss (ppo_agent.py:221-275) + _compute_action_bound_loss (base_agent.py:522-546).
- * d_mean[M,32] = d loss / d mean;  stats += {sum min-term, sum clip, sum ratio, sum bound, n_valid} */
+/* PPOAgent._compute_actor_loss (ppo_agent.py:221-275) + _compute_action_bound_loss (base_agent.py:522-546) + the mean
+ * regulariser reg_weight * mean(sum mean^2) (action_reg_weight, ppo_agent.py:268-272, distribution_gaussian_diag.py:113-116; the
+ * entropy term of :262-266 is a constant for the fixed-std policy and has no gradient).
+ * d_mean[M,32] = d loss / d mean;  stats[0..3] += means over the exploring samples of {min-term, clipped?, ratio, bound},
+ * stats[5] += mean of sum mean^2 (only when reg_weight != 0) */
 int addhip_actor_loss(const float* mean, const float* norm_action, const float* old_logp, const float* adv,
                       const float* rand_mask, int32_t M, float std, float logp_const, float clip_ratio,
-                      float bound_weight, float loss_scale, const float* n_valid /*device [1]*/, float* d_mean,
+                      float bound_weight, float reg_weight, float loss_scale, const float* n_valid /*device [1]*/, float* d_mean,
                       float* stats, void* stream);
 /* count of rand_mask == 1 -> out[0] */
 int addhip_count_mask(const float* rand_mask, int32_t M, float* out, void* stream);
@@ -352,6 +355,11 @@ int addhip_grad_clip(float* grad, int64_t count, float max_norm, float* scratch,
 /* torch.optim.AdamW step on a flat buffer (mp_optimizer.py:14-40; lr, betas (0.9,0.999), eps 1e-8) */
 int addhip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+/* torch.optim.SGD(momentum=0.9) step on a flat buffer (optimizer.type "SGD", mp_optimizer.py:33-36): g += wd*p; buf = (step==1) ? g : momentum*buf + g;
+ * p -= lr*buf */
+int addhip_sgd(float* param, const float* grad, float* momentum_buf, int64_t count, float lr, float momentum, float weight_decay,
+               int32_t step, void* stream);
 
 /* ReturnTracker running means over the T steps of an iteration (base_agent.py:596-621):
  * ep_stats [T,3] -> state {episodes, mean_return, mean_ep_len} updated step by step */

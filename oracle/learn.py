@@ -226,6 +226,8 @@ class LossCfg:
     def __init__(self, **kw):
         self.ppo_clip_ratio = 0.2
         self.action_bound_weight = 10.0
+        self.action_entropy_weight = 0.0
+        self.action_reg_weight = 0.0
         self.critic_loss_weight = 1.0
         self.disc_loss_weight = 0.5
         self.disc_logit_reg = 0.01
@@ -261,6 +263,14 @@ def compute_loss(model, cfg, batch):
     bound = torch.mean(torch.sum(torch.square(vmin), dim=-1) + torch.sum(torch.square(vmax), dim=-1))
     actor_loss = actor_loss + cfg.action_bound_weight * bound
     info["action_bound_loss"] = bound.item()
+    if cfg.action_entropy_weight != 0:  # ppo_agent.py:262-266, distribution_gaussian_diag.py:96-99
+        ent = torch.sum(torch.broadcast_to(model.logstd, mean.shape), dim=-1) + 0.5 * mean.shape[-1] * np.log(2.0 * np.pi * np.e)
+        actor_loss = actor_loss - cfg.action_entropy_weight * torch.mean(ent)
+        info["action_entropy"] = torch.mean(ent).item()
+    if cfg.action_reg_weight != 0:      # ppo_agent.py:268-272, distribution_gaussian_diag.py:113-116
+        reg = torch.mean(torch.sum(torch.square(mean), dim=-1))
+        actor_loss = actor_loss + cfg.action_reg_weight * reg
+        info["action_reg_loss"] = reg.item()
     # discriminator (add_agent.py:141-202)
     nd = t32(batch["norm_diff"]).requires_grad_(True)
     pos_logit = model.disc(torch.zeros(1, nd.shape[1], dtype=nd.dtype))

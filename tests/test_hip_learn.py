@@ -254,14 +254,15 @@ def test_actor_loss_head_gradient():
     loss = -torch.mean(torch.minimum(a * ratio, a * torch.clamp(ratio, 0.8, 1.2)))
     vmin, vmax = torch.clamp_max(mt[sel] + 1, 0), torch.clamp_min(mt[sel] - 1, 0)
     bound = torch.mean(torch.sum(vmin ** 2, -1) + torch.sum(vmax ** 2, -1))
-    (loss + 10.0 * bound).backward()
+    reg = torch.mean(torch.sum(mt[sel] ** 2, -1))  # action_reg_weight term (ppo_agent.py:268-272)
+    (loss + 10.0 * bound + 0.3 * reg).backward()
     pad = lambda x: np.concatenate([x, np.zeros((M, 3), F)], -1)
     nv = torch.zeros(1, device="cuda")
     dm = torch.zeros(M, 32, device="cuda")
     stats = torch.zeros(8, device="cuda")
     dmask = T(mask)
     L.call("addhip_count_mask", L.ptr(dmask), M, L.ptr(nv), L.current_stream())
-    L.call("addhip_actor_loss", P(T(pad(mean))), P(T(pad(na))), P(T(old)), P(T(adv)), L.ptr(dmask), M, std, c, 0.2, 10.0, 1.0, L.ptr(nv),
+    L.call("addhip_actor_loss", P(T(pad(mean))), P(T(pad(na))), P(T(old)), P(T(adv)), L.ptr(dmask), M, std, c, 0.2, 10.0, 0.3, 1.0, L.ptr(nv),
            L.ptr(dm), L.ptr(stats), L.current_stream())
     torch.cuda.synchronize()
     assert float(nv.item()) == mask.sum()
@@ -271,6 +272,7 @@ def test_actor_loss_head_gradient():
     nvf = mask.sum()  # the statistics are means over the exploring samples already
     np.testing.assert_allclose(-s[0], loss.item(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(s[3], bound.item(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(s[5], reg.item(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(s[2], ratio.mean().item(), rtol=1e-4)
     np.testing.assert_allclose(s[1], (torch.abs(ratio - 1) > 0.2).float().mean().item(), atol=2.0 / nvf)
 
@@ -367,6 +369,27 @@ def test_adamw_matches_torch():
         L.call("addhip_adamw", L.ptr(dp), P(T(g)), L.ptr(m), L.ptr(v), n, 1e-4, 0.9, 0.999, 1e-8, 0.0, step, L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(dp.cpu().numpy(), p.detach().numpy(), rtol=1e-6, atol=1e-8)
+
+
+def test_sgd_momentum_matches_torch():
+    """optimizer.type "SGD" (mp_optimizer.py:33-36): torch.optim.SGD(lr, momentum=0.9, weight_decay) over three steps."""
+    import torch
+    import add_gym_amd._lib as L
+
+    rng = np.random.RandomState(2)
+    n = 100003
+    p0 = rng.standard_normal(n).astype(F)
+    pt = torch.nn.Parameter(torch.tensor(p0))
+    opt = torch.optim.SGD([pt], 1e-2, momentum=0.9, weight_decay=1e-3)
+    dp, buf = T(p0), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        g = rng.standard_normal(n).astype(F)
+        pt.grad = torch.tensor(g)
+        opt.step()
+        L.call("addhip_sgd", L.ptr(dp), P(T(g)), L.ptr(buf), n, 1e-2, 0.9, 1e-3, step, L.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dp.cpu().numpy(), pt.detach().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(buf.cpu().numpy(), opt.state[pt]["momentum_buffer"].numpy(), rtol=1e-6, atol=1e-7)
 
 
 def test_philox_fills_and_return_tracker():
