@@ -71,7 +71,7 @@ class RigidModelT(C.Structure):
     _fields_ = [("num_bodies", C.c_int32), ("num_points", C.c_int32), ("body", f32p), ("topo", f32p), ("points", f32p), ("dt", C.c_float),
                 ("substeps", C.c_int32), ("gravity", C.c_float), ("contact_stiffness", C.c_float), ("contact_damping", C.c_float),
                 ("friction", C.c_float), ("friction_vel_eps", C.c_float), ("limit_stiffness", C.c_float), ("max_torque", C.c_float),
-                ("limit_margin", C.c_float), ("termination_mask", C.c_uint32)]
+                ("limit_margin", C.c_float), ("termination_mask", C.c_uint32), ("env_scale", f32p)]
 
 
 RIGID_BODY_W, RIGID_TOPO_W = 32, 8
@@ -94,6 +94,8 @@ SIGNATURES = {
     "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp],
     "addhip_fill_normal": [vp, i64, u64, u64, vp],
     "addhip_fill_uniform": [vp, i64, u64, u64, vp],
+    "addhip_fill_normal_at": [vp, i64, u64, u64, vp, vp],
+    "addhip_fill_uniform_at": [vp, i64, u64, u64, vp, vp],
     "addhip_fill_zero": [vp, i64, vp],
     "addhip_disc_prep": [vp, vp, i32, i32, i64, vp, f32, vp, vp, vp, P(SamplerT), i32, vp, vp],
     "addhip_sampler_update": [P(SamplerT), i32, vp],

@@ -52,7 +52,9 @@ __device__ __forceinline__ U4 philox(uint64_t ctr, uint64_t stream_id, uint64_t 
 }
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0,1)
 
-__global__ void fill_uniform_kernel(float* out, long long n, uint64_t seed, uint64_t sid) {
+// (sid_base: optional device counter added to the stream id -- lets a captured hipGraph draw fresh numbers on every replay)
+__global__ void fill_uniform_kernel(float* out, long long n, uint64_t seed, uint64_t sid, const uint64_t* sid_base) {
+  if (sid_base) sid += sid_base[0];
   long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
   for (; q * 4 < n; q += step) {
     U4 r = philox((uint64_t)q, sid, seed);
@@ -61,7 +63,8 @@ __global__ void fill_uniform_kernel(float* out, long long n, uint64_t seed, uint
       if (q * 4 + k < n) out[q * 4 + k] = v[k];
   }
 }
-__global__ void fill_normal_kernel(float* out, long long n, uint64_t seed, uint64_t sid) {
+__global__ void fill_normal_kernel(float* out, long long n, uint64_t seed, uint64_t sid, const uint64_t* sid_base) {
+  if (sid_base) sid += sid_base[0];
   long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
   for (; q * 4 < n; q += step) {
     U4 r = philox((uint64_t)q, sid, seed);
@@ -624,12 +627,24 @@ __global__ void return_tracker_fold_kernel(const float* ep, int T, float* state)
 
 extern "C" int addhip_fill_normal(float* out, int64_t count, uint64_t seed, uint64_t stream_id, void* stream) {
   ADDHIP_REQUIRE(out && count > 0, "fill_normal: bad arguments");
-  hipLaunchKernelGGL(fill_normal_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id);
+  hipLaunchKernelGGL(fill_normal_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id,
+                     (const uint64_t*)nullptr);
+  return addhip::check_launch("fill_normal_kernel");
+}
+extern "C" int addhip_fill_normal_at(float* out, int64_t count, uint64_t seed, uint64_t stream_id, const uint64_t* stream_base, void* stream) {
+  ADDHIP_REQUIRE(out && count > 0 && stream_base, "fill_normal_at: bad arguments");
+  hipLaunchKernelGGL(fill_normal_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id, stream_base);
   return addhip::check_launch("fill_normal_kernel");
 }
 extern "C" int addhip_fill_uniform(float* out, int64_t count, uint64_t seed, uint64_t stream_id, void* stream) {
   ADDHIP_REQUIRE(out && count > 0, "fill_uniform: bad arguments");
-  hipLaunchKernelGGL(fill_uniform_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id);
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id,
+                     (const uint64_t*)nullptr);
+  return addhip::check_launch("fill_uniform_kernel");
+}
+extern "C" int addhip_fill_uniform_at(float* out, int64_t count, uint64_t seed, uint64_t stream_id, const uint64_t* stream_base, void* stream) {
+  ADDHIP_REQUIRE(out && count > 0 && stream_base, "fill_uniform_at: bad arguments");
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id, stream_base);
   return addhip::check_launch("fill_uniform_kernel");
 }
 

@@ -173,7 +173,10 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
 
   const int nb = M.num_bodies;
   const float h = M.dt / (float)M.substeps;
-  const float kc = M.contact_stiffness, cn = M.contact_damping, mu = M.friction, veps = M.friction_vel_eps;
+  const float kc = M.contact_stiffness, cn = M.contact_damping, veps = M.friction_vel_eps;
+  // domain randomisation: per-env PD gain multiplier and ground friction (both 1 x / the model's value without it)
+  const float gscale = (M.env_scale && on) ? M.env_scale[2 * env] : 1.f;
+  const float mu = (M.env_scale && on) ? M.env_scale[2 * env + 1] : M.friction;
   // private per-body arrays (scratch): spatial velocity, then (pass 3) spatial acceleration; world up-vector in body coords; height
   float bv[MAXB][6], bnz[MAXB][3], bh[MAXB];
   unsigned touch = 0;
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
       if (k == 0) { carryI = I; carryP = p; break; }
       // joint: PD torque with the implicit diagonal (stable PD unless the torque clamp is active), limit spring
       const float q = LD(F_POSE, 7 + dof), qd = LD(F_VEL, 6 + dof);
-      const float lo = bc[22], hi = bc[23], damp = bc[24], arm = bc[25], flim = fminf(bc[26], M.max_torque), kp = bc[27], kv = bc[28];
+      const float lo = bc[22], hi = bc[23], damp = bc[24], arm = bc[25], flim = fminf(bc[26], M.max_torque), kp = gscale * bc[27], kv = gscale * bc[28];
       const float tgt = fminf(fmaxf(LD(F_TGT, dof), lo + M.limit_margin), hi - M.limit_margin);
       const float tpd = kp * (tgt - q) - kv * qd;
       float tau, dadd;

@@ -60,6 +60,17 @@ class RigidEntity(BaseEntity):
         self.contact_bits = torch.zeros(n, dtype=torch.int32, device=device)  # one bit per link
         self._own_target = torch.zeros(n, 32, device=device)
         self._target = self._own_target
+        # domain randomisation (build-defined extension, off by default; the reference has none): per-env PD gain scale and
+        # ground friction, redrawn every `resample_interval` control steps, plus random horizontal pushes of the root
+        dr = self._opts.get("domain_randomization") or {}
+        self._dr = dict(dr) if dr.get("enabled", False) else None
+        self.env_scale = None
+        self._steps = 0
+        if self._dr is not None:
+            self.env_scale = torch.ones(n, 2, device=device)
+            self._dr_u = torch.zeros(n, 2, device=device)
+            self._dr_seed = int(self._dr.get("seed", 0))
+            self._resample_scales()
         self._upload()
 
     def _upload(self):
@@ -70,7 +81,8 @@ class RigidEntity(BaseEntity):
         self.c_struct = L.RigidModelT(t.num_bodies, t.num_points, L.ptr(self._d_body), L.ptr(self._d_topo), L.ptr(self._d_points),
                                       float(o["dt"]), int(o["substeps"]), float(o["gravity"]), float(o["contact_stiffness"]),
                                       float(o["contact_damping"]), float(o["friction"]), float(o["friction_vel_eps"]),
-                                      float(o["limit_stiffness"]), float(o["max_torque"]), float(o["position_limit_margin"]), int(self._term_mask))
+                                      float(o["limit_stiffness"]), float(o["max_torque"]), float(o["position_limit_margin"]), int(self._term_mask),
+                                      L.ptr(self.env_scale))
         self._dirty = False
 
     def set_termination_links(self, allowed_link_names):
@@ -202,9 +214,32 @@ class RigidEntity(BaseEntity):
     links = property(lambda s: s._links)
     n_dofs = property(lambda s: s._n_dofs)
 
+    def _resample_scales(self):
+        """env_scale[:, 0] ~ U(gain_scale range), env_scale[:, 1] ~ U(friction range); Philox draws keyed by the control-step count."""
+        d = self._dr
+        L.call("addhip_fill_uniform", L.ptr(self._dr_u), 2 * self.n, self._dr_seed, (8 << 40) + self._steps, L.current_stream())
+        g0, g1 = d.get("gain_scale", [1.0, 1.0])
+        f0, f1 = d.get("friction", [self._opts["friction"]] * 2)
+        lo = torch.tensor([float(g0), float(f0)], device=self._device)
+        hi = torch.tensor([float(g1), float(f1)], device=self._device)
+        torch.addcmul(lo, self._dr_u, hi - lo, out=self.env_scale)
+
+    def _randomize(self):
+        d = self._dr
+        every = int(d.get("resample_interval", 0))
+        if every > 0 and self._steps > 0 and self._steps % every == 0:
+            self._resample_scales()
+        push = int(d.get("push_interval", 0))
+        if push > 0 and self._steps > 0 and self._steps % push == 0:  # horizontal velocity kick of the root, |dv| <= push_velocity per axis
+            L.call("addhip_fill_uniform", L.ptr(self._dr_u), 2 * self.n, self._dr_seed, (9 << 40) + self._steps, L.current_stream())
+            self.vel[:, 0:2] += (2.0 * self._dr_u - 1.0) * float(d.get("push_velocity", 0.5))
+
     def step(self):
         if self._dirty:
             self._upload()
+        if self._dr is not None:
+            self._randomize()
+        self._steps += 1
         L.call("addhip_rigid_step", self.c_struct, L.ptr(self.pose), L.ptr(self.vel), L.ptr(self._target), int(self._target.shape[-1]), self.n,
                L.ptr(self.contact), L.ptr(self.contact_bits), L.current_stream())
 
@@ -243,7 +278,7 @@ class RigidScene(BaseScene):
 
 class RigidBodyEngine(BaseEngine):
     DEFAULTS = dict(substeps=4, gravity=9.81, contact_stiffness=2.0e4, contact_damping=3.0e2, friction=1.0, friction_vel_eps=0.01,
-                    limit_stiffness=2.0e3, max_torque=200.0, position_limit_margin=1e-4)
+                    limit_stiffness=2.0e3, max_torque=200.0, position_limit_margin=1e-4, domain_randomization=None)
 
     def __init__(self, **cfg):
         self.cfg = cfg

@@ -154,6 +154,13 @@ class ADDAgent:
         self._train_state = z(3)
         self._timers = {}
         self._test_calls = 0
+        # agent.rollout_graph: capture the T steps of a training rollout (actor MLP, noise, engine step, fused env step, masked
+        # reset: ~13 launches per step) into one hipGraph per ring phase and replay it every iteration.  The Philox stream ids
+        # come from a device counter advanced once per iteration, so every replay draws fresh numbers -- the same numbers the
+        # call-by-call path draws (the two are bit-identical; tests/test_hip_agent.py).
+        self._rollout_graph = bool(cfg.get("rollout_graph", False))
+        self._graphs, self._graph_warm = {}, False
+        self._sid_base = torch.zeros(1, dtype=torch.int64, device=dev)
         # optional externally supplied random draws (parity tests replay the reference's draws through these):
         #   {"noise": [T][N,29], "uniforms": {Philox stream id (stream_* below): [3,N]}, "perms": iterator of int64 permutations, "pre_step": fn(t)}
         self.inject = None
@@ -364,11 +371,15 @@ class ADDAgent:
     def stream_test_reset(test_call, k):
         return (6 << 40) + (int(test_call) << 20) + int(k)
 
-    def _draw_uniforms(self, stream_id):
+    def _draw_uniforms(self, stream_id, relative=False):
+        """relative: stream_id is an offset from the device counter _sid_base (hipGraph-captured rollouts)."""
         if self.inject is not None and "uniforms" in self.inject:
             self._W["u"].copy_(self.inject["uniforms"][stream_id])
             return
-        L.call("addhip_fill_uniform", L.ptr(self._W["u"]), 3 * self.N, self._seed, stream_id, self._stream())
+        if relative:
+            L.call("addhip_fill_uniform_at", L.ptr(self._W["u"]), 3 * self.N, self._seed, stream_id, L.ptr(self._sid_base), self._stream())
+        else:
+            L.call("addhip_fill_uniform", L.ptr(self._W["u"]), 3 * self.N, self._seed, stream_id, self._stream())
 
     def _sync_foreign_engine_in(self):
         """Slow path for engines without hot_state(): gather the BaseEntity getters into the packed rows."""
@@ -385,26 +396,28 @@ class ADDAgent:
             ent.set_qpos(self._S["sim_pose"][ids], envs_idx=ids)            # add_observation.py:314-322
             ent.set_dofs_velocity(self._S["sim_vel"][ids, :35], envs_idx=ids)  # :323-331
 
-    def _reset_envs(self, reset_all, obs_slot, disc_slot, demo_slot, stream_id):
+    def _reset_envs(self, reset_all, obs_slot, disc_slot, demo_slot, stream_id, relative=False):
         """ADDAgent._reset_envs (add_agent.py:221-233), masked on device (no host nonzero)."""
         S = self._S
         mask = None
         if not self._fast_engine:
             mask = torch.ones(self.N, dtype=torch.bool, device=self._device) if reset_all else (S["done"] != 0)
-        self._draw_uniforms(stream_id)
+        self._draw_uniforms(stream_id, relative)
         u = self._W["u"]
         L.call("addhip_env_reset", self._motion_lib.c_struct, self._task, self._env_c, self._smp_c, L.ptr(u[0]), L.ptr(u[1]), L.ptr(u[2]),
                L.ptr(obs_slot), L.ptr(disc_slot), L.ptr(demo_slot), int(reset_all), self._head, self._stream())
         if not self._fast_engine:
             self._sync_foreign_engine_out(mask)
 
-    def _decide_action(self, t, slot_t, deterministic):
+    def _decide_action(self, t, slot_t, deterministic, relative=False):
         """PPOAgent._decide_action (ppo_agent.py:72-104) + record (ppo_agent.py:106-109)."""
         B, W, Nm, m = self._B, self._W, self._Nrm, self._model
         st = self._stream()
         self._act_plans[slot_t].run(st)
         if not deterministic and self.inject is not None and "noise" in self.inject:
             W["noise"].copy_(self.inject["noise"][t])
+        elif not deterministic and relative:
+            L.call("addhip_fill_normal_at", L.ptr(W["noise"]), self.N * L.NUM_DOF, self._seed, (1 << 40) + t, L.ptr(self._sid_base), st)
         elif not deterministic:
             L.call("addhip_fill_normal", L.ptr(W["noise"]), self.N * L.NUM_DOF, self._seed, (1 << 40) + self._iter * self.T + t, st)
         explore_u, exp_prob = None, 1.0
@@ -439,6 +452,10 @@ class ADDAgent:
     # ------------------------------------------------------------------ training loop
     def _rollout_train(self):
         B, T = self._B, self.T
+        if self._rollout_graph and self._graph_ok():
+            self._rollout_train_graph()
+            self._total_samples += T * self.N
+            return
         B["ep_stats"].zero_()
         for t in range(T):
             self._decide_action(t, t, False)
@@ -448,6 +465,43 @@ class ADDAgent:
             # obs slot t+1 already holds the post-step obs; reset envs overwrite theirs (base_agent.py:449-453)
             self._reset_envs(False, B["obs"][t + 1], B["disc_obs"][t + 1], B["disc_demo"][t + 1], self.stream_train_reset(self._iter * T + t))
         self._total_samples += T * self.N
+
+    def _graph_ok(self):
+        """A rollout can be replayed from a graph when nothing in it depends on host state that changes between iterations:
+        engine state shared in place, no injected draws, constant exploration probability, no host-driven randomisation."""
+        ent = self._env.robot.entity
+        return (self._fast_engine and self.inject is None and not math.isfinite(self._exp_anneal_samples) and self._exp_prob_beg >= 1.0
+                and getattr(ent, "_dr", None) is None)
+
+    def _rollout_body_relative(self):
+        """The T steps with stream ids relative to the device counter (what the graph captures; also run eagerly once)."""
+        B, T = self._B, self.T
+        B["ep_stats"].zero_()
+        for t in range(T):
+            self._decide_action(t, t, False, relative=True)
+            self._step_env(t, self._step_out[t], self._env_c)
+            self._reset_envs(False, B["obs"][t + 1], B["disc_obs"][t + 1], B["disc_demo"][t + 1], self.stream_train_reset(t), relative=True)
+
+    def _rollout_train_graph(self):
+        T = self.T
+        self._sid_base.fill_(self._iter * T)  # outside the graph: the only per-iteration input of the rollout
+        h0 = self._head
+        if not self._graph_warm:  # first use: run eagerly so that every kernel is loaded before a capture starts
+            ent = self._env.robot.entity
+            if getattr(ent, "_dirty", False):
+                ent._upload()
+            self._rollout_body_relative()
+            self._graph_warm = True
+            return
+        g = self._graphs.get(h0)
+        if g is None:  # one graph per ring phase (the ring slot of step t is (h0 + t) % 3, a launch argument)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._rollout_body_relative()
+            self._graphs[h0] = g
+        self._head = h0
+        g.replay()
+        self._head = (h0 + T) % L.HIST
 
     def _build_train_data(self):
         """add_agent.py:110-139 then ppo_agent.py:111-159."""

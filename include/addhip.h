@@ -185,6 +185,9 @@ typedef struct {
   float contact_stiffness, contact_damping, friction, friction_vel_eps;
   float limit_stiffness, max_torque, limit_margin;
   uint32_t termination_mask; /* bit b: a ground contact of link b raises contact_flag (robot.py:221-231 with add_done.py:36-45) */
+  /* domain randomisation (build-defined extension; the reference has none): per-env multipliers [N,2] = (PD gain scale applied to kp
+   * and kv, ground friction coefficient replacing `friction`), or NULL */
+  const float* env_scale;
 } addhip_rigid_model_t;
 /* One control step for every env, in place on the packed state rows (pose[N,36], vel[N,36]); target [N,target_stride] = joint
  * position targets (breadth-first dof order).  contact_flag [N] (or NULL): 1 if a link selected by termination_mask touched
@@ -248,6 +251,10 @@ int addhip_actor_sample(const float* mean, int32_t ld_mean, const float* noise /
 /* counter-based Philox4x32-10 fills (stateless: element i of call (seed,stream_id) is fixed) */
 int addhip_fill_normal(float* out, int64_t count, uint64_t seed, uint64_t stream_id, void* stream_);
 int addhip_fill_uniform(float* out, int64_t count, uint64_t seed, uint64_t stream_id, void* stream_);
+/* same, with the stream id = stream_id + stream_base[0] read ON THE DEVICE at execution time: a captured hipGraph (the whole rollout
+ * of an iteration) then draws fresh numbers on every replay once the caller has advanced the counter */
+int addhip_fill_normal_at(float* out, int64_t count, uint64_t seed, uint64_t stream_id, const uint64_t* stream_base, void* stream_);
+int addhip_fill_uniform_at(float* out, int64_t count, uint64_t seed, uint64_t stream_id, const uint64_t* stream_base, void* stream_);
 
 /* ---- build-train-data (add_agent.py:110-139, amp_agent.py:194-206, sampler.py:20-55) ---- */
 /* norm_diff = (demo-agent)/max(mean_abs,1e-4); err = sum((agent-demo)^2) scatter-added per (clip,segment);

@@ -287,7 +287,7 @@ def contact_terms(model, prm, nz, height, v, h):
         vn = np.einsum("ni,ni->n", nb_, vp)
         vt = vp - vn[:, None] * nb_
         fn0 = np.maximum(k * d - cn * vn, 0.0)
-        ct = mu * fn0 / np.maximum(np.linalg.norm(vt, axis=-1), veps)
+        ct = mu * fn0 / np.maximum(np.linalg.norm(vt, axis=-1), veps)   # mu: scalar, or [n] with per-env domain randomisation
         fn_eff = np.maximum(fn0 - h * k * vn, 0.0)
         f = fn_eff[:, None] * nb_ - ct[:, None] * vt
         nn = nb_[:, :, None] * nb_[:, None, :]

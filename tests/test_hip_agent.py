@@ -515,3 +515,38 @@ def test_episode_time_limit_rows_feed_the_critic():
             assert not torch.equal(B["obs_timeout"][t_env], B["obs"][ag.T][t_env])
         assert torch.isfinite(B["tar_val"]).all() and torch.isfinite(B["adv"]).all() and torch.isfinite(B["timeout_vals"]).all()
     assert hits >= 200  # nearly every env ran into the 0.2 s limit in 24 steps (a few reach the clip end first: DONE_SUCC)
+
+
+def test_rollout_graph_replays_the_same_rollout():
+    """agent.rollout_graph: the T rollout steps of an iteration captured into one hipGraph per ring phase (BASELINE configs[4]:
+    "hipGraph-captured rollout step").  Replays must draw the same Philox numbers as the call-by-call path and produce
+    bit-identical buffers, iteration after iteration (eager warm-up, capture, then pure replays, all three ring phases)."""
+    import torch
+    import add_gym_amd.learning.add_agent as A
+
+    bufs = []
+    for graph in (False, True):
+        cfg = make_cfg(512, steps_per_iter=8, rollout_graph=graph)
+        cfg["task"]["motion_file"] = "synthetic:2x60"
+        cfg["seed"] = 4
+        ag = A.ADDAgent(cfg)
+        ag.reset_all_envs()
+        ag._init_train()
+        out = []
+        for it in range(7):
+            if it:
+                ag._B["obs"][0].copy_(ag._B["obs"][ag.T])
+            ag._rollout_train()
+            ag._iter += 1
+            torch.cuda.synchronize()
+            out.append({k: ag._B[k].clone() for k in ("obs", "action", "a_logp", "done", "reward", "motion_time", "disc_obs", "ep_stats")})
+        bufs.append(out)
+        if graph:
+            assert len(ag._graphs) == 3 and ag._total_samples == 7 * 8 * 512  # T = 8: the ring phase advances by 2 per iteration
+    for it, (a, b) in enumerate(zip(*bufs)):
+        for k in a:
+            if k == "ep_stats":  # sums of finished returns / lengths accumulated by float atomics: order varies run to run
+                torch.testing.assert_close(a[k], b[k], rtol=1e-5, atol=1e-5)
+            else:
+                assert torch.equal(a[k], b[k]), (it, k)
+    assert int((bufs[0][-1]["done"] != 0).sum()) > 0
