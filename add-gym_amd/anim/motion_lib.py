@@ -40,11 +40,12 @@ class MotionLib:
         self._dt_inv = round(1 / dt)  # motion_lib.py:23
         self.reference_compat = bool(reference_compat)
         self.from_cache = False
-        if frames_list is None and str(motion_file).startswith("synthetic:"):
-            from .synth import parse_synthetic, synth_clip
+        if frames_list is None and str(motion_file).startswith(("synthetic:", "synthetic_stand:")):
+            from .synth import parse_synthetic, synth_clip, synth_stand_clip
 
             clips, nframes = parse_synthetic(motion_file)
-            frames_list = [synth_clip(kin_char_model, list(motion_order), c, nframes) for c in range(clips)]
+            gen = synth_stand_clip if str(motion_file).startswith("synthetic_stand:") else synth_clip
+            frames_list = [gen(kin_char_model, list(motion_order), c, nframes) for c in range(clips)]
             weights = [1.0] * clips
         cache_file = None
         if frames_list is None:

@@ -7,8 +7,11 @@ from add_gym_amd.config import load_config
 from add_gym_amd.learning.add_agent import ADDAgent
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+engine = sys.argv[3] if len(sys.argv) > 3 else "kinematic"
+motion = sys.argv[4] if len(sys.argv) > 4 else "synthetic:3x900"
 N, T = 4096, 32
-cfg = load_config("train", [f"engine.num_envs={N}", f"agent.matmul_precision={prec}", "task.motion_file=synthetic:3x900", "agent.iters_per_output=10",
+print(f"engine {engine}, motion {motion}")
+cfg = load_config("train", [f"engine={engine}", f"engine.num_envs={N}", f"agent.matmul_precision={prec}", f"task.motion_file={motion}", "agent.iters_per_output=10",
                             "agent.test_episodes=0", f"agent.max_samples={iters * N * T}"])
 d = tempfile.mkdtemp()
 ag = ADDAgent(cfg)
