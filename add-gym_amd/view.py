@@ -22,7 +22,7 @@ def export_playback(cfg, out_file, steps, source="policy"):
     agent.set_mode(AgentMode.TEST)
     agent.reset_all_envs()
     lib, S, N = agent._motion_lib, agent._S, agent.N
-    rec = {k: [] for k in ("sim_pose", "ref_pose", "reward", "done", "motion_id", "motion_time")}
+    rec = {k: [] for k in ("sim_pose", "sim_vel", "ref_pose", "ref_vel", "reward", "done", "motion_id", "motion_time", "time")}
     reward = torch.zeros(N, device=agent._device)
     out = L.StepOutT(L.ptr(agent._B["obs"][0]), None, None, L.ptr(agent._B["disc_obs"][agent.T]), L.ptr(agent._B["disc_demo"][agent.T]), L.ptr(reward),
                      None, None, None, None)
@@ -38,11 +38,11 @@ def export_playback(cfg, out_file, steps, source="policy"):
             agent._decide_action(0, 0, True)
             agent._step_env(0, out, agent._env_c_test)
         t = S["time"] + S["time_off"]
-        ref_pose, _ = lib.get_precomputed_motion_step(S["motion_id"], t, packed=True)
-        for key, val in (("sim_pose", S["sim_pose"]), ("ref_pose", ref_pose), ("reward", reward), ("done", S["done"]), ("motion_id", S["motion_id"]),
-                         ("motion_time", t)):
+        ref_pose, ref_vel = lib.get_precomputed_motion_step(S["motion_id"], t, packed=True)
+        for key, val in (("sim_pose", S["sim_pose"]), ("sim_vel", S["sim_vel"]), ("ref_pose", ref_pose), ("ref_vel", ref_vel), ("reward", reward),
+                         ("done", S["done"]), ("motion_id", S["motion_id"]), ("motion_time", t), ("time", S["time"])):
             rec[key].append(val.detach().cpu().numpy().copy())
-        agent._reset_envs(False, agent._B["obs"][0], agent._B["disc_obs"][agent.T], agent._B["disc_demo"][agent.T], (11 << 20) + k)
+        agent._reset_envs(False, agent._B["obs"][0], agent._B["disc_obs"][agent.T], agent._B["disc_demo"][agent.T], (7 << 40) + k)  # Philox namespace 7: playback resets
     kin = agent._env.robot._kin_char_model
     arrays = {k: np.stack(v) for k, v in rec.items()}
     np.savez_compressed(out_file, dt=np.float32(agent._env.ctrl_dt), layout="pose = root xyz | root quaternion wxyz | 29 joint angles (kinematic-tree order)",

@@ -481,7 +481,24 @@ def test_kinematic_playback_export(tmp_path):
     live = arrays["done"] == 0  # (envs that ran past the clip end are reset after the step)
     assert live.mean() > 0.5 and np.abs(arrays["sim_pose"] - arrays["ref_pose"])[live].max() < 1e-3  # fp32 clock vs recomputed time
     assert arrays["reward"][live].min() > 0.84  # all four reward terms at their maximum (0.5 + 0.1 + 0.15 + 0.1)
-    export_playback(cfg, str(out), 5, source="policy")  # deterministic policy path runs too
+    # policy playback: every exported reward and done flag recomputed by the CPU oracle from the exported simulator / reference
+    # states (add_reward.py:103-177, add_done.py:96-147)
+    from oracle import task as OT
+
+    cfg2 = make_cfg(16, steps_per_iter=8)
+    cfg2["task"]["motion_file"] = "synthetic:1x60"  # 2 s clip: some envs run past its end (SUCC), the random policy fails poses (FAIL)
+    arr = export_playback(cfg2, str(out), 60, source="policy")
+    tcfg = OT.TaskCfg()
+    unpack = lambda p, v: (p[:, 0:3], p[:, 3:7], v[:, 0:3], v[:, 3:6], p[:, 7:36], v[:, 6:35])
+    clip_len = np.float32((60 - 1) / 30.0)
+    n_done = 0
+    for k in range(60):
+        sim, ref = unpack(arr["sim_pose"][k], arr["sim_vel"][k]), unpack(arr["ref_pose"][k], arr["ref_vel"][k])
+        np.testing.assert_allclose(arr["reward"][k], OT.reward(tcfg, sim, ref), rtol=0, atol=5e-6, err_msg=f"step {k}")
+        want = OT.done_flags(tcfg, arr["time"][k], arr["motion_time"][k], np.full(16, clip_len, np.float32), np.zeros(16, np.int32), sim[0], sim[4], ref[0], ref[4], None)
+        assert np.array_equal(arr["done"][k], want), k
+        n_done += int((want != 0).sum())
+    assert n_done > 0
 
 
 def test_episode_time_limit_rows_feed_the_critic():
