@@ -56,7 +56,8 @@ class GemmT(C.Structure):
                 ("B", f32p), ("ldb", C.c_int32), ("b_kcontig", C.c_int32), ("C", f32p), ("ldc", C.c_int32), ("epilogue", C.c_int32),
                 ("bias", f32p), ("mask", f32p), ("ldmask", C.c_int32), ("a_mean", f32p), ("a_std", f32p), ("split_k", C.c_int32),
                 ("alpha", C.c_float), ("colsum", f32p), ("precision", C.c_int32),
-                ("relu_bits", f32p), ("mask_bits", f32p), ("ldbits", C.c_int32), ("accumulate", C.c_int32)]
+                ("relu_bits", f32p), ("mask_bits", f32p), ("ldbits", C.c_int32), ("accumulate", C.c_int32),
+                ("operands_bf16", C.c_int32), ("C16", f32p), ("ldc16", C.c_int32)]
 
 
 class GatherT(C.Structure):
@@ -89,6 +90,7 @@ SIGNATURES = {
     "addhip_kin_engine_step": [vp, vp, vp, i32, i32, f32, f32, vp],
     "addhip_rigid_step": [P(RigidModelT), vp, vp, vp, i32, i32, vp, vp, vp],
     "addhip_gemm_f32": [P(GemmT), vp],
+    "addhip_to_bf16": [vp, vp, i64, i32, i32, i32, vp],
     "addhip_slab_reduce": [vp, i32, i64, vp, i64, f32, i32, vp],
     "addhip_col_sum": [vp, i32, i32, i32, vp, f32, i32, vp],
     "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp],

@@ -384,13 +384,15 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* X, int M, int
 
 namespace addhip {
 int gemm_split_dispatch(const addhip_gemm_t& g, int planes, hipStream_t st);  // gemm_split.hip
+int gemm_bf16_dispatch(const addhip_gemm_t& g, hipStream_t st);               // gemm_bf16.hip
 }
 
 extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   ADDHIP_REQUIRE(gp, "null gemm descriptor");
   addhip_gemm_t g = *gp;
   ADDHIP_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem %d x %d x %d", g.M, g.N, g.K);
-  ADDHIP_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
+  ADDHIP_REQUIRE(g.A && g.B && (g.C || (g.operands_bf16 && g.C16)), "gemm: null operand");
+  ADDHIP_REQUIRE(g.operands_bf16 || !g.C16, "gemm: a bf16 result copy (C16) is written by the bf16-storage path only");
   ADDHIP_REQUIRE(aligned16(g.A) && aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0), "gemm: operands must be 16-byte aligned with ld %% 4 == 0");
   if (g.a_kcontig) ADDHIP_REQUIRE(g.K % 4 == 0, "gemm: K must be a multiple of 4 for a k-contiguous A");
   else ADDHIP_REQUIRE(g.M % 4 == 0, "gemm: M must be a multiple of 4 for an m-contiguous A");
@@ -399,8 +401,8 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   ADDHIP_REQUIRE(g.epilogue >= ADDHIP_EPI_NONE && g.epilogue <= ADDHIP_EPI_MASK, "gemm: bad epilogue");
   if (g.epilogue == ADDHIP_EPI_BIAS || g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_REQUIRE(g.bias, "gemm: bias missing");
   if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_REQUIRE(g.mask || g.mask_bits, "gemm: mask missing");
-  if (g.mask_bits) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && g.M > SMALL_M && g.ldbits * 32 >= g.N, "gemm: mask_bits need the MASK epilogue, M > 8 and ldbits >= ceil(N/32)");
-  if (g.relu_bits) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_BIAS_RELU && g.M > SMALL_M && g.ldbits * 32 >= g.N && g.split_k <= 1,
+  if (g.mask_bits) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && (g.M > SMALL_M || g.operands_bf16) && g.ldbits * 32 >= g.N, "gemm: mask_bits need the MASK epilogue, M > 8 and ldbits >= ceil(N/32)");
+  if (g.relu_bits) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_BIAS_RELU && (g.M > SMALL_M || g.operands_bf16) && g.ldbits * 32 >= g.N && g.split_k <= 1,
                                   "gemm: relu_bits need the BIAS_RELU epilogue, M > 8 and ldbits >= ceil(N/32)");
   if (g.split_k > 1) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_NONE, "gemm: split-K slabs take no epilogue");
   if (g.accumulate) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_NONE && !g.colsum, "gemm: accumulate takes no epilogue");
@@ -410,6 +412,10 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
                      g.precision == ADDHIP_PREC_BF16X3, "gemm: bad precision");
   if (g.alpha == 0.0f) g.alpha = 1.0f;
   hipStream_t st = (hipStream_t)stream;
+  if (g.operands_bf16) {
+    ADDHIP_REQUIRE(!g.accumulate, "gemm: accumulate is not built for bf16-stored operands");
+    return addhip::gemm_bf16_dispatch(g, st);
+  }
   if (g.M <= SMALL_M && g.a_kcontig && !g.a_mean && g.split_k <= 1) {
     if (g.b_kcontig) hipLaunchKernelGGL(gemm_small_m_kernel<true>, dim3((g.N + 3) / 4), dim3(256), 0, st, g);
     else hipLaunchKernelGGL(gemm_small_m_kernel<false>, dim3((g.N + 31) / 32), dim3(256), 0, st, g);

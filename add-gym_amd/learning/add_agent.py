@@ -63,6 +63,11 @@ class ADDAgent:
             raise ValueError(f"agent.matmul_precision must be one of {sorted(H.PRECISIONS)}")
         self._matmul_precision = prec       # a property of this agent: carried by every GEMM descriptor it builds
         self._prec = H.PRECISIONS[prec]
+        # "bf16" = bf16 STORAGE in the update step: hidden activations, pre-activation gradients and a shadow of the weights live
+        # in HBM as bf16 (fp32 master weights, fp32 accumulation, AdamW in fp32); the head / loss kernels, the rollout and the
+        # value / discriminator evaluation passes keep fp32 operands (formed by the bf16x2 products)
+        self._storage16 = prec == "bf16"
+        self._prec_small = H.PRECISIONS["bf16x2"] if self._storage16 else self._prec
 
         # ---- motion library + sampler (add_motion.py:14-33)
         kin = env.robot._kin_char_model
@@ -144,6 +149,8 @@ class ADDAgent:
         self._grad_clip = float(opt.get("grad_clip", 0.0))  # mp_optimizer.py:10, 42-46 (0 = off: the reference's default)
         if self._distributed:  # DDP ctor behaviour: every rank starts from rank 0's weights (base_agent.py:50-57)
             D.broadcast_(self._model.params, 0)
+        if self._storage16:
+            self._model.enable_shadow()
 
         self._build_workspace()
         self._build_plans()
@@ -210,9 +217,17 @@ class ADDAgent:
         # split-K scratch: one per net, because the three nets' update sections run on three concurrent streams
         self._slabs_all = z(3, need)
         self._slabs = self._slabs_all[0]
-        self._run_actor = NetRunner(m, m.actor, rows, dev, self._slabs_all[0], self._prec)
-        self._run_critic = NetRunner(m, m.critic, rows, dev, self._slabs_all[1], self._prec)
-        self._run_disc = NetRunner(m, m.disc, rows, dev, self._slabs_all[2], self._prec)
+        s16 = self._storage16
+        self._run_actor = NetRunner(m, m.actor, Mb + 1 if s16 else rows, dev, self._slabs_all[0], self._prec, s16)
+        self._run_critic = NetRunner(m, m.critic, Mb + 1 if s16 else rows, dev, self._slabs_all[1], self._prec, s16)
+        self._run_disc = NetRunner(m, m.disc, Mb + 1 if s16 else rows, dev, self._slabs_all[2], self._prec, s16)
+        # rollout / evaluation passes: the same runners, except in bf16-storage mode (fp32 operands, bf16x2 products)
+        if s16:
+            self._roll_actor = NetRunner(m, m.actor, N, dev, None, self._prec_small)
+            self._eval_critic = NetRunner(m, m.critic, self._eval_rows, dev, None, self._prec_small)
+            self._eval_disc = NetRunner(m, m.disc, self._eval_rows, dev, None, self._prec_small)
+        else:
+            self._roll_actor, self._eval_critic, self._eval_disc = self._run_actor, self._run_critic, self._run_disc
         self._side_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         OS, DS = self._task.obs_stride, self._task.disc_stride
         hd = m.disc.hidden
@@ -220,9 +235,13 @@ class ADDAgent:
                        norm_obs=z(Mb, OS), norm_act=z(Mb, 32), mb_logp=z(Mb), mb_adv=z(Mb), mb_tar=z(Mb), mb_mask=z(Mb), norm_diff=z(rows + 1, DS),
                        dv=z(Mb), dlogit=z(Mb + 1), a2=z(Mb, hd[-1]), a1=z(Mb, hd[0]), g=z(Mb, DS), G=z(Mb, DS), e1=z(Mb, hd[0]), da2=z(Mb, hd[-1]),
                        stats=z(32), scratch=z(4096, dt=torch.float64), adv_stats=z(2), rstats=z(2), perm_idx=z(Mb, dt=torch.int64))
+        if s16:  # bf16 copies of the GEMM operands the fp32 kernels produce
+            b16 = lambda *shape: torch.zeros(*shape, dtype=torch.bfloat16, device=dev)
+            self._W.update(norm_obs16=b16(Mb, OS), norm_diff16=b16(Mb + 1, DS), a2_16=b16(Mb, hd[-1]), a1_16=b16(Mb, hd[0]), G16=b16(Mb, DS),
+                           e1_16=b16(Mb, hd[0]))
 
     def _gemm(self, plan, *a, **k):
-        k.setdefault("precision", self._prec)
+        k.setdefault("precision", self._prec_small)
         g = gemm(*a, **k)
         plan.hold(g)
         plan.add("addhip_gemm_f32", g)
@@ -238,8 +257,9 @@ class ADDAgent:
         self._act_plans, self._step_out, self._reset_args = [], [], []
         for t in range(T + 1):
             p = Plan()
-            ra.forward(p, L.ptr(B["obs"][t]), N, a_mean=L.ptr(Nm["obs_mean"]), a_std=L.ptr(Nm["obs_std"]))
-            self._gemm(p, N, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
+            rr = self._roll_actor
+            rr.forward(p, L.ptr(B["obs"][t]), N, a_mean=L.ptr(Nm["obs_mean"]), a_std=L.ptr(Nm["obs_std"]))
+            self._gemm(p, N, 32, hA, L.ptr(rr.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
             self._act_plans.append(p)
         for t in range(T):
             self._step_out.append(L.StepOutT(L.ptr(B["obs"][t + 1]), None, L.ptr(B["obs_timeout"]), L.ptr(B["disc_obs"][t]), L.ptr(B["disc_demo"][t]),
@@ -254,7 +274,9 @@ class ADDAgent:
         # (the whole flat gradient is zeroed once per step, before the three sections fork: _run_update_sections; bias and head
         # gradients are then accumulated by atomics from the kernels that already hold the data)
         # actor
-        ra.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True)
+        s16 = self._storage16
+        x16 = L.ptr(W["norm_obs16"]) if s16 else None
+        ra.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True, x16_ptr=x16)
         self._gemm(p, Mb, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
         p.add("addhip_count_mask", L.ptr(W["mb_mask"]), Mb, L.ptr(W["nv"]))
         p.add("addhip_actor_loss", L.ptr(W["mean"]), L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_mask"]), Mb, m.std32,
@@ -265,20 +287,21 @@ class ADDAgent:
         p.add("addhip_col_sum", L.ptr(W["d_mean"]), Mb, 32, 32, m.g("actor", "bh"), 1.0, 1)
         self._gemm(p, Mb, hA, 32, L.ptr(W["d_mean"]), 32, 1, m.p("actor", "Wh"), hA, 0, L.ptr(ra.dz[-1]), hA, L.EPI_MASK,
                    colsum=m.g("actor", f"b{len(m.actor.hidden) - 1}"), **ra.mask_args(len(m.actor.hidden) - 1, 0, Mb))
-        ra.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True)
+        ra.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True, x16_ptr=x16)
         self._update_marks = [("actor", len(p.calls))]  # the net's gradient is complete after this many calls
         # critic
-        rc.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True)
+        rc.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True, x16_ptr=x16)
         p.add("addhip_critic_head", L.ptr(rc.h[-1]), hC, hC, Mb, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(W["mb_tar"]), self._critic_loss_weight * gs,
               None, L.ptr(W["dv"]), L.ptr(W["stats"]) + 4 * 8)
         p.add("addhip_head_backward", L.ptr(W["dv"]), m.p("critic", "Wh"), L.ptr(rc.h[-1]), hC, hC, Mb, L.ptr(rc.dz[-1]), m.g("critic", "Wh"),
               m.g("critic", "bh"), m.g("critic", f"b{len(m.critic.hidden) - 1}"))
-        rc.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True)
+        rc.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True, x16_ptr=x16)
         self._update_marks.append(("critic", len(p.calls)))
         # discriminator: Mb agent/demo differences + one zero-difference row (row Mb of norm_diff stays 0)
         Md = Mb + 1
         nd = L.ptr(W["norm_diff"])
-        rd.forward(p, nd, Md, sign_bits=True)
+        nd16 = L.ptr(W["norm_diff16"]) if s16 else None
+        rd.forward(p, nd, Md, sign_bits=True, x16_ptr=nd16)
         p.add("addhip_disc_head", L.ptr(rd.h[-1]), hD, hD, Mb, L.ptr(rd.h[-1]) + 4 * Mb * hD, m.p("disc", "Wh"), m.p("disc", "bh"), ls_d,
               L.ptr(W["dlogit"]), L.ptr(W["dlogit"]) + 4 * Mb, L.ptr(W["stats"]) + 4 * 12)
         p.add("addhip_head_backward", L.ptr(W["dlogit"]), m.p("disc", "Wh"), L.ptr(rd.h[-1]), hD, hD, Md, L.ptr(rd.dz[-1]), m.g("disc", "Wh"),
@@ -289,15 +312,32 @@ class ADDAgent:
             raise NotImplementedError("the gradient-penalty chain is written for the 2-hidden-layer discriminator (fc_2layers_*)")
         d1, d2 = m.disc.hidden
         p.add("addhip_bcast_mask", m.p("disc", "Wh"), L.ptr(h2), d2, d2, Mb, L.ptr(W["a2"]))
-        self._gemm(p, Mb, d1, d2, L.ptr(W["a2"]), d2, 1, m.p("disc", "W1"), d1, 0, L.ptr(W["a1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
-        self._gemm(p, Mb, DS, d1, L.ptr(W["a1"]), d1, 1, m.p("disc", "W0"), DS, 0, L.ptr(W["g"]), DS)
-        p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, L.ptr(W["G"]), L.ptr(W["stats"]) + 4 * 20)
-        # second-order terms: da1 = G W1^T ; e1 = da1 * m1 ; da2 = (e1 W2^T) * m2
-        self._gemm(p, Mb, d1, DS, L.ptr(W["G"]), DS, 1, m.p("disc", "W0"), DS, 1, L.ptr(W["e1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
-        self._gemm(p, Mb, d2, d1, L.ptr(W["e1"]), d1, 1, m.p("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **rd.mask_args(1, 0, Mb))
-        p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
-        rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1"]), d1, L.ptr(W["G"]), DS, Mb), 1: (L.ptr(W["a2"]), d2, L.ptr(W["e1"]), d1, Mb)},
-                    grads_zeroed=True, top_bias_done=True)
+        if s16:
+            # the same chain on bf16 operands: a2 and G are rounded once, a1 / e1 leave their GEMMs as bf16, g and da2 as fp32
+            # (the penalty and the column sum read them)
+            k16 = dict(precision=L.PREC_BF16, operands_bf16=1)
+            p.add("addhip_to_bf16", L.ptr(W["a2"]), L.ptr(W["a2_16"]), Mb, d2, d2, d2)
+            self._gemm(p, Mb, d1, d2, L.ptr(W["a2_16"]), d2, 1, m.p16("disc", "W1"), d1, 0, None, d1, L.EPI_MASK, C16=L.ptr(W["a1_16"]), ldc16=d1,
+                       **k16, **rd.mask_args(0, 0, Mb))
+            self._gemm(p, Mb, DS, d1, L.ptr(W["a1_16"]), d1, 1, m.p16("disc", "W0"), DS, 0, L.ptr(W["g"]), DS, **k16)
+            p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, L.ptr(W["G"]), L.ptr(W["stats"]) + 4 * 20)
+            p.add("addhip_to_bf16", L.ptr(W["G"]), L.ptr(W["G16"]), Mb, DS, DS, DS)
+            self._gemm(p, Mb, d1, DS, L.ptr(W["G16"]), DS, 1, m.p16("disc", "W0"), DS, 1, None, d1, L.EPI_MASK, C16=L.ptr(W["e1_16"]), ldc16=d1,
+                       **k16, **rd.mask_args(0, 0, Mb))
+            self._gemm(p, Mb, d2, d1, L.ptr(W["e1_16"]), d1, 1, m.p16("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **k16, **rd.mask_args(1, 0, Mb))
+            p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
+            rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1_16"]), d1, L.ptr(W["G16"]), DS, Mb), 1: (L.ptr(W["a2_16"]), d2, L.ptr(W["e1_16"]), d1, Mb)},
+                        grads_zeroed=True, top_bias_done=True, x16_ptr=nd16)
+        else:
+            self._gemm(p, Mb, d1, d2, L.ptr(W["a2"]), d2, 1, m.p("disc", "W1"), d1, 0, L.ptr(W["a1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
+            self._gemm(p, Mb, DS, d1, L.ptr(W["a1"]), d1, 1, m.p("disc", "W0"), DS, 0, L.ptr(W["g"]), DS)
+            p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, L.ptr(W["G"]), L.ptr(W["stats"]) + 4 * 20)
+            # second-order terms: da1 = G W1^T ; e1 = da1 * m1 ; da2 = (e1 W2^T) * m2
+            self._gemm(p, Mb, d1, DS, L.ptr(W["G"]), DS, 1, m.p("disc", "W0"), DS, 1, L.ptr(W["e1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
+            self._gemm(p, Mb, d2, d1, L.ptr(W["e1"]), d1, 1, m.p("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **rd.mask_args(1, 0, Mb))
+            p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
+            rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1"]), d1, L.ptr(W["G"]), DS, Mb), 1: (L.ptr(W["a2"]), d2, L.ptr(W["e1"]), d1, Mb)},
+                        grads_zeroed=True, top_bias_done=True)
         # L2 terms (add_agent.py:161-164, 181-186): logit reg on the head weights, weight decay on all disc weights
         wd = self._disc_weight_decay
         p.add("addhip_l2_grad", m.p("disc", "W0"), m.g("disc", "W0"), m.n_elem("disc", "W0"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
@@ -321,15 +361,17 @@ class ADDAgent:
             for r0 in range(0, total, chunk):
                 rows = min(chunk, total - r0)
                 p = Plan()
-                rc.forward(p, L.ptr(src) + 4 * r0 * OS, rows, a_mean=L.ptr(Nm["obs_mean"]), a_std=L.ptr(Nm["obs_std"]))
-                p.add("addhip_head_gemv", L.ptr(rc.h[-1]), hC, hC, rows, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(dst) + 4 * r0)
+                ec = self._eval_critic
+                ec.forward(p, L.ptr(src) + 4 * r0 * OS, rows, a_mean=L.ptr(Nm["obs_mean"]), a_std=L.ptr(Nm["obs_std"]))
+                p.add("addhip_head_gemv", L.ptr(ec.h[-1]), hC, hC, rows, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(dst) + 4 * r0)
                 self._critic_eval.append(p)
         self._disc_eval = []  # (r0, rows, forward + logits plan)
         for r0 in range(0, T * N, chunk):
             rows = min(chunk, T * N - r0)
             p = Plan()
-            rd.forward(p, L.ptr(W["norm_diff"]), rows)
-            p.add("addhip_head_gemv", L.ptr(rd.h[-1]), hD, hD, rows, m.p("disc", "Wh"), m.p("disc", "bh"), L.ptr(W["logits"]))
+            ed = self._eval_disc
+            ed.forward(p, L.ptr(W["norm_diff"]), rows)
+            p.add("addhip_head_gemv", L.ptr(ed.h[-1]), hD, hD, rows, m.p("disc", "Wh"), m.p("disc", "bh"), L.ptr(W["logits"]))
             self._disc_eval.append((r0, rows, p))
 
         self._gather_c = L.GatherT(L.ptr(W["perm_idx"]), Mb, L.ptr(B["obs"]), OS, tk.obs_dim, L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(B["action"]),
@@ -587,6 +629,8 @@ class ADDAgent:
                 else:
                     L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, self._lr, 0.9, 0.999, 1e-8,
                            self._wd, m.opt_step, st)
+                if self._storage16:
+                    m.refresh_shadow(st)
                 steps += 1
         return steps
 
@@ -600,6 +644,10 @@ class ADDAgent:
         main = torch.cuda.current_stream()
         streams = [main] + self._side_streams
         L.call("addhip_fill_zero", L.ptr(m.grads), m.count, main.cuda_stream)  # MPOptimizer.step's zero_grad (mp_optimizer.py:14-16)
+        if self._storage16:  # bf16 copies of the gathered minibatch rows, before the three sections fork
+            W, tk = self._W, self._task
+            L.call("addhip_to_bf16", L.ptr(W["norm_obs"]), L.ptr(W["norm_obs16"]), self.Mb, tk.obs_stride, tk.obs_stride, tk.obs_stride, main.cuda_stream)
+            L.call("addhip_to_bf16", L.ptr(W["norm_diff"]), L.ptr(W["norm_diff16"]), self.Mb + 1, tk.disc_stride, tk.disc_stride, tk.disc_stride, main.cuda_stream)
         fork = torch.cuda.Event()
         fork.record(main)
         # stream-ordered asynchronous collectives are an nccl (RCCL) property; any other backend (gloo in rehearsals) gets one
@@ -905,6 +953,7 @@ class ADDAgent:
         sd = {k.replace("_model.module.", "_model."): v for k, v in sd.items()}
         Nm, tk, m = self._Nrm, self._task, self._model
         m.load(sd)
+        m.refresh_shadow()
         Nm["obs_cnt"].copy_(sd["_obs_norm._count"])
         Nm["obs_mean"][:tk.obs_dim] = sd["_obs_norm._mean"].to(self._device)
         Nm["obs_std"][:tk.obs_dim] = sd["_obs_norm._std"].to(self._device)

@@ -64,7 +64,7 @@ class Model:
             for key, shape in net.specs:
                 if key in keys:
                     self.offsets[(net.name, key)] = (off, shape)
-                    off += (math.prod(shape) + 3) // 4 * 4
+                    off += (math.prod(shape) + 7) // 8 * 8  # 32-byte steps: every tensor is 16-byte aligned in the bf16 shadow too
             return first, off
 
         first_layer = ("W0", "b0")
@@ -80,6 +80,7 @@ class Model:
         self.exp_avg = torch.zeros(off, device=device)
         self.exp_avg_sq = torch.zeros(off, device=device)
         self.opt_step = 0
+        self.params16 = None  # bf16 shadow of params (agent.matmul_precision = bf16), refreshed after every optimiser step
         self._init_params(seed)
         # distribution_gaussian_diag.py:24-31, 63-94: fp32 logstd vector -> std and the log-prob constant
         logstd = torch.full((L.NUM_DOF,), float(math.log(self.action_std)), dtype=torch.float32)
@@ -100,6 +101,20 @@ class Model:
 
     def g(self, net, key):
         return self.p(net, key, self.grads)
+
+    def enable_shadow(self):
+        self.params16 = torch.zeros(self.count, dtype=torch.bfloat16, device=self.device)
+        self.refresh_shadow()
+
+    def refresh_shadow(self, stream=None):
+        """params16 = bf16(params), round to nearest even (one pass over the flat buffer)."""
+        if self.params16 is not None:
+            L.call("addhip_to_bf16", L.ptr(self.params), L.ptr(self.params16), 1, self.count, self.count, self.count,
+                   L.current_stream() if stream is None else stream)
+
+    def p16(self, net, key):
+        off, _ = self.offsets[(net, key)]
+        return self.params16.data_ptr() + 2 * off
 
     def n_elem(self, net, key):
         return math.prod(self.offsets[(net, key)][1])
@@ -208,9 +223,16 @@ class Plan:
 class NetRunner:
     """Forward / backward call recording for one Mlp over `rows` rows with its own activation buffers."""
 
-    def __init__(self, model, net, rows, device, slabs, precision=L.PREC_F32):
+    def __init__(self, model, net, rows, device, slabs, precision=L.PREC_F32, storage16=False):
         self.m, self.net, self.rows, self.slabs = model, net, rows, slabs
         self.precision = precision  # ADDHIP_PREC_* of every GEMM this runner records (agent.matmul_precision)
+        # storage16 (agent.matmul_precision = bf16): hidden activations and pre-activation gradients are kept as bf16 in HBM and
+        # the GEMMs read the model's bf16 weight shadow; the last hidden layer and the top gradient also exist in fp32 for the
+        # loss-head kernels
+        self.storage16 = bool(storage16)
+        if self.storage16:
+            self.h16 = [torch.zeros(rows, h, dtype=torch.bfloat16, device=device) for h in net.hidden]
+            self.dz16 = [torch.zeros(rows, h, dtype=torch.bfloat16, device=device) for h in net.hidden]
         self.early_mark = None
         self._bits_valid = False
         # ReLU sign bits of the hidden activations (1 bit per element): what the backward GEMMs read as their mask instead of
@@ -232,15 +254,30 @@ class NetRunner:
         """Mask of the backward pass through the ReLU of `layer` for rows [r0, r0+cnt): the sign bits where the forward pass
         of this plan wrote them (row chunks of more than 8 rows), the fp32 activations otherwise."""
         h = self.net.hidden[layer]
-        if self._bits_valid and cnt > 8:
+        if self._bits_valid and (cnt > 8 or self.storage16):
             ldb = (h + 31) // 32
             return dict(mask_bits=L.ptr(self.hb[layer]) + 4 * r0 * ldb, ldbits=ldb)
         return dict(mask=L.ptr(self.h[layer]) + 4 * r0 * h, ldmask=h)
 
-    def forward(self, plan, x_ptr, rows, a_mean=None, a_std=None, sign_bits=False):
-        """sign_bits: also write the ReLU sign bits (forward passes that are followed by a backward pass in the same plan)."""
+    def forward(self, plan, x_ptr, rows, a_mean=None, a_std=None, sign_bits=False, x16_ptr=None):
+        """sign_bits: also write the ReLU sign bits (forward passes that are followed by a backward pass in the same plan).
+        x16_ptr: bf16 copy of the input rows (storage16 runners)."""
         net, m = self.net, self.m
         self._bits_valid = bool(sign_bits)
+        if self.storage16:
+            assert x16_ptr is not None and a_mean is None, "bf16-storage runners take a bf16 copy of their (already normalised) input"
+            prev, ld, k = x16_ptr, net.in_ld, net.in_ld
+            n = len(net.hidden)
+            for i, h in enumerate(net.hidden):
+                for r0, cnt in self._row_chunks(rows):
+                    bits = dict(relu_bits=L.ptr(self.hb[i]) + 4 * r0 * ((h + 31) // 32), ldbits=(h + 31) // 32) if sign_bits else {}
+                    g = gemm(cnt, h, k, prev + 2 * r0 * ld, ld, 1, m.p16(net.name, f"W{i}"), k, 1,
+                             L.ptr(self.h[i]) + 4 * r0 * h if i == n - 1 else None, h, L.EPI_BIAS_RELU, m.p(net.name, f"b{i}"),
+                             precision=L.PREC_BF16, operands_bf16=1, C16=L.ptr(self.h16[i]) + 2 * r0 * h, ldc16=h, **bits)
+                    plan.hold(g)
+                    plan.add("addhip_gemm_f32", g)
+                prev, ld, k = L.ptr(self.h16[i]), h, h
+            return
         prev, ld, k = x_ptr, net.in_ld, net.in_ld
         for i, h in enumerate(net.hidden):
             for r0, cnt in self._row_chunks(rows):
@@ -251,26 +288,35 @@ class NetRunner:
                 plan.add("addhip_gemm_f32", g)
             prev, ld, k = L.ptr(self.h[i]), h, h
 
-    def backward(self, plan, x_ptr, rows, extra_dw=None, grads_zeroed=False, top_bias_done=False):
+    def backward(self, plan, x_ptr, rows, extra_dw=None, grads_zeroed=False, top_bias_done=False, x16_ptr=None):
         """dz[-1] must hold d loss / d (pre-activation of the last hidden layer).  extra_dw: {layer: (A_ptr, lda, B_ptr, ldb)}
         second product accumulated into dW of that layer (the gradient-penalty terms).  grads_zeroed: the caller cleared the
         whole gradient buffer at the start of the step (no per-bias memsets here); top_bias_done: the kernel that produced
-        dz[-1] also accumulated the top layer's bias gradient."""
+        dz[-1] also accumulated the top layer's bias gradient.  storage16 runners: x16_ptr = bf16 copy of the input rows, the
+        extra_dw operands are bf16 too, and the fp32 top gradient is rounded to bf16 once at the start."""
         net, m = self.net, self.m
         n = len(net.hidden)
+        s16 = self.storage16
+        esz = 2 if s16 else 4
+        kw = dict(precision=L.PREC_BF16, operands_bf16=1) if s16 else dict(precision=self.precision)
+        dz = self.dz16 if s16 else self.dz
+        acts = self.h16 if s16 else self.h
+        if s16:
+            assert x16_ptr is not None and grads_zeroed
+            plan.add("addhip_to_bf16", L.ptr(self.dz[n - 1]), L.ptr(self.dz16[n - 1]), rows, net.hidden[n - 1], net.hidden[n - 1], net.hidden[n - 1])
         for i in reversed(range(n)):
             out_d = net.hidden[i]
             in_ld = net.in_ld if i == 0 else net.hidden[i - 1]
-            inp = x_ptr if i == 0 else L.ptr(self.h[i - 1])
+            inp = (x16_ptr if s16 else x_ptr) if i == 0 else L.ptr(acts[i - 1])
             s = split_k_for(out_d, in_ld, rows)
             slab = out_d * in_ld
-            g = gemm(out_d, in_ld, rows, L.ptr(self.dz[i]), out_d, 0, inp, in_ld, 0, L.ptr(self.slabs), in_ld, split_k=s, precision=self.precision)
+            g = gemm(out_d, in_ld, rows, L.ptr(dz[i]), out_d, 0, inp, in_ld, 0, L.ptr(self.slabs), in_ld, split_k=s, **kw)
             plan.hold(g)
             plan.add("addhip_gemm_f32", g)
             total = s
             if extra_dw and i in extra_dw:
                 a_ptr, lda, b_ptr, ldb, erows = extra_dw[i]
-                g2 = gemm(out_d, in_ld, erows, a_ptr, lda, 0, b_ptr, ldb, 0, L.ptr(self.slabs) + 4 * s * slab, in_ld, split_k=s, precision=self.precision)
+                g2 = gemm(out_d, in_ld, erows, a_ptr, lda, 0, b_ptr, ldb, 0, L.ptr(self.slabs) + 4 * s * slab, in_ld, split_k=s, **kw)
                 plan.hold(g2)
                 plan.add("addhip_gemm_f32", g2)
                 total = 2 * s
@@ -286,8 +332,9 @@ class NetRunner:
                 if not grads_zeroed:
                     plan.add("addhip_fill_zero", m.g(net.name, f"b{i - 1}"), prev_d)
                 for r0, cnt in self._row_chunks(rows):
-                    g3 = gemm(cnt, prev_d, out_d, L.ptr(self.dz[i]) + 4 * r0 * out_d, out_d, 1, m.p(net.name, f"W{i}"), prev_d, 0,
-                              L.ptr(self.dz[i - 1]) + 4 * r0 * prev_d, prev_d, L.EPI_MASK, colsum=m.g(net.name, f"b{i - 1}"), precision=self.precision,
-                              **self.mask_args(i - 1, r0, cnt))
+                    out = dict(C16=L.ptr(self.dz16[i - 1]) + 2 * r0 * prev_d, ldc16=prev_d) if s16 else {}
+                    g3 = gemm(cnt, prev_d, out_d, L.ptr(dz[i]) + esz * r0 * out_d, out_d, 1, (m.p16 if s16 else m.p)(net.name, f"W{i}"), prev_d, 0,
+                              None if s16 else L.ptr(self.dz[i - 1]) + 4 * r0 * prev_d, prev_d, L.EPI_MASK, colsum=m.g(net.name, f"b{i - 1}"),
+                              **kw, **out, **self.mask_args(i - 1, r0, cnt))
                     plan.hold(g3)
                     plan.add("addhip_gemm_f32", g3)

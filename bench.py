@@ -96,7 +96,8 @@ def gemm_roofline(agent, precision):
     else:
         products = {"bf16x3": 6, "bf16x2": 3, "bf16": 1}[precision]
         peak = MFMA_BF16_PEAK_TFLOPS / products
-        kern = "gemm_split_kernel (v_mfma_f32_32x32x16_bf16 x %d per k-step; small shapes stay on gemm_kernel); all GEMM launches of one optimiser step" % products
+        kern = ("gemm_bf16_kernel (bf16 operands in HBM, " if precision == "bf16" else "gemm_split_kernel (") + \
+               "v_mfma_f32_32x32x16_bf16 x %d per k-step; small shapes stay on gemm_kernel); all GEMM launches of one optimiser step" % products
         tr, tr_src = None, None
     return {"bound": "mfma", "kernel": kern, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": tr, "traffic_source": tr_src,
             "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"],
@@ -346,12 +347,14 @@ def main():
         del agent
         alts = []
         for prec, what in (("bf16x3", "6 bf16 MFMAs on an exact 3-way split (fp32-level error)"),
-                           ("bf16x2", "3 bf16 MFMAs on the two leading chunks (16 significant bits per operand; TF32-class, 64x less error than TF32)")):
+                           ("bf16x2", "3 bf16 MFMAs on the two leading chunks (16 significant bits per operand; TF32-class, 64x less error than TF32)"),
+                           ("bf16", "bf16 STORAGE: activations, gradients and a weight shadow kept as bf16 in HBM (update step), 1 bf16 MFMA per k-step, "
+                                    "fp32 accumulate and master weights; rollout / evaluation passes on bf16x2")):
             agent2 = make_agent(prec)
             dt2 = timed(agent2)
             if rank == 0:
                 alts.append({"matmul_precision": prec, "value": env_steps / dt2, "unit": "env-steps/s", "ms_per_step": 1000.0 * dt2 / a.steps,
-                             "dtype": "f32 operands and results; products = " + what + ", fp32 accumulate",
+                             "dtype": ("bf16 operands; " if prec == "bf16" else "f32 operands and results; products = ") + what + ", fp32 accumulate",
                              "roofline": gemm_roofline(agent2, prec)})
             del agent2
         if rank == 0:

@@ -228,8 +228,19 @@ typedef struct {
    * C[M,ldc] with hardware fp32 atomics (no epilogue; the caller zeroes C, e.g. the flat gradient buffer at the start of an optimiser
    * step; several GEMMs may accumulate into the same C).  Summation order is not fixed: results vary in the last bits run to run. */
   int32_t accumulate;
+  /* bf16 STORAGE (agent.matmul_precision = bf16).  operands_bf16 != 0: A and B point at bf16 values (lda / ldb count bf16 elements; K or the
+   * contiguous extent, and the leading dimensions, multiples of 8), products by v_mfma_f32_32x32x16_bf16 with fp32 accumulation, no
+   * conversion anywhere.  C16 (optional): a second copy of the result rounded to bf16 (nearest even), leading dimension ldc16; with it C
+   * may be NULL.  Epilogues, sign bits, column sums and split-K slabs (fp32) as for fp32 operands; no fused normalisation. */
+  int32_t operands_bf16;
+  uint16_t* C16;
+  int32_t ldc16;
 } addhip_gemm_t;
 int addhip_gemm_f32(const addhip_gemm_t* g, void* stream);
+
+/* dst[r*ld_dst + c] = bf16(src[r*ld_src + c]), round to nearest even (bf16-storage mode: minibatch inputs, head gradients, the weight
+ * shadow after an optimiser step); cols and both leading dimensions multiples of 4 */
+int addhip_to_bf16(const float* src, uint16_t* dst, int64_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream);
 
 /* out[n] (+)= scale * sum over `slabs` of in[s*slab_stride + n]  (split-K combine, grads) */
 int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count,

@@ -135,7 +135,7 @@ def _check_param_summary(g, prefix, named, steps, lr=1e-4, long_run=False):
     for name, val in named.items():
         f = np.asarray(val, np.float64).reshape(-1)
         ref_l2 = float(g[f"{prefix}.{name}.l2"])
-        assert abs(np.sqrt(np.square(f).sum()) - ref_l2) <= 2e-4 * max(ref_l2, 1e-12), (prefix, name)
+        assert abs(np.sqrt(np.square(f).sum()) - ref_l2) <= (6e-4 if long_run else 2e-4) * max(ref_l2, 1e-12), (prefix, name)
         stride = max(1, f.size // 64)
         d = np.abs(np.asarray(val, F).reshape(-1)[::stride][:64] - g[f"{prefix}.{name}.sample"])
         if long_run:  # a whole iteration (40 steps): rounding noise compounds; bound it against the distance travelled (<= lr*steps)
@@ -152,25 +152,36 @@ def _mid(cdf, k):
     return F(0.5 * (lo + float(cdf[k])))
 
 
-@pytest.mark.parametrize("precision", PRECISIONS)
-def test_one_full_iteration_matches_reference_and_oracle(precision):
+LOOP_VARIANTS = {"loop_1iter": dict(two=False, task={}), "loop_1iter_two": dict(two=True, task={}),
+                 "loop_1iter_time": dict(two=False, task=dict(max_episode_length=0.4))}
+
+
+@pytest.mark.parametrize("name,precision", [("loop_1iter", p) for p in PRECISIONS] + [("loop_1iter_two", "fp32"), ("loop_1iter_time", "fp32")])
+def test_one_full_iteration_matches_reference_and_oracle(name, precision):
     """BASELINE config 1 stand-in: the reference's own iteration (fake kinematic engine, recorded draws) replayed
-    through the HIP engine."""
+    through the HIP engine.  Variants: the two-clip library (clip draws, raw-frame table offsets, [2,20] sampler table) and a
+    0.4 s episode limit with pre-aged episode clocks, whose DONE_TIME samples must bootstrap from the PRE-reset observation
+    (ppo_agent.py:117-133; here: the obs_timeout rows, since no next_obs buffer is kept)."""
     import torch
     from oracle import loop as LP
     from oracle import task as OT
     from tests.util import oracle_lib
 
-    g = gload("loop_1iter")
+    g = gload(name)
+    var = LOOP_VARIANTS[name]
     Tn, n = g["noise"].shape[:2]
     cfg = make_cfg(n, steps_per_iter=Tn, matmul_precision=precision)
-    ag = make_agent(cfg, [gload("motion_small")["frames"]], [1.0])
+    cfg["task"].update(var["task"])
+    ms = gload("motion_small")
+    frames, weights = ([ms["two_frames0"], ms["two_frames1"]], [1.0, 3.0]) if var["two"] else ([ms["frames"]], [1.0])
+    ag = make_agent(cfg, frames, weights)
     ag._model.load({k: torch.tensor(v) for k, v in OL.synth_params(int(g["seed"])).items()})
 
     # ---- oracle run alongside: supplies the per-step sampler probabilities needed to turn the reference's
     # multinomial draws into the uniforms of the device sampler, and a second opinion on every output
-    lib = oracle_lib(golden_tables=True)
-    orc = LP.Agent(LP.AgentCfg(), OT.TaskCfg(), lib, n, OL.synth_params(int(g["seed"])))
+    lib = oracle_lib(two=var["two"], golden_tables=True)
+    orc = LP.Agent(LP.AgentCfg(), OT.TaskCfg(**var["task"]), lib, n, OL.synth_params(int(g["seed"])))
+    clip_cdf = np.cumsum(lib.weights, dtype=F)
     init = dict(ids=g["init_ids"], segments=g["init_segments"], jitter=g["init_jitter"])
     resets = []
     for t in range(Tn):
@@ -182,19 +193,23 @@ def test_one_full_iteration_matches_reference_and_oracle(precision):
         u = np.zeros((3, n), F)
         probs = orc.task.sampler.probs(draw["ids"]) if len(env_ids) else None
         for j, e in enumerate(env_ids):
-            u[0, e] = 0.5  # single clip
+            u[0, e] = _mid(clip_cdf, int(draw["ids"][j]))  # the clip the reference's multinomial drew
             u[1, e] = _mid(np.cumsum(probs[j]), int(draw["segments"][j]))
             u[2, e] = draw["jitter"][j]
         return T(u)
 
     inj_u = {ag.stream_reset_all(0): uniforms(np.arange(n), init)}
     orc.init(init)
+    preset = g["time_preset"].astype(F)  # zeros except in the time variant: episode clocks aged, motion clocks untouched
+    orc.task.time = (orc.task.time + preset).astype(F)
+    orc.task.time_off = (orc.task.time_off - preset).astype(F)
+    errors0 = orc.task.sampler.errors.copy()  # the table in effect during the whole rollout (it is updated in build-train-data)
     orc_info = orc.train_iter(LP.Draws(g["noise"], resets, g["perms"]), [(plan[t] >= 0) for t in range(Tn)])
+    errors1, orc.task.sampler.errors = orc.task.sampler.errors, errors0
     for t in range(Tn):
         ids = np.nonzero(orc.buf["done"][t] != 0)[0]
-        # sampler errors do not change during the rollout, so probabilities computed after the fact are the ones in effect
         inj_u[ag.stream_train_reset(0 * Tn + t)] = uniforms(ids, resets[t])
-    # the oracle updated its sampler errors at the end of the iteration; the draws above must use the initial (all-ones) table
+    orc.task.sampler.errors = errors1
     assert np.all(g["reset_count"] == [(orc.buf["done"][t] != 0).sum() for t in range(Tn)])
 
     ent = ag._env.robot.entity
@@ -207,11 +222,17 @@ def test_one_full_iteration_matches_reference_and_oracle(precision):
     ag.inject = dict(noise=T(g["noise"]), uniforms=inj_u, perms=perms, pre_step=pre_step)
     ag.reset_all_envs()
     ag._init_train()
+    ag._S["time"].add_(T(preset))
+    ag._S["time_off"].sub_(T(preset))
     info = ag._train_iter()
     torch.cuda.synchronize()
     B = ag._B
     done = B["done"].cpu().numpy()
     assert np.array_equal(done, g["buf.done"])                                   # bit-exact flags, whole rollout
+    if name == "loop_1iter_time":
+        assert (done == 3).sum() >= 10
+    if name == "loop_1iter_two":
+        assert set(np.unique(B["motion_id"].cpu().numpy())) == {0, 1}
     assert np.array_equal(B["motion_time"].cpu().numpy(), g["buf.motion_times"])  # bit-exact clocks and reset times
     np.testing.assert_allclose(B["obs"][Tn - 1].cpu().numpy()[:, :264], g["buf.obs_last"], rtol=0, atol=5e-5)
     assert np.all(B["obs"].cpu().numpy()[..., 264:] == 0)

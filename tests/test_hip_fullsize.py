@@ -20,8 +20,8 @@ F = np.float32
 # profiles/r02_grad_error_table.log).  fp32 MFMA and the exact bf16x3 split must be as close to float64 as torch's fp32 is, give or
 # take summation order (factor 8, floor 2e-4); bf16x2 keeps 16 significant bits per operand (2^-15 |a||b| per product).
 L2_FACTOR, L2_FLOOR = {"fp32": 8.0, "bf16x3": 8.0}, 2e-4
-L2_ABS = {"bf16x2": 1.5e-2}
-MAX_ABS = {"fp32": 4e-2, "bf16x3": 4e-2, "bf16x2": 1e-1}   # largest element error / largest gradient element, per tensor (torch-CPU fp32 itself: up to 3e-2)
+L2_ABS = {"bf16x2": 1.5e-2, "bf16": 1.2e-1}   # bf16 = bf16 STORAGE of activations / gradients / weight shadow (8 significant bits, nearest even)
+MAX_ABS = {"fp32": 4e-2, "bf16x3": 4e-2, "bf16x2": 1e-1, "bf16": 4e-1}   # largest element error / largest gradient element, per tensor (torch-CPU fp32 itself: up to 3e-2)
 
 
 def _fill_minibatch(ag, model, seed):
@@ -59,7 +59,7 @@ def _fill_minibatch(ag, model, seed):
 _ORACLE_GRADS = {}  # CPU autograd gradients of the minibatch, shared by the precision parametrisation
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x2"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x2", "bf16"])
 def test_update_plan_at_4096_envs_all_gradients_match_oracle(precision):
     import torch
     import add_gym_amd.learning.add_agent as A
@@ -105,7 +105,7 @@ def test_update_plan_at_4096_envs_all_gradients_match_oracle(precision):
     # logged scalars of the step
     ag._total_samples = ag.T * ag.N
     stats = ag._collect_info(1)
-    tol = 1e-3
+    tol = 2e-2 if precision == "bf16" else 1e-3
     for k in ("critic_loss", "actor_loss", "disc_loss", "disc_grad_penalty", "disc_logit_loss", "disc_neg_logit", "clip_frac", "imp_ratio"):
         np.testing.assert_allclose(stats[k], info[k], rtol=tol, atol=tol, err_msg=k)
     # padded rows / columns of the device layout never receive gradient
@@ -251,3 +251,39 @@ def test_randomised_rigid_shard_8192_envs_and_graph_rollout():
         assert torch.isfinite(ag._S["sim_pose"]).all() and torch.isfinite(ag._S["sim_vel"]).all()
         assert (len(ag._graphs) > 0) == (not dr)
         assert int((ag._B["done"] == 1).sum()) > 0
+
+
+def test_bf16_storage_mode_tracks_fp32_training():
+    """agent.matmul_precision=bf16 (bf16 activations / gradients / weight shadow in HBM for the update step, fp32 master weights and
+    accumulation): six iterations from the same seeds stay close to the fp32-MFMA run -- losses and discriminator statistics within
+    10 %, identical rollouts at iteration 0 (the rollout runs on fp32 operands), parameters within the distance Adam travels."""
+    import torch
+    import add_gym_amd.learning.add_agent as A
+
+    runs = {}
+    for prec in ("fp32", "bf16"):
+        cfg = make_cfg(1024, steps_per_iter=32, matmul_precision=prec)
+        cfg["task"]["motion_file"] = "synthetic:2x600"
+        cfg["seed"] = 3
+        ag = A.ADDAgent(cfg)
+        assert ag._storage16 == (prec == "bf16")
+        ag.reset_all_envs()
+        ag._init_train()
+        rows = []
+        for it in range(6):
+            info = ag._train_iter()
+            ag._iter += 1
+            rows.append(info)
+            if it == 0:
+                first_done = ag._B["done"].clone()
+        torch.cuda.synchronize()
+        runs[prec] = (rows, first_done, ag._model.export())
+        del ag
+    a, b = runs["fp32"], runs["bf16"]
+    assert torch.equal(a[1], b[1])  # same weights, same draws: the first rollout's done flags coincide
+    for it in range(6):
+        for k in ("critic_loss", "disc_loss", "disc_grad_penalty", "disc_reward_mean", "adv_std", "mean_return"):
+            x, y = float(a[0][it][k]), float(b[0][it][k])
+            assert np.isfinite(y) and abs(x - y) <= 0.10 * max(abs(x), abs(y)) + 2e-3, (it, k, x, y)
+    for k, v in a[2].items():  # 240 optimiser steps at lr 1e-4: nobody moved further than 0.024 from the start
+        assert float((v - b[2][k]).abs().max()) <= 3e-2, k

@@ -228,3 +228,83 @@ def test_relu_sign_bits_roundtrip(N, precision):
     torch.cuda.synchronize()
     assert torch.equal(out_b, out_f) and float((out_f != 0).float().mean()) > 0.3
     torch.testing.assert_close(cs_b, cs_f, rtol=1e-4, atol=1e-3)
+
+
+def run_gemm_bf16(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, seed=0, both_outputs=True):
+    """Operands STORED as bf16 (addhip_gemm_t.operands_bf16): the products are exact, so against float64 on the same bf16 values the
+    only error is the fp32 accumulation; the optional bf16 result copy must be the fp32 result rounded to nearest even."""
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import gemm
+
+    rng = np.random.RandomState(seed)
+    A = torch.tensor(rng.uniform(-1, 1, (M, K)).astype(F)).to(torch.bfloat16)
+    B = torch.tensor(rng.uniform(-1, 1, (N, K)).astype(F)).to(torch.bfloat16)
+    bias = rng.uniform(-1, 1, N).astype(F)
+    mask = rng.uniform(-1, 1, (M, N)).astype(F)
+    dA = (A if a_kc else A.t().contiguous()).cuda()
+    dB = (B if b_kc else B.t().contiguous()).cuda()
+    lda, ldb = (K if a_kc else M), (K if b_kc else N)
+    ldc = (N + 7) // 8 * 8
+    dC = torch.full((max(split_k, 1), M, ldc), 9.0, device="cuda")
+    dC16 = torch.full((M, ldc), 9.0, device="cuda", dtype=torch.bfloat16)
+    dbias, dmask = T(bias), T(mask)
+    dcs = torch.full((N,), 0.5, device="cuda")
+    use16 = both_outputs and split_k <= 1
+    g = gemm(M, N, K, L.ptr(dA), lda, a_kc, L.ptr(dB), ldb, b_kc, L.ptr(dC), ldc, epilogue, L.ptr(dbias), L.ptr(dmask), N, None, None, split_k, 1.0,
+             L.ptr(dcs) if epilogue == 3 else None, 1, operands_bf16=1, C16=L.ptr(dC16) if use16 else None, ldc16=ldc)
+    L.call("addhip_gemm_f32", g, L.current_stream())
+    torch.cuda.synchronize()
+    A64, B64 = A.double().numpy(), B.double().numpy()
+    ref = A64 @ B64.T
+    scale = np.abs(A64) @ np.abs(B64).T
+    if epilogue in (1, 2):
+        ref = ref + bias
+    if epilogue == 2:
+        ref = np.maximum(ref, 0)
+    if epilogue == 3:
+        ref = np.where(mask > 0, ref, 0)
+    out = dC.cpu().numpy().astype(np.float64)
+    got = out.sum(0)[:, :N] if split_k > 1 else out[0][:, :N]
+    err = np.abs(got - ref)
+    assert np.all(err <= 4e-7 * scale + 1e-6), (M, N, K, a_kc, b_kc, epilogue, split_k, float((err / np.maximum(scale, 1e-30)).max()))
+    if ldc > N:
+        assert np.all(out[0][:, N:] == 9.0)
+    if use16:
+        want16 = torch.tensor(dC[0].cpu().numpy()[:, :N]).to(torch.bfloat16)
+        assert torch.equal(dC16.cpu()[:, :N], want16)  # same fp32 value, rounded to nearest even
+    if epilogue == 3:
+        cs = dcs.cpu().numpy().astype(np.float64) - 0.5
+        cs_scale = np.where(mask > 0, scale, 0).sum(0)
+        assert np.all(np.abs(cs - got.sum(0)) <= 4e-7 * cs_scale + 1e-5)
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])
+def test_gemm_bf16_storage(a_kc, b_kc):
+    """The bf16-storage GEMM (gemm_bf16.hip): every operand layout, ragged edges, K tails, epilogues, split-K slabs."""
+    M0 = 4104 if not a_kc else 4100  # m-contiguous operands move 8 rows per load
+    N0 = 1032 if not b_kc else 1000
+    run_gemm_bf16(M0, N0, 1024 + 8, a_kc, b_kc)
+    run_gemm_bf16(256, 128, 64, a_kc, b_kc)
+    run_gemm_bf16(16384 if not a_kc else 16385, 512, 272, a_kc, b_kc)
+    if a_kc:
+        for epi in (1, 2, 3):
+            run_gemm_bf16(1000, 512, 1024, 1, b_kc, epilogue=epi)
+    if not a_kc and not b_kc:  # the weight-gradient shapes: K = minibatch rows (odd count: the discriminator's Mb + 1), split-K slabs
+        run_gemm_bf16(1024, 272, 16385, 0, 0, split_k=22)
+        run_gemm_bf16(1024, 1024, 16384, 0, 0, split_k=8)
+        run_gemm_bf16(32, 512, 4096, 0, 0, split_k=32)
+
+
+def test_to_bf16_rounds_to_nearest_even():
+    import torch
+    import add_gym_amd._lib as L
+
+    rng = np.random.RandomState(1)
+    x = np.concatenate([rng.standard_normal(4096 * 12).astype(F) * 10, np.asarray([1.00390625, 1.01171875, -1.00390625, 3.0e-39], F)]).reshape(-1, 4)
+    src = torch.zeros(x.shape[0], 8, device="cuda")
+    src[:, :4] = T(x)
+    dst = torch.full((x.shape[0], 12), 7.0, device="cuda", dtype=torch.bfloat16)
+    L.call("addhip_to_bf16", L.ptr(src), L.ptr(dst), x.shape[0], 4, 8, 12, L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, :4].cpu(), torch.tensor(x).to(torch.bfloat16)) and bool((dst[:, 4:] == 7.0).all())

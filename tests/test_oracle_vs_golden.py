@@ -298,12 +298,22 @@ def test_losses_grads_adamw():
             _check_summary(g, f"param{step + 1}", {k: v.detach().numpy() for k, v in model.p.items()}, rtol=1e-5)
 
 
-def test_loop_one_iteration():
-    g = gload("loop_1iter")
+LOOP_VARIANTS = {"loop_1iter": dict(two=False, task={}), "loop_1iter_two": dict(two=True, task={}),
+                 "loop_1iter_time": dict(two=False, task=dict(max_episode_length=0.4))}
+
+
+@pytest.mark.parametrize("name", list(LOOP_VARIANTS))
+def test_loop_one_iteration(name):
+    """One whole reference iteration replayed: single clip; two clips (clip draws, raw-frame table offsets, [2,20] sampler table);
+    0.4 s episode limit with pre-aged episode clocks (DONE_TIME samples bootstrap from the pre-reset next_obs)."""
+    g = gload(name)
+    v = LOOP_VARIANTS[name]
     n = g["noise"].shape[1]
-    lib = oracle_lib(golden_tables=True)
-    ag = LP.Agent(LP.AgentCfg(), T.TaskCfg(), lib, n, L.synth_params(int(g["seed"])))
+    lib = oracle_lib(two=v["two"], golden_tables=True)
+    ag = LP.Agent(LP.AgentCfg(), T.TaskCfg(**v["task"]), lib, n, L.synth_params(int(g["seed"])))
     ag.init(dict(ids=g["init_ids"], segments=g["init_segments"], jitter=g["init_jitter"]))
+    ag.task.time = (ag.task.time + g["time_preset"]).astype(np.float32)          # (zeros except in the time variant)
+    ag.task.time_off = (ag.task.time_off - g["time_preset"]).astype(np.float32)
     Tn = g["noise"].shape[0]
     resets = []
     for t in range(Tn):

@@ -363,13 +363,31 @@ def gen_normalizers():
     _save("normalizers", **out)
 
 
-def gen_loop_1iter():
+def gen_loop_1iter_two():
+    """The whole iteration on the TWO-clip library (weights 1:3): clip ids are drawn per reset, the sampler table is [2,20], and the
+    step tables are indexed with the raw-frame clip offsets (motion_lib.py:280-282, 322-326)."""
+    gen_loop_1iter(name="loop_1iter_two", two_clip=True)
+
+
+def gen_loop_1iter_time():
+    """The whole iteration with a 0.4 s episode limit and envs that are already up to 0.36 s into their episodes, so that DONE_TIME
+    samples occur: the critic then bootstraps from V(next_obs) of the PRE-reset observation (ppo_agent.py:117-133)."""
+    gen_loop_1iter(name="loop_1iter_time", task_over={"max_episode_length": 0.4}, time_preset=True)
+
+
+def gen_loop_1iter(name="loop_1iter", two_clip=False, task_over=None, time_preset=False):
     n = 32
-    ag, cfg = build_agent(n, seed=5)
+    ag, cfg = build_agent(n, seed=5, two_clip=two_clip, task_over=task_over)
     load_synth(ag, 303)
     log0 = DrawLog()
     with log0.recording():
         ag._curr_obs, ag._curr_info = ag._reset_envs()
+    preset = torch.zeros(n)
+    if time_preset:
+        # shift the episode clock without moving the motion clock: k/64 is exact in fp32 and so is (offset - k/64)
+        preset = T(np.random.RandomState(12).randint(0, 24, n).astype(np.float32) / 64.0)
+        ag._env.time_buf[:] = ag._env.time_buf + preset
+        ag._add_obs._motion_time_offsets[:] = ag._add_obs._motion_time_offsets - preset
     ag._exp_buffer.clear()
     perm0 = ag._exp_buffer._sample_buf.clone()
     # force some early terminations through fake contacts at chosen steps
@@ -409,7 +427,7 @@ def gen_loop_1iter():
     pad = lambda x, fill, dt: torch.cat([x.to(dt), torch.full((kmax - len(x),), fill, dtype=dt)])
     eb = ag._exp_buffer
     out = dict(
-        seed=303, contact_plan=contact_plan, noise=torch.stack(noise),
+        seed=303, contact_plan=contact_plan, noise=torch.stack(noise), time_preset=preset,
         reset_count=np.asarray([len(r[0]) for r in resets]),
         reset_ids=torch.stack([pad(r[0], 0, torch.long) for r in resets]),
         reset_segments=torch.stack([pad(r[1], 0, torch.long) for r in resets]),
@@ -433,7 +451,7 @@ def gen_loop_1iter():
     names = [n_ for n_, _ in PARAM_SHAPES]
     sd_params = dict(ag.named_parameters())
     out.update({"param." + k: v for k, v in param_summary({n_: sd_params[n_] for n_ in names}).items()})
-    _save("loop_1iter", **out)
+    _save(name, **out)
 
 
 def gen_logger():
@@ -555,5 +573,5 @@ def gen_test_rollout():
           mean_return=float(info["mean_return"]), mean_ep_len=float(info["mean_ep_len"]), num_eps=int(info["num_eps"]))
 
 
-AGENT_GENS = dict(logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
+AGENT_GENS = dict(loop_1iter_two=gen_loop_1iter_two, loop_1iter_time=gen_loop_1iter_time, logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
                   td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
