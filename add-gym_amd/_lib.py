@@ -91,6 +91,7 @@ SIGNATURES = {
     "addhip_rigid_step": [P(RigidModelT), vp, vp, vp, i32, i32, vp, vp, vp],
     "addhip_gemm_f32": [P(GemmT), vp],
     "addhip_to_bf16": [vp, vp, i64, i32, i32, i32, vp],
+    "addhip_to_bf16_t": [vp, vp, i32, i32, i32, i32, vp],
     "addhip_slab_reduce": [vp, i32, i64, vp, i64, f32, i32, vp],
     "addhip_col_sum": [vp, i32, i32, i32, vp, f32, i32, vp],
     "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp],

@@ -234,6 +234,24 @@ __global__ void to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ 
   }
 }
 
+// transposing variant: dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) through a 32x33 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void to_bf16_t_kernel(const float* __restrict__ src, u16* __restrict__ dst, int rows, int cols, int ld_src, int ld_dst) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + ty + 8 * j, c = c0 + tx;
+    tile[ty + 8 * j][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, r = r0 + tx;
+    if (r < rows && c < cols) dst[(size_t)c * ld_dst + r] = to_bf16(tile[tx][ty + 8 * j]);
+  }
+}
+
 }  // namespace
 
 namespace addhip {
@@ -277,4 +295,10 @@ extern "C" int addhip_to_bf16(const float* src, uint16_t* dst, int64_t rows, int
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)rows, cols, ld_src, ld_dst);
   return addhip::check_launch("to_bf16_kernel");
+}
+
+extern "C" int addhip_to_bf16_t(const float* src, uint16_t* dst, int32_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream) {
+  ADDHIP_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "to_bf16_t: bad arguments");
+  hipLaunchKernelGGL(to_bf16_t_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, ld_src, ld_dst);
+  return addhip::check_launch("to_bf16_t_kernel");
 }

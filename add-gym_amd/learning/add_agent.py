@@ -317,9 +317,9 @@ class ADDAgent:
             # (the penalty and the column sum read them)
             k16 = dict(precision=L.PREC_BF16, operands_bf16=1)
             p.add("addhip_to_bf16", L.ptr(W["a2"]), L.ptr(W["a2_16"]), Mb, d2, d2, d2)
-            self._gemm(p, Mb, d1, d2, L.ptr(W["a2_16"]), d2, 1, m.p16("disc", "W1"), d1, 0, None, d1, L.EPI_MASK, C16=L.ptr(W["a1_16"]), ldc16=d1,
+            self._gemm(p, Mb, d1, d2, L.ptr(W["a2_16"]), d2, 1, m.p16t("disc", "W1"), d2, 1, None, d1, L.EPI_MASK, C16=L.ptr(W["a1_16"]), ldc16=d1,
                        **k16, **rd.mask_args(0, 0, Mb))
-            self._gemm(p, Mb, DS, d1, L.ptr(W["a1_16"]), d1, 1, m.p16("disc", "W0"), DS, 0, L.ptr(W["g"]), DS, **k16)
+            self._gemm(p, Mb, DS, d1, L.ptr(W["a1_16"]), d1, 1, m.p16t("disc", "W0"), d1, 1, L.ptr(W["g"]), DS, **k16)
             p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, L.ptr(W["G"]), L.ptr(W["stats"]) + 4 * 20)
             p.add("addhip_to_bf16", L.ptr(W["G"]), L.ptr(W["G16"]), Mb, DS, DS, DS)
             self._gemm(p, Mb, d1, DS, L.ptr(W["G16"]), DS, 1, m.p16("disc", "W0"), DS, 1, None, d1, L.EPI_MASK, C16=L.ptr(W["e1_16"]), ldc16=d1,

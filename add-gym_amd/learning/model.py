@@ -103,18 +103,32 @@ class Model:
         return self.p(net, key, self.grads)
 
     def enable_shadow(self):
+        """bf16 shadows of the parameters: params16 in the flat layout (W[out,in]: what the forward and weight-gradient GEMMs read) and
+        params16t holding W^T[in,out] of every hidden weight past a net's first layer (what the backward dX GEMMs and the gradient-
+        penalty chain read, k-contiguously)."""
         self.params16 = torch.zeros(self.count, dtype=torch.bfloat16, device=self.device)
+        self.params16t = torch.zeros(self.count, dtype=torch.bfloat16, device=self.device)
+        self._transposed = [(net.name, f"W{i}") for net in self.nets for i in range(len(net.hidden)) if i > 0 or net is self.disc]
         self.refresh_shadow()
 
     def refresh_shadow(self, stream=None):
-        """params16 = bf16(params), round to nearest even (one pass over the flat buffer)."""
+        """params16 = bf16(params), round to nearest even (one pass over the flat buffer) + the transposed copies."""
         if self.params16 is not None:
-            L.call("addhip_to_bf16", L.ptr(self.params), L.ptr(self.params16), 1, self.count, self.count, self.count,
-                   L.current_stream() if stream is None else stream)
+            st = L.current_stream() if stream is None else stream
+            L.call("addhip_to_bf16", L.ptr(self.params), L.ptr(self.params16), 1, self.count, self.count, self.count, st)
+            for net, key in self._transposed:
+                off, (rows, cols) = self.offsets[(net, key)]
+                L.call("addhip_to_bf16_t", self.p(net, key), self.params16t.data_ptr() + 2 * off, rows, cols, cols, rows, st)
 
     def p16(self, net, key):
         off, _ = self.offsets[(net, key)]
         return self.params16.data_ptr() + 2 * off
+
+    def p16t(self, net, key):
+        """W^T [in, out] (leading dimension = out)."""
+        assert (net, key) in self._transposed
+        off, _ = self.offsets[(net, key)]
+        return self.params16t.data_ptr() + 2 * off
 
     def n_elem(self, net, key):
         return math.prod(self.offsets[(net, key)][1])
@@ -333,7 +347,9 @@ class NetRunner:
                     plan.add("addhip_fill_zero", m.g(net.name, f"b{i - 1}"), prev_d)
                 for r0, cnt in self._row_chunks(rows):
                     out = dict(C16=L.ptr(self.dz16[i - 1]) + 2 * r0 * prev_d, ldc16=prev_d) if s16 else {}
-                    g3 = gemm(cnt, prev_d, out_d, L.ptr(dz[i]) + esz * r0 * out_d, out_d, 1, (m.p16 if s16 else m.p)(net.name, f"W{i}"), prev_d, 0,
+                    # dX = dz W: fp32 path reads W[out,in] n-contiguously; the bf16-storage path reads the transposed shadow W^T[in,out]
+                    wb = (m.p16t(net.name, f"W{i}"), out_d, 1) if s16 else (m.p(net.name, f"W{i}"), prev_d, 0)
+                    g3 = gemm(cnt, prev_d, out_d, L.ptr(dz[i]) + esz * r0 * out_d, out_d, 1, wb[0], wb[1], wb[2],
                               None if s16 else L.ptr(self.dz[i - 1]) + 4 * r0 * prev_d, prev_d, L.EPI_MASK, colsum=m.g(net.name, f"b{i - 1}"),
                               **kw, **out, **self.mask_args(i - 1, r0, cnt))
                     plan.hold(g3)

@@ -241,6 +241,9 @@ int addhip_gemm_f32(const addhip_gemm_t* g, void* stream);
 /* dst[r*ld_dst + c] = bf16(src[r*ld_src + c]), round to nearest even (bf16-storage mode: minibatch inputs, head gradients, the weight
  * shadow after an optimiser step); cols and both leading dimensions multiples of 4 */
 int addhip_to_bf16(const float* src, uint16_t* dst, int64_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream);
+/* transposing variant: dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) -- the [in,out] copy of a weight matrix [out,in], which lets the
+ * backward (dX) GEMMs of the bf16-storage mode read the weights k-contiguously like the forward ones */
+int addhip_to_bf16_t(const float* src, uint16_t* dst, int32_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream);
 
 /* out[n] (+)= scale * sum over `slabs` of in[s*slab_stride + n]  (split-K combine, grads) */
 int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count,
