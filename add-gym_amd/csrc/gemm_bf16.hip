@@ -5,11 +5,10 @@
 //
 // Unlike gemm_split.hip (fp32 operands split into bf16 planes on their way into LDS, 16-deep stages) nothing is converted
 // here: 128x128 tile, 4 wavefronts of 64x64 (2x2 accumulators of v_mfma_f32_32x32x16_bf16), 64-deep K stages = 16 MFMAs per
-// wave and barrier, LDS double buffer (2 x 2 x 18 KB -> 2 workgroups per CU), next stage prefetched global -> VGPR.
-// LDS image of an operand tile: [row][64 k] bf16, row stride 144 B (36 dwords: a ds_read_b128 lane group covers all 64 banks).
-// k-contiguous operands arrive as 16-byte chunks and go to LDS unchanged; m/n-contiguous operands (the weight-gradient GEMMs:
-// dW = dz^T x, both operands row-major over the minibatch) are transposed on the way: each thread loads the same 8 rows of
-// two consecutive k and writes 8 packed (k, k+1) dwords.
+// wave and barrier; either an LDS double buffer (2 x 32 KB -> 2 workgroups per CU, the next stage's DMA in flight under this
+// stage's MFMAs) or one 32 KB stage and 3-4 workgroups per CU covering for each other.  The tiles go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4; no staging registers, no ds_write pass), bank-swizzled through the source addresses; operands
+// that are m/n-contiguous in HBM are NOT transposed on the way in: their fragments are read with ds_read_b64_tr_b16.
 //
 // Replaces (in bf16 mode): the torch.nn.Linear forward/backward of PPOModel / ADDModel (ppo_model.py:13-21, add_model.py:12-15).
 #include "common.h"
@@ -21,78 +20,104 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int RS = BK * 2 + 16;         // bytes per LDS row
-constexpr int TILE = 128 * RS;          // bytes per operand tile
+constexpr int TILE = 128 * BK * 2;      // bytes per operand tile in LDS (16 KB, either image)
+constexpr int STAGE = 2 * TILE;         // A tile, B tile
 constexpr int EPI_RUNTIME = -1;
 
-__device__ __forceinline__ unsigned pack_lo(unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); }   // low halves
-__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }  // high halves
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* ltr_t;
+
+__device__ uint4 g_zero_chunk;  // 16 zero bytes: the source of LDS chunks beyond the end of K
+
 // fp32 -> bf16, round to nearest even (no NaN special-casing: the callers' values are finite)
 __device__ __forceinline__ u16 to_bf16(float v) {
   const unsigned u = __float_as_uint(v);
   return (u16)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-// ---- k-contiguous operand P[r*ld + k]: 128 rows x 8 chunks of 8 k = 1024 chunks, 4 per thread
-template <bool GUARD>
-__device__ __forceinline__ void load_kc(uint4* reg, const u16* __restrict__ P, int ld, int r0, int k0, int R, int kend) {
+// ---- operand tiles in LDS.  Both images are filled by LDS-DMA (global_load_lds_dwordx4: each wave-instruction lands
+// 64 x 16 B = 1 KiB at a wave-uniform LDS address, lane-linear), so the bank swizzle sits on the per-lane SOURCE address
+// and the same XOR is applied by the fragment reads.
+//
+// k-contiguous operand P[r*ld + k] (activations, weights, transposed weight shadows):
+//   image [128 rows][64 k], 128-B rows of 8 chunks; chunk c of row r sits at chunk position c ^ ((r >> 1) & 7)
+//   (a ds_read_b128 lane group = 16 rows at one k chunk then covers all 64 banks); one piece = 8 rows.
+// m/n-contiguous operand P[k*ld + r] (the weight-gradient GEMMs dW = dz^T x: both operands row-major over the minibatch):
+//   image [64 k][128 rows], 256-B rows of 16 chunks; chunk ch of k-row kr sits at position ch ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+//   one piece = 4 k-rows.  MFMA fragments (8 consecutive k of one row per lane) come out of it by two ds_read_b64_tr_b16
+//   (each delivers a 4 k x 16 rows block transposed), conflict-free with this XOR.
+__device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int mc_swz(int kr) { return ((kr & 3) << 2) | ((kr >> 2) & 3); }
+
+template <bool KC>
+struct Stager {
+  unsigned off[4];   // byte offset of this lane's 16-byte chunk from the stage's (uniform) source base, pieces 4*wave .. 4*wave+3
+  int kq[4];         // the k (relative to the stage's first k) the chunk starts at (KC) / lies on (MC): tail guard
+  // rows_left = R - r0 (>= 1; a multiple of 8 for MC)
+  __device__ __forceinline__ void init(int wave, int lane, int ld, int rows_left) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = threadIdx.x + 256 * i;
-    const int row = c >> 3, kq = (c & 7) * 8;
-    const int r = min(r0 + row, R - 1), k = k0 + kq;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (!GUARD || k < kend) v = *reinterpret_cast<const uint4*>(P + (size_t)r * ld + k);  // K % 8 == 0: a chunk is in or out as a whole
-    reg[i] = v;
-  }
-}
-__device__ __forceinline__ void store_kc(char* lds, const uint4* reg) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = threadIdx.x + 256 * i;
-    *reinterpret_cast<uint4*>(lds + (c >> 3) * RS + (c & 7) * 16) = reg[i];
-  }
-}
-// ---- m/n-contiguous operand P[k*ld + r]: 32 k-pairs x 16 chunks of 8 rows = 512 tasks, 2 per thread (2 loads each)
-template <bool GUARD>
-__device__ __forceinline__ void load_mc(uint4* reg, const u16* __restrict__ P, int ld, int r0, int k0, int R, int kend) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int t = threadIdx.x + 256 * i;
-    const int kp = t & 31, rq = (t >> 5) * 8;
-    const int r = min(r0 + rq, R - 8), k = k0 + 2 * kp;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (!GUARD || k + j < kend) v = *reinterpret_cast<const uint4*>(P + (size_t)(k + j) * ld + r);
-      reg[2 * i + j] = v;
+    for (int i = 0; i < 4; ++i) {
+      const int piece = 4 * wave + i;
+      if (KC) {
+        const int row = 8 * piece + (lane >> 3), c = (lane & 7) ^ kc_swz(row);
+        off[i] = 2u * ((unsigned)min(row, rows_left - 1) * (unsigned)ld + 8u * c);
+        kq[i] = 8 * c;
+      } else {
+        const int kr = 4 * piece + (lane >> 4), ch = (lane & 15) ^ mc_swz(kr);
+        off[i] = 2u * ((unsigned)kr * (unsigned)ld + (unsigned)min(8 * ch, rows_left - 8));
+        kq[i] = kr;
+      }
     }
   }
-}
-__device__ __forceinline__ void store_mc(char* lds, const uint4* reg) {
+  // src: the operand at (tile's first row, stage's first k); dst: this operand's tile in the stage buffer; kleft = kend - k0
+  template <bool GUARD>
+  __device__ __forceinline__ void issue(const char* src, char* dst, int wave, int kleft) const {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int t = threadIdx.x + 256 * i;
-    const int kp = t & 31, rq = (t >> 5) * 8;
-    const uint4 a = reg[2 * i], b = reg[2 * i + 1];  // rows rq..rq+7 at k and k+1
-    const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-    char* dst = lds + rq * RS + kp * 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      *reinterpret_cast<unsigned*>(dst + (2 * q) * RS) = pack_lo(av[q], bv[q]);
-      *reinterpret_cast<unsigned*>(dst + (2 * q + 1) * RS) = pack_hi(av[q], bv[q]);
+    for (int i = 0; i < 4; ++i) {
+      const char* s = src + off[i];
+      if (GUARD && kq[i] >= kleft) s = reinterpret_cast<const char*>(&g_zero_chunk);  // K % 8 == 0: a chunk is in or out as a whole
+      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(dst + (4 * wave + i) * 1024), 16, 0, 0);
     }
   }
-}
+};
 
-__device__ __forceinline__ bf16x8 frag(const char* lds, int row, int kstep, int h) {
-  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + row * RS + kstep * 32 + h * 16));
-}
+// fragment (rows row0 .. row0+31 of the tile, k 16*ks .. 16*ks+15): lane (li, lh) gets row row0+li, k 16*ks + 8*lh .. +7
+struct FragKC {
+  unsigned base, x;  // row byte offset, lh ^ swizzle
+  __device__ __forceinline__ void init(int w0, int li, int lh) { base = (unsigned)(w0 + li) * 128u; x = (unsigned)(lh ^ kc_swz(li)); }  // w0 % 64 == 0
+  __device__ __forceinline__ bf16x8 get(const char* tile, int a, int ks) const {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + base + a * (32 * 128) + (((2u * ks) ^ x) << 4)));
+  }
+};
+struct FragMC {
+  unsigned addr[2][2];  // [a][j]: this lane's address for the j-th 4-k block of fragment a at ks = 0
+  __device__ __forceinline__ void init(int w0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kr = 8 * (g >> 1) + 4 * j + q;                  // + 16*ks: leaves mc_swz(kr) unchanged
+        const int ch = (w0 + a * 32 + 16 * (g & 1)) / 8 + (p >> 1);
+        addr[a][j] = 256u * kr + 16u * (ch ^ mc_swz(kr)) + 8u * (p & 1);
+      }
+  }
+  __device__ __forceinline__ bf16x8 get(const char* tile, int a, int ks) const {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(tile + addr[a][0] + ks * (16 * 256)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(tile + addr[a][1] + ks * (16 * 256)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  }
+};
+template <bool KC> struct FragSel { typedef FragKC type; };
+template <> struct FragSel<false> { typedef FragMC type; };
 
-template <bool AKC, bool BKC, int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE];
-  constexpr int STAGE = 2 * TILE;
+template <bool AKC, bool BKC, int EPI, bool SB>
+__global__ __launch_bounds__(256, SB ? ((AKC && BKC) ? 4 : 3) : 2) void gemm_bf16_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(1024))) char lds[SB ? 4 * 32 * (64 * 4 + 16) : 2 * STAGE];
 
   // XCD-aware remap (blocks b and b+8 share an XCD): each XCD gets a contiguous run of tiles, N-tile fastest
   const int total = tiles_m * tiles_n;
@@ -109,11 +134,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(addhip_gemm_t g, int til
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   const int nk_full = kend > kbeg ? (kend - kbeg) / BK : 0;
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
   const int li = lane & 31, lh = lane >> 5;
-  const u16* __restrict__ A = reinterpret_cast<const u16*>(g.A);
-  const u16* __restrict__ B = reinterpret_cast<const u16*>(g.B);
+
+  // stage sources: (tile's first row, first k of the split) and the step between stages
+  const char* srcA = reinterpret_cast<const char*>(g.A) + 2 * (AKC ? (size_t)m0 * g.lda + kbeg : (size_t)kbeg * g.lda + m0);
+  const char* srcB = reinterpret_cast<const char*>(g.B) + 2 * (BKC ? (size_t)n0 * g.ldb + kbeg : (size_t)kbeg * g.ldb + n0);
+  const size_t stepA = 2 * (AKC ? (size_t)BK : (size_t)BK * g.lda), stepB = 2 * (BKC ? (size_t)BK : (size_t)BK * g.ldb);
+  Stager<AKC> sa;
+  Stager<BKC> sb;
+  sa.init(wave, lane, g.lda, g.M - m0);
+  sb.init(wave, lane, g.ldb, g.N - n0);
+  typename FragSel<AKC>::type fa_;
+  typename FragSel<BKC>::type fb_;
+  if constexpr (AKC) fa_.init(wm0, li, lh); else fa_.init(wm0, lane);
+  if constexpr (BKC) fb_.init(wn0, li, lh); else fb_.init(wn0, lane);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -123,99 +159,146 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(addhip_gemm_t g, int til
 #pragma unroll
       for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
 
-  uint4 ra[4], rb[4];
-  auto fetch = [&](int kt) {
-    const int k0 = kbeg + kt * BK;
+  auto stage = [&](int kt, int buf) {
+    char* dst = lds + buf * STAGE;
+    const int kleft = kend - (kbeg + kt * BK);
     if (kt < nk_full) {
-      if (AKC) load_kc<false>(ra, A, g.lda, m0, k0, g.M, kend); else load_mc<false>(ra, A, g.lda, m0, k0, g.M, kend);
-      if (BKC) load_kc<false>(rb, B, g.ldb, n0, k0, g.N, kend); else load_mc<false>(rb, B, g.ldb, n0, k0, g.N, kend);
+      sa.template issue<false>(srcA + kt * stepA, dst, wave, kleft);
+      sb.template issue<false>(srcB + kt * stepB, dst + TILE, wave, kleft);
     } else {
-      if (AKC) load_kc<true>(ra, A, g.lda, m0, k0, g.M, kend); else load_mc<true>(ra, A, g.lda, m0, k0, g.M, kend);
-      if (BKC) load_kc<true>(rb, B, g.ldb, n0, k0, g.N, kend); else load_mc<true>(rb, B, g.ldb, n0, k0, g.N, kend);
+      sa.template issue<true>(srcA + kt * stepA, dst, wave, kleft);
+      sb.template issue<true>(srcB + kt * stepB, dst + TILE, wave, kleft);
     }
   };
-  auto stash = [&](int buf) {
-    char* a_dst = lds + buf * STAGE;
-    if (AKC) store_kc(a_dst, ra); else store_mc(a_dst, ra);
-    if (BKC) store_kc(a_dst + TILE, rb); else store_mc(a_dst + TILE, rb);
-  };
-  if (nk > 0) {
-    fetch(0);
-    stash(0);
-  }
-  __syncthreads();
+  // Double-buffered (!SB): one barrier per 64-deep stage.  Its vmcnt(0) retires this wave's share of stage kt (issued one whole
+  // compute phase earlier), the barrier itself makes every wave's share visible and proves stage kt-1's buffer is no longer
+  // being read, so the DMA of stage kt+1 into that buffer is issued right behind it and stays in flight under the 16 MFMAs
+  // of stage kt.  Single-buffered (SB): issue, wait + barrier, compute, barrier; the CU's other workgroups fill the waits.
+  if (!SB && nk > 0) stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+    const int cur = SB ? 0 : (kt & 1);
+    if (SB) {
+      if (kt > 0) __syncthreads();
+      stage(kt, 0);
+    }
+    __syncthreads();
+    if (!SB && kt + 1 < nk) stage(kt + 1, cur ^ 1);
     const char* a_cur = lds + cur * STAGE;
     const char* b_cur = a_cur + TILE;
-    const bool more = kt + 1 < nk;
-    if (more) fetch(kt + 1);
+    // (the compiler sinks each k-step's fragment reads to just behind the issue of the MFMAs that consume the previous ones)
+    bf16x8 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) fa[0][a] = fa_.get(a_cur, a, 0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) fb[0][b] = fb_.get(b_cur, b, 0);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 fa[2], fb[2];
+      if (ks + 1 < BK / 16) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fa[a] = frag(a_cur, wm0 + a * 32 + li, ks, lh);
+        for (int a = 0; a < 2; ++a) fa[(ks + 1) & 1][a] = fa_.get(a_cur, a, ks + 1);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) fb[b] = frag(b_cur, wn0 + b * 32 + li, ks, lh);
+        for (int b = 0; b < 2; ++b) fb[(ks + 1) & 1][b] = fb_.get(b_cur, b, ks + 1);
+      }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
     }
-    if (more) stash(cur ^ 1);
-    __syncthreads();
   }
 
-  // epilogue: lane owns column n0+wn0+b*32+li; register x is row (x&3)+8*(x>>2)+4*lh of the 32x32 tile
+  // epilogue.  In the accumulators a lane owns ONE column (n0+wn0+b*32+li) and register x is row (x&3)+8*(x>>2)+4*lh of the
+  // 32x32 tile: bias, ReLU, mask, sign bits and the bias-gradient column sums are done in that layout, then each 32-row
+  // half of the wave's 64x64 block goes through a wave-private LDS buffer and leaves as 16-byte stores along the rows
+  // (2-byte and 4-byte stores straight from the accumulators cost 4-8x the store instructions, which is what a
+  // short-K launch then spends its time on).
   const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
   float* C = g.C ? g.C + (size_t)blockIdx.z * (size_t)g.M * g.ldc : nullptr;
   u16* C16 = reinterpret_cast<u16*>(g.C16);
+  constexpr int ERS = 64 * 4 + 16;  // bytes per staged row: 64 fp32 + one 16-byte pad
+  __syncthreads();                  // every wave is done with the last stage
+  char* ebuf = lds + wave * (32 * ERS);
+  const bool c_vec = C && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (g.ldc & 3) == 0;
+  const bool c16_vec = C16 && (reinterpret_cast<uintptr_t>(C16) & 15) == 0 && (g.ldc16 & 7) == 0;
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int col = n0 + wn0 + b * 32 + li;
-    const bool col_ok = col < g.N;
-    const float bias = (col_ok && (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU)) ? g.bias[col] : 0.f;
+  for (int a = 0; a < 2; ++a) {
+    const int rtile = m0 + wm0 + a * 32;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int rbase = m0 + wm0 + a * 32 + 4 * lh;
-      float mk[16];
+    for (int b = 0; b < 2; ++b) {
+      const int cgroup = n0 + wn0 + b * 32, col = cgroup + li;
+      const bool col_ok = col < g.N;
+      const float bias = (col_ok && (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU)) ? g.bias[col] : 0.f;
+      // sign-bit word of tile row `lane` (lanes 0..31), fetched once and handed out by readlane
+      unsigned mword = 0u;
+      if (epi == ADDHIP_EPI_MASK && g.mask_bits && lane < 32 && cgroup < g.N && rtile + lane < g.M)
+        mword = g.mask_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)];
+      unsigned rword = 0u;  // lanes 0..31: the ReLU sign-bit word of tile row `lane`
       float cs = 0.f;
-      const int cgroup = n0 + wn0 + b * 32;
-      if (epi == ADDHIP_EPI_MASK) {
-        if (g.mask_bits) {
-#pragma unroll
-          for (int x = 0; x < 16; ++x) {
-            const int row = rbase + (x & 3) + 8 * (x >> 2);
-            const unsigned wbits = (cgroup < g.N && row < g.M) ? g.mask_bits[(size_t)row * g.ldbits + (cgroup >> 5)] : 0u;
-            mk[x] = ((wbits >> li) & 1u) ? 1.f : 0.f;
-          }
-        } else {
-#pragma unroll
-          for (int x = 0; x < 16; ++x) {
-            const int row = rbase + (x & 3) + 8 * (x >> 2);
-            mk[x] = (col_ok && row < g.M) ? g.mask[(size_t)row * g.ldmask + col] : 0.f;
-          }
-        }
-      }
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
-        const int row = rbase + (x & 3) + 8 * (x >> 2);
+        const int r0 = (x & 3) + 8 * (x >> 2), rloc = r0 + 4 * lh, row = rtile + rloc;
+        const bool ok = col_ok && row < g.M;
         float v = g.alpha * acc[a][b][x] + bias;
         if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-        if (epi == ADDHIP_EPI_MASK) v = mk[x] > 0.f ? v : 0.f;
-        if (col_ok && row < g.M) {
-          if (C) C[(size_t)row * g.ldc + col] = v;
-          if (C16) C16[(size_t)row * g.ldc16 + col] = to_bf16(v);
-          if (epi == ADDHIP_EPI_MASK) cs += v;
+        if (epi == ADDHIP_EPI_MASK) {
+          if (g.mask_bits) {
+            const unsigned w0 = __builtin_amdgcn_readlane(mword, r0), w1 = __builtin_amdgcn_readlane(mword, r0 + 4);
+            v = (((lh ? w1 : w0) >> li) & 1u) ? v : 0.f;
+          } else {
+            v = (ok && g.mask[(size_t)row * g.ldmask + col] > 0.f) ? v : 0.f;
+          }
+          if (ok) cs += v;
         }
         if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {
-          const unsigned long long pos = __ballot(col_ok && row < g.M && v > 0.f);
-          if (li == 0 && row < g.M && cgroup < g.N) g.relu_bits[(size_t)row * g.ldbits + (cgroup >> 5)] = lh ? (unsigned)(pos >> 32) : (unsigned)pos;
+          const unsigned long long pos = __ballot(ok && v > 0.f);
+          rword = lane == r0 ? (unsigned)pos : lane == r0 + 4 ? (unsigned)(pos >> 32) : rword;
         }
+        *reinterpret_cast<float*>(ebuf + rloc * ERS + (b * 32 + li) * 4) = v;
       }
+      if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits && lane < 32 && cgroup < g.N && rtile + lane < g.M)
+        g.relu_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)] = rword;
       if (epi == ADDHIP_EPI_MASK && g.colsum) {
         cs += __shfl_xor(cs, 32, 64);
         if (lh == 0 && col_ok) atomicAdd(&g.colsum[col], cs);
+      }
+    }
+    if (C) {  // 16 lanes x 4 columns per row, 4 rows per instruction
+      const int c4 = (lane & 15) * 4, col = n0 + wn0 + c4;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rloc = (lane >> 4) + 4 * i, row = rtile + rloc;
+        const float4 v = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c4 * 4);
+        if (row < g.M) {
+          float* dst = C + (size_t)row * g.ldc + col;
+          if (c_vec && col + 3 < g.N) {
+            *reinterpret_cast<float4*>(dst) = v;
+          } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (col + j < g.N) dst[j] = e[j];
+          }
+        }
+      }
+    }
+    if (C16) {  // 8 lanes x 8 columns per row, 8 rows per instruction
+      const int c8 = (lane & 7) * 8, col = n0 + wn0 + c8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rloc = (lane >> 3) + 8 * i, row = rtile + rloc;
+        const float4 lo = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4);
+        const float4 hi = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4 + 16);
+        if (row < g.M) {
+          u16* dst = C16 + (size_t)row * g.ldc16 + col;
+          const u16 e[8] = {to_bf16(lo.x), to_bf16(lo.y), to_bf16(lo.z), to_bf16(lo.w), to_bf16(hi.x), to_bf16(hi.y), to_bf16(hi.z), to_bf16(hi.w)};
+          if (c16_vec && col + 7 < g.N) {
+            *reinterpret_cast<uint4*>(dst) = make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
+                                                         e[6] | ((unsigned)e[7] << 16));
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (col + j < g.N) dst[j] = e[j];
+          }
+        }
       }
     }
   }
@@ -267,7 +350,15 @@ int gemm_bf16_dispatch(const addhip_gemm_t& g, hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int split = g.split_k > 1 ? g.split_k : 1;
   dim3 grid(tiles_m * tiles_n, 1, split), block(256);
-#define ADDHIP_LAUNCH(AK, BKc, EPI) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKc, EPI>), grid, block, 0, st, g, tiles_m, tiles_n)
+  // single LDS stage x 4 (3 with a transposed operand) workgroups per CU when the launch has the workgroups to fill that,
+  // double-buffered stages x 2 workgroups per CU otherwise (measured: 1024-tile launches 7-17 % faster single-buffered,
+  // 512-workgroup launches 3-5 % faster double-buffered)
+  const bool single = (long long)tiles_m * tiles_n * split >= 768;
+#define ADDHIP_LAUNCH(AK, BKc, EPI)                                                                          \
+  do {                                                                                                       \
+    if (single) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKc, EPI, true>), grid, block, 0, st, g, tiles_m, tiles_n); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKc, EPI, false>), grid, block, 0, st, g, tiles_m, tiles_n);       \
+  } while (0)
   if (g.a_kcontig && g.b_kcontig) {
     if (g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_BIAS_RELU);
     else if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_MASK);
