@@ -65,7 +65,7 @@ class GatherT(C.Structure):
                 ("obs_std", f32p), ("action", f32p), ("a_mean", f32p), ("a_std", f32p), ("a_logp", f32p), ("adv", f32p), ("tar_val", f32p),
                 ("rand_mask", f32p), ("disc_obs", f32p), ("disc_demo", f32p), ("disc_stride", C.c_int32), ("disc_dim", C.c_int32),
                 ("mean_abs", f32p), ("min_diff", C.c_float), ("norm_obs", f32p), ("norm_action", f32p), ("o_logp", f32p), ("o_adv", f32p),
-                ("o_tar_val", f32p), ("o_mask", f32p), ("norm_diff", f32p)]
+                ("o_tar_val", f32p), ("o_mask", f32p), ("norm_diff", f32p), ("norm_obs16", f32p), ("norm_diff16", f32p)]
 
 
 class RigidModelT(C.Structure):
@@ -92,6 +92,7 @@ SIGNATURES = {
     "addhip_gemm_f32": [P(GemmT), vp],
     "addhip_to_bf16": [vp, vp, i64, i32, i32, i32, vp],
     "addhip_to_bf16_t": [vp, vp, i32, i32, i32, i32, vp],
+    "addhip_shadow_refresh": [vp, vp, vp, i64, vp, vp, vp, i32, vp],
     "addhip_slab_reduce": [vp, i32, i64, vp, i64, f32, i32, vp],
     "addhip_col_sum": [vp, i32, i32, i32, vp, f32, i32, vp],
     "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp],

@@ -359,6 +359,31 @@ __global__ void slab_reduce_kernel(const float* in, int slabs, long long stride,
     out[i] = accumulate ? out[i] + s : s;
   }
 }
+// the same, four elements per thread (count, stride % 4 == 0, 16-byte aligned buffers); sums in the same slab order
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(const float4* in, int slabs, long long stride4, float4* out, long long count4, float scale,
+                                                           int accumulate) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (; i < count4; i += step) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= slabs; k += 4) {
+      const float4 a = in[k * stride4 + i], b = in[(k + 1) * stride4 + i], c = in[(k + 2) * stride4 + i], d = in[(k + 3) * stride4 + i];
+      s.x = ((s.x + a.x) + b.x) + c.x + d.x; s.y = ((s.y + a.y) + b.y) + c.y + d.y;
+      s.z = ((s.z + a.z) + b.z) + c.z + d.z; s.w = ((s.w + a.w) + b.w) + c.w + d.w;
+    }
+    for (; k < slabs; ++k) {
+      const float4 a = in[k * stride4 + i];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
+    if (accumulate) {
+      const float4 o = out[i];
+      s.x = o.x + s.x; s.y = o.y + s.y; s.z = o.z + s.z; s.w = o.w + s.w;
+    }
+    out[i] = s;
+  }
+}
 
 // column sums of a row-major [M,N] matrix: each block reduces a 64-column strip over a slice of rows
 // into an LDS tile, then one atomicAdd per column per block (out must be pre-scaled/zeroed by the caller
@@ -441,6 +466,13 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
 extern "C" int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count, float scale,
                                   int32_t accumulate, void* stream) {
   ADDHIP_REQUIRE(in && out && slabs > 0 && count > 0, "slab_reduce: bad arguments");
+  if (count % 4 == 0 && slab_stride % 4 == 0 && aligned16(in) && aligned16(out)) {
+    long long b4 = (count / 4 + 255) / 256;
+    if (b4 > 2048) b4 = 2048;
+    hipLaunchKernelGGL(slab_reduce4_kernel, dim3((unsigned)b4), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(in), slabs,
+                       (long long)slab_stride / 4, reinterpret_cast<float4*>(out), (long long)count / 4, scale, accumulate);
+    return addhip::check_launch("slab_reduce4_kernel");
+  }
   int blocks = (int)((count + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, slabs, (long long)slab_stride, out,

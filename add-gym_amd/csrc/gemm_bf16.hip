@@ -335,6 +335,48 @@ __global__ __launch_bounds__(256) void to_bf16_t_kernel(const float* __restrict_
   }
 }
 
+// flat convert + the transposed copies of up to ADDHIP_SHADOW_MAX_MATS matrices, one launch: blocks [0, flat_blocks) stride over the
+// flat buffer, the rest are 32x32 transposition tiles, matrix by matrix (tile_end = running block count)
+struct ShadowMats {
+  long long offset[ADDHIP_SHADOW_MAX_MATS];
+  int rows[ADDHIP_SHADOW_MAX_MATS], cols[ADDHIP_SHADOW_MAX_MATS], tile_end[ADDHIP_SHADOW_MAX_MATS];
+  int n;
+};
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __restrict__ params, u16* __restrict__ flat16, u16* __restrict__ trans16,
+                                                             long long count, int flat_blocks, ShadowMats mats) {
+  __shared__ float tile[32][33];
+  if ((int)blockIdx.x < flat_blocks) {
+    const long long n4 = count >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)flat_blocks * 256) {
+      const float4 v = reinterpret_cast<const float4*>(params)[i];
+      reinterpret_cast<uint2*>(flat16)[i] =
+          make_uint2((unsigned)to_bf16(v.x) | ((unsigned)to_bf16(v.y) << 16), (unsigned)to_bf16(v.z) | ((unsigned)to_bf16(v.w) << 16));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) flat16[(n4 << 2) + threadIdx.x] = to_bf16(params[(n4 << 2) + threadIdx.x]);
+    return;
+  }
+  int t = blockIdx.x - flat_blocks, mi = 0;
+  while (mi + 1 < mats.n && t >= mats.tile_end[mi]) ++mi;
+  if (mi > 0) t -= mats.tile_end[mi - 1];
+  const int rows = mats.rows[mi], cols = mats.cols[mi];
+  const int tcols = (cols + 31) / 32;
+  const int r0 = (t / tcols) * 32, c0 = (t % tcols) * 32;
+  const float* src = params + mats.offset[mi];
+  u16* dst = trans16 + mats.offset[mi];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + ty + 8 * j, c = c0 + tx;
+    tile[ty + 8 * j][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, r = r0 + tx;
+    if (r < rows && c < cols) dst[(size_t)c * rows + r] = to_bf16(tile[tx][ty + 8 * j]);
+  }
+}
+
 }  // namespace
 
 namespace addhip {
@@ -392,4 +434,29 @@ extern "C" int addhip_to_bf16_t(const float* src, uint16_t* dst, int32_t rows, i
   ADDHIP_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "to_bf16_t: bad arguments");
   hipLaunchKernelGGL(to_bf16_t_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, ld_src, ld_dst);
   return addhip::check_launch("to_bf16_t_kernel");
+}
+
+extern "C" int addhip_shadow_refresh(const float* params, uint16_t* flat16, uint16_t* trans16, int64_t count, const int64_t* offset, const int32_t* rows,
+                                     const int32_t* cols, int32_t n_mats, void* stream) {
+  ADDHIP_REQUIRE(params && flat16 && count > 0 && n_mats >= 0 && n_mats <= ADDHIP_SHADOW_MAX_MATS, "shadow_refresh: bad arguments");
+  ADDHIP_REQUIRE(n_mats == 0 || (trans16 && offset && rows && cols), "shadow_refresh: matrix table missing");
+  ADDHIP_REQUIRE(aligned16(params) && (reinterpret_cast<uintptr_t>(flat16) & 7u) == 0, "shadow_refresh: misaligned buffers");
+  ShadowMats mats;
+  mats.n = n_mats > 0 ? n_mats : 1;
+  int tiles = 0;
+  for (int i = 0; i < ADDHIP_SHADOW_MAX_MATS; ++i) {
+    const bool on = i < n_mats;
+    ADDHIP_REQUIRE(!on || (offset[i] >= 0 && rows[i] > 0 && cols[i] > 0 && offset[i] + (int64_t)rows[i] * cols[i] <= count),
+                   "shadow_refresh: a matrix lies outside the flat buffer");
+    mats.offset[i] = on ? offset[i] : 0;
+    mats.rows[i] = on ? rows[i] : 0;
+    mats.cols[i] = on ? cols[i] : 0;
+    if (on) tiles += ((rows[i] + 31) / 32) * ((cols[i] + 31) / 32);
+    mats.tile_end[i] = tiles;
+  }
+  long long fb = (count / 4 + 255) / 256;
+  const int flat_blocks = (int)(fb < 1 ? 1 : fb > 2048 ? 2048 : fb);
+  hipLaunchKernelGGL(shadow_refresh_kernel, dim3((unsigned)(flat_blocks + tiles)), dim3(256), 0, (hipStream_t)stream, params, flat16, trans16,
+                     (long long)count, flat_blocks, mats);
+  return addhip::check_launch("shadow_refresh_kernel");
 }

@@ -310,18 +310,27 @@ __global__ void diffnorm_merge_kernel(float* mean_abs, long long* count, float* 
 }
 
 // ------------------------------------------------------------------ minibatch gather
+// fp32 -> bf16, round to nearest even (finite inputs), as addhip_to_bf16
+__device__ __forceinline__ unsigned short bf16_rne(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
 __global__ __launch_bounds__(256) void gather_kernel(addhip_gather_t g) {
   const int lane = threadIdx.x & 63;
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < g.count; r += gridDim.x * 4) {
     const long long src = g.idx[r];
-    for (int c = lane; c < g.obs_stride; c += 64)
-      g.norm_obs[(size_t)r * g.obs_stride + c] = c < g.obs_dim ? (g.obs[src * g.obs_stride + c] - g.obs_mean[c]) / g.obs_std[c] : 0.f;
+    for (int c = lane; c < g.obs_stride; c += 64) {
+      const float v = c < g.obs_dim ? (g.obs[src * g.obs_stride + c] - g.obs_mean[c]) / g.obs_std[c] : 0.f;
+      g.norm_obs[(size_t)r * g.obs_stride + c] = v;
+      if (g.norm_obs16) g.norm_obs16[(size_t)r * g.obs_stride + c] = bf16_rne(v);
+    }
     if (lane < 32)
       g.norm_action[(size_t)r * 32 + lane] = lane < ADDHIP_NUM_DOF ? (g.action[src * 32 + lane] - g.a_mean[lane]) / g.a_std[lane] : 0.f;
     for (int c = lane; c < g.disc_stride; c += 64) {
       float v = 0.f;
       if (c < g.disc_dim) v = (g.disc_demo[src * g.disc_stride + c] - g.disc_obs[src * g.disc_stride + c]) / fmaxf(g.mean_abs[c], g.min_diff);
       g.norm_diff[(size_t)r * g.disc_stride + c] = v;
+      if (g.norm_diff16) g.norm_diff16[(size_t)r * g.disc_stride + c] = bf16_rne(v);
     }
     if (lane == 0) {
       g.o_logp[r] = g.a_logp[src];

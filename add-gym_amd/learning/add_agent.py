@@ -228,7 +228,8 @@ class ADDAgent:
             self._eval_disc = NetRunner(m, m.disc, self._eval_rows, dev, None, self._prec_small)
         else:
             self._roll_actor, self._eval_critic, self._eval_disc = self._run_actor, self._run_critic, self._run_disc
-        self._side_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        # (the discriminator's section is the step's longest chain: its stream gets the higher priority)
+        self._side_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)]
         OS, DS = self._task.obs_stride, self._task.disc_stride
         hd = m.disc.hidden
         self._W = dict(mean=z(rows, 32), d_mean=z(rows, 32), noise=z(N, L.NUM_DOF), explore_u=z(N), u=z(3, N), logits=z(rows), nv=z(1),
@@ -299,6 +300,13 @@ class ADDAgent:
         self._update_marks.append(("critic", len(p.calls)))
         # discriminator: Mb agent/demo differences + one zero-difference row (row Mb of norm_diff stays 0)
         Md = Mb + 1
+        # L2 terms (add_agent.py:161-164, 181-186): logit reg on the head weights, weight decay on all disc weights.  They go into the
+        # freshly zeroed gradient buffer FIRST (the weight gradients are added to them by the split-K combines below), where they run
+        # beside the other nets' GEMMs instead of alone at the end of the step's longest chain.
+        wd = self._disc_weight_decay
+        p.add("addhip_l2_grad", m.p("disc", "W0"), m.g("disc", "W0"), m.n_elem("disc", "W0"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
+        p.add("addhip_l2_grad", m.p("disc", "W1"), m.g("disc", "W1"), m.n_elem("disc", "W1"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
+        p.add("addhip_l2_grad", m.p("disc", "Wh"), m.g("disc", "Wh"), m.n_elem("disc", "Wh"), 2.0 * ls_d * (wd + self._disc_logit_reg), L.ptr(W["stats"]) + 4 * 25)
         nd = L.ptr(W["norm_diff"])
         nd16 = L.ptr(W["norm_diff16"]) if s16 else None
         rd.forward(p, nd, Md, sign_bits=True, x16_ptr=nd16)
@@ -327,7 +335,7 @@ class ADDAgent:
             self._gemm(p, Mb, d2, d1, L.ptr(W["e1_16"]), d1, 1, m.p16("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **k16, **rd.mask_args(1, 0, Mb))
             p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
             rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1_16"]), d1, L.ptr(W["G16"]), DS, Mb), 1: (L.ptr(W["a2_16"]), d2, L.ptr(W["e1_16"]), d1, Mb)},
-                        grads_zeroed=True, top_bias_done=True, x16_ptr=nd16)
+                        grads_zeroed=True, top_bias_done=True, x16_ptr=nd16, accumulate_dw=True)
         else:
             self._gemm(p, Mb, d1, d2, L.ptr(W["a2"]), d2, 1, m.p("disc", "W1"), d1, 0, L.ptr(W["a1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
             self._gemm(p, Mb, DS, d1, L.ptr(W["a1"]), d1, 1, m.p("disc", "W0"), DS, 0, L.ptr(W["g"]), DS)
@@ -337,12 +345,7 @@ class ADDAgent:
             self._gemm(p, Mb, d2, d1, L.ptr(W["e1"]), d1, 1, m.p("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **rd.mask_args(1, 0, Mb))
             p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
             rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1"]), d1, L.ptr(W["G"]), DS, Mb), 1: (L.ptr(W["a2"]), d2, L.ptr(W["e1"]), d1, Mb)},
-                        grads_zeroed=True, top_bias_done=True)
-        # L2 terms (add_agent.py:161-164, 181-186): logit reg on the head weights, weight decay on all disc weights
-        wd = self._disc_weight_decay
-        p.add("addhip_l2_grad", m.p("disc", "W0"), m.g("disc", "W0"), m.n_elem("disc", "W0"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
-        p.add("addhip_l2_grad", m.p("disc", "W1"), m.g("disc", "W1"), m.n_elem("disc", "W1"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
-        p.add("addhip_l2_grad", m.p("disc", "Wh"), m.g("disc", "Wh"), m.n_elem("disc", "Wh"), 2.0 * ls_d * (wd + self._disc_logit_reg), L.ptr(W["stats"]) + 4 * 25)
+                        grads_zeroed=True, top_bias_done=True, accumulate_dw=True)
         self._update_marks.append(("disc", len(p.calls)))
         # Launch / exchange schedule of one optimiser step: (stream, first call, last call, gradient range to all-reduce after it).
         # Actor and critic hand over everything but their first layer as soon as it is final; the collectives are issued
@@ -377,7 +380,8 @@ class ADDAgent:
         self._gather_c = L.GatherT(L.ptr(W["perm_idx"]), Mb, L.ptr(B["obs"]), OS, tk.obs_dim, L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(B["action"]),
                                    L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), L.ptr(B["a_logp"]), L.ptr(B["adv"]), L.ptr(B["tar_val"]), L.ptr(B["rand_mask"]),
                                    L.ptr(B["disc_obs"]), L.ptr(B["disc_demo"]), DS, tk.disc_dim, L.ptr(Nm["d_abs"]), 1e-4, L.ptr(W["norm_obs"]),
-                                   L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_tar"]), L.ptr(W["mb_mask"]), L.ptr(W["norm_diff"]))
+                                   L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_tar"]), L.ptr(W["mb_mask"]), L.ptr(W["norm_diff"]),
+                                   L.ptr(W["norm_obs16"]) if s16 else None, L.ptr(W["norm_diff16"]) if s16 else None)
 
     # ------------------------------------------------------------------ public surface
     def get_num_envs(self):
@@ -596,17 +600,21 @@ class ADDAgent:
             randperm = lambda: torch.randperm(total, device=self._device)
         if not hasattr(self, "_perm") or self._perm is None:
             self._perm, self._perm_head = randperm(), 0
+        sample_count = min(self._total_samples, total)
         if self._perm_head + n <= total:
             idx = self._perm[self._perm_head:self._perm_head + n]
             self._perm_head += n
+            if sample_count == total:  # the usual case (full buffer, slice inside one permutation): the gather reads the slice in place
+                self._gather_c.idx = idx.data_ptr()
+                return
         else:
             idx0 = self._perm[self._perm_head:]
             rem = n - (total - self._perm_head)
             self._perm = randperm()
             idx = torch.cat([idx0, self._perm[:rem]])
             self._perm_head = rem
-        sample_count = min(self._total_samples, total)
         self._W["perm_idx"].copy_(torch.remainder(idx, sample_count))
+        self._gather_c.idx = L.ptr(self._W["perm_idx"])
 
     def _update_model(self):
         """ppo_agent.py:171-192."""
@@ -644,10 +652,7 @@ class ADDAgent:
         main = torch.cuda.current_stream()
         streams = [main] + self._side_streams
         L.call("addhip_fill_zero", L.ptr(m.grads), m.count, main.cuda_stream)  # MPOptimizer.step's zero_grad (mp_optimizer.py:14-16)
-        if self._storage16:  # bf16 copies of the gathered minibatch rows, before the three sections fork
-            W, tk = self._W, self._task
-            L.call("addhip_to_bf16", L.ptr(W["norm_obs"]), L.ptr(W["norm_obs16"]), self.Mb, tk.obs_stride, tk.obs_stride, tk.obs_stride, main.cuda_stream)
-            L.call("addhip_to_bf16", L.ptr(W["norm_diff"]), L.ptr(W["norm_diff16"]), self.Mb + 1, tk.disc_stride, tk.disc_stride, tk.disc_stride, main.cuda_stream)
+        # (bf16-storage mode: the gather wrote the bf16 copies of the minibatch rows too; row Mb of norm_diff16 stays 0 from its allocation)
         fork = torch.cuda.Event()
         fork.record(main)
         # stream-ordered asynchronous collectives are an nccl (RCCL) property; any other backend (gloo in rehearsals) gets one

@@ -109,16 +109,18 @@ class Model:
         self.params16 = torch.zeros(self.count, dtype=torch.bfloat16, device=self.device)
         self.params16t = torch.zeros(self.count, dtype=torch.bfloat16, device=self.device)
         self._transposed = [(net.name, f"W{i}") for net in self.nets for i in range(len(net.hidden)) if i > 0 or net is self.disc]
+        import ctypes as C
+        n = len(self._transposed)
+        offs, dims = zip(*(self.offsets[k] for k in self._transposed))
+        self._shadow_table = ((C.c_int64 * n)(*offs), (C.c_int32 * n)(*(d[0] for d in dims)), (C.c_int32 * n)(*(d[1] for d in dims)), n)
         self.refresh_shadow()
 
     def refresh_shadow(self, stream=None):
-        """params16 = bf16(params), round to nearest even (one pass over the flat buffer) + the transposed copies."""
+        """params16 = bf16(params), round to nearest even, + the transposed copies: one launch."""
         if self.params16 is not None:
             st = L.current_stream() if stream is None else stream
-            L.call("addhip_to_bf16", L.ptr(self.params), L.ptr(self.params16), 1, self.count, self.count, self.count, st)
-            for net, key in self._transposed:
-                off, (rows, cols) = self.offsets[(net, key)]
-                L.call("addhip_to_bf16_t", self.p(net, key), self.params16t.data_ptr() + 2 * off, rows, cols, cols, rows, st)
+            offs, rows, cols, n = self._shadow_table
+            L.call("addhip_shadow_refresh", L.ptr(self.params), L.ptr(self.params16), L.ptr(self.params16t), self.count, offs, rows, cols, n, st)
 
     def p16(self, net, key):
         off, _ = self.offsets[(net, key)]
@@ -302,12 +304,13 @@ class NetRunner:
                 plan.add("addhip_gemm_f32", g)
             prev, ld, k = L.ptr(self.h[i]), h, h
 
-    def backward(self, plan, x_ptr, rows, extra_dw=None, grads_zeroed=False, top_bias_done=False, x16_ptr=None):
+    def backward(self, plan, x_ptr, rows, extra_dw=None, grads_zeroed=False, top_bias_done=False, x16_ptr=None, accumulate_dw=False):
         """dz[-1] must hold d loss / d (pre-activation of the last hidden layer).  extra_dw: {layer: (A_ptr, lda, B_ptr, ldb)}
         second product accumulated into dW of that layer (the gradient-penalty terms).  grads_zeroed: the caller cleared the
         whole gradient buffer at the start of the step (no per-bias memsets here); top_bias_done: the kernel that produced
         dz[-1] also accumulated the top layer's bias gradient.  storage16 runners: x16_ptr = bf16 copy of the input rows, the
-        extra_dw operands are bf16 too, and the fp32 top gradient is rounded to bf16 once at the start."""
+        extra_dw operands are bf16 too, and the fp32 top gradient is rounded to bf16 once at the start.  accumulate_dw: the
+        weight gradients are ADDED to what the gradient buffer holds (L2 terms written there earlier in the step)."""
         net, m = self.net, self.m
         n = len(net.hidden)
         s16 = self.storage16
@@ -334,7 +337,7 @@ class NetRunner:
                 plan.hold(g2)
                 plan.add("addhip_gemm_f32", g2)
                 total = 2 * s
-            plan.add("addhip_slab_reduce", L.ptr(self.slabs), total, slab, m.g(net.name, f"W{i}"), slab, 1.0, 0)
+            plan.add("addhip_slab_reduce", L.ptr(self.slabs), total, slab, m.g(net.name, f"W{i}"), slab, 1.0, int(accumulate_dw))
             if i == 1:
                 # every gradient of this net except W0 / b0 is final here (b1 came with the dX GEMM of layer 2, the head's
                 # with the loss kernels): an early bucket for the data-parallel exchange

@@ -244,6 +244,12 @@ int addhip_to_bf16(const float* src, uint16_t* dst, int64_t rows, int32_t cols, 
 /* transposing variant: dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) -- the [in,out] copy of a weight matrix [out,in], which lets the
  * backward (dX) GEMMs of the bf16-storage mode read the weights k-contiguously like the forward ones */
 int addhip_to_bf16_t(const float* src, uint16_t* dst, int32_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream);
+/* The whole bf16 weight shadow after an optimiser step in ONE launch: flat16[i] = bf16(params[i]) for i < count, and for each of the
+ * n_mats (<= ADDHIP_SHADOW_MAX_MATS) row-major matrices [rows, cols] at params + offset the transposed copy [cols, rows] at
+ * trans16 + offset (offset, rows, cols: host arrays) */
+#define ADDHIP_SHADOW_MAX_MATS 8
+int addhip_shadow_refresh(const float* params, uint16_t* flat16, uint16_t* trans16, int64_t count, const int64_t* offset, const int32_t* rows,
+                          const int32_t* cols, int32_t n_mats, void* stream);
 
 /* out[n] (+)= scale * sum over `slabs` of in[s*slab_stride + n]  (split-K combine, grads) */
 int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count,
@@ -322,6 +328,7 @@ typedef struct {
   const float* disc_obs; const float* disc_demo; int32_t disc_stride; int32_t disc_dim;
   const float* mean_abs; float min_diff;
   float* norm_obs; float* norm_action; float* o_logp; float* o_adv; float* o_tar_val; float* o_mask; float* norm_diff;
+  uint16_t* norm_obs16; uint16_t* norm_diff16; /* optional (NULL = none): bf16 copies of norm_obs / norm_diff, same strides (bf16-storage mode) */
 } addhip_gather_t;
 int addhip_gather_minibatch(const addhip_gather_t* g, void* stream);
 

@@ -83,6 +83,9 @@ def minibatch_loss_gradients_and_adamw(precision="fp32"):
     W["mb_mask"].copy_(T(mb["rand_action_mask"]))
     W["norm_diff"].zero_()
     W["norm_diff"][:M, :114] = T(mb["norm_diff"])
+    if "norm_obs16" in W:  # bf16-storage mode: the gather kernel writes these copies (round to nearest even, as the tensor cast does)
+        W["norm_obs16"].copy_(W["norm_obs"])
+        W["norm_diff16"].copy_(W["norm_diff"][:W["norm_diff16"].shape[0]])
     model = OL.Model(params)
     opt = OL.AdamW(model, 1e-4)
     st = L.current_stream()

@@ -308,3 +308,31 @@ def test_to_bf16_rounds_to_nearest_even():
     L.call("addhip_to_bf16", L.ptr(src), L.ptr(dst), x.shape[0], 4, 8, 12, L.current_stream())
     torch.cuda.synchronize()
     assert torch.equal(dst[:, :4].cpu(), torch.tensor(x).to(torch.bfloat16)) and bool((dst[:, 4:] == 7.0).all())
+
+
+def test_shadow_refresh_flat_and_transposed_in_one_launch():
+    """addhip_shadow_refresh == addhip_to_bf16 over the flat buffer + addhip_to_bf16_t per listed matrix (ragged 32x32 tiles included)."""
+    import ctypes as C
+    import torch
+    import add_gym_amd._lib as L
+
+    torch.manual_seed(3)
+    mats = [(0, 1024, 272), (1024 * 272 + 1024, 512, 1024), (1024 * 272 + 1024 + 512 * 1024 + 512, 40, 100)]
+    count = mats[-1][0] + 40 * 100 + 7
+    params = torch.randn(count, device="cuda")
+    flat16 = torch.full((count,), 9.0, device="cuda", dtype=torch.bfloat16)
+    trans16 = torch.full((count,), 9.0, device="cuda", dtype=torch.bfloat16)
+    n = len(mats)
+    L.call("addhip_shadow_refresh", L.ptr(params), L.ptr(flat16), L.ptr(trans16), count, (C.c_int64 * n)(*(m[0] for m in mats)),
+           (C.c_int32 * n)(*(m[1] for m in mats)), (C.c_int32 * n)(*(m[2] for m in mats)), n, L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(flat16, params.to(torch.bfloat16))
+    covered = torch.zeros(count, dtype=torch.bool, device="cuda")
+    for off, r, c in mats:
+        want = params[off:off + r * c].view(r, c).t().contiguous().to(torch.bfloat16)
+        assert torch.equal(trans16[off:off + r * c].view(c, r), want)
+        covered[off:off + r * c] = True
+    assert bool((trans16[~covered] == 9.0).all())
+    with pytest.raises(RuntimeError):
+        L.call("addhip_shadow_refresh", L.ptr(params), L.ptr(flat16), L.ptr(trans16), count, (C.c_int64 * 1)(count - 10), (C.c_int32 * 1)(8),
+               (C.c_int32 * 1)(8), 1, L.current_stream())

@@ -224,6 +224,14 @@ def test_gather_minibatch():
                   L.ptr(o["no"]), L.ptr(o["na"]), L.ptr(o["lp"]), L.ptr(o["ad"]), L.ptr(o["tv"]), L.ptr(o["mk"]), L.ptr(o["nd"]))
     L.call("addhip_gather_minibatch", g, L.current_stream())
     torch.cuda.synchronize()
+    # optional bf16 copies (bf16-storage mode): exactly the fp32 outputs rounded to nearest even
+    fp32_out = {k: o[k].clone() for k in ("no", "nd")}
+    o16 = dict(no=torch.ones(Mb, 264, device="cuda", dtype=torch.bfloat16), nd=torch.ones(Mb, 116, device="cuda", dtype=torch.bfloat16))
+    g.norm_obs16, g.norm_diff16 = L.ptr(o16["no"]), L.ptr(o16["nd"])
+    L.call("addhip_gather_minibatch", g, L.current_stream())
+    torch.cuda.synchronize()
+    for k in ("no", "nd"):
+        assert torch.equal(o[k], fp32_out[k]) and torch.equal(o16[k], o[k].to(torch.bfloat16))
     np.testing.assert_allclose(o["no"].cpu().numpy(), (obs[idx] - om) / os_, rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(o["na"].cpu().numpy()[:, :29], (act[idx][:, :29] - am) / as_, rtol=1e-6, atol=1e-6)
     assert np.all(o["na"].cpu().numpy()[:, 29:] == 0) and np.all(o["nd"].cpu().numpy()[:, 114:] == 0)
