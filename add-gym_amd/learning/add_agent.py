@@ -215,12 +215,13 @@ class ADDAgent:
                 in_ld = net.in_ld if i == 0 else net.hidden[i - 1]
                 need = max(need, 2 * split_k_for(h, in_ld, Mb + 1) * h * in_ld)  # x2: gradient-penalty product shares the reduce
         # split-K scratch: one per net, because the three nets' update sections run on three concurrent streams
-        self._slabs_all = z(3, need)
+        self._slabs_all = z(4, need)  # [3]: the discriminator's top-layer weight gradient, which runs beside the rest of its backward pass
         self._slabs = self._slabs_all[0]
         s16 = self._storage16
         self._run_actor = NetRunner(m, m.actor, Mb + 1 if s16 else rows, dev, self._slabs_all[0], self._prec, s16)
         self._run_critic = NetRunner(m, m.critic, Mb + 1 if s16 else rows, dev, self._slabs_all[1], self._prec, s16)
         self._run_disc = NetRunner(m, m.disc, Mb + 1 if s16 else rows, dev, self._slabs_all[2], self._prec, s16)
+        self._run_disc.aux_slabs = (len(m.disc.hidden) - 1, self._slabs_all[3])
         # rollout / evaluation passes: the same runners, except in bf16-storage mode (fp32 operands, bf16x2 products)
         if s16:
             self._roll_actor = NetRunner(m, m.actor, N, dev, None, self._prec_small)
@@ -228,8 +229,8 @@ class ADDAgent:
             self._eval_disc = NetRunner(m, m.disc, self._eval_rows, dev, None, self._prec_small)
         else:
             self._roll_actor, self._eval_critic, self._eval_disc = self._run_actor, self._run_critic, self._run_disc
-        # (the discriminator's section is the step's longest chain: its stream gets the higher priority)
-        self._side_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)]
+        # (the discriminator's section is the step's longest chain: its two streams get the higher priority)
+        self._side_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=-1)]
         OS, DS = self._task.obs_stride, self._task.disc_stride
         hd = m.disc.hidden
         self._W = dict(mean=z(rows, 32), d_mean=z(rows, 32), noise=z(N, L.NUM_DOF), explore_u=z(N), u=z(3, N), logits=z(rows), nv=z(1),
@@ -310,6 +311,7 @@ class ADDAgent:
         nd = L.ptr(W["norm_diff"])
         nd16 = L.ptr(W["norm_diff16"]) if s16 else None
         rd.forward(p, nd, Md, sign_bits=True, x16_ptr=nd16)
+        d_head = len(p.calls)
         p.add("addhip_disc_head", L.ptr(rd.h[-1]), hD, hD, Mb, L.ptr(rd.h[-1]) + 4 * Mb * hD, m.p("disc", "Wh"), m.p("disc", "bh"), ls_d,
               L.ptr(W["dlogit"]), L.ptr(W["dlogit"]) + 4 * Mb, L.ptr(W["stats"]) + 4 * 12)
         p.add("addhip_head_backward", L.ptr(W["dlogit"]), m.p("disc", "Wh"), L.ptr(rd.h[-1]), hD, hD, Md, L.ptr(rd.dz[-1]), m.g("disc", "Wh"),
@@ -319,6 +321,7 @@ class ADDAgent:
         if len(m.disc.hidden) != 2:
             raise NotImplementedError("the gradient-penalty chain is written for the 2-hidden-layer discriminator (fc_2layers_*)")
         d1, d2 = m.disc.hidden
+        d_gp = len(p.calls)
         p.add("addhip_bcast_mask", m.p("disc", "Wh"), L.ptr(h2), d2, d2, Mb, L.ptr(W["a2"]))
         if s16:
             # the same chain on bf16 operands: a2 and G are rounded once, a1 / e1 leave their GEMMs as bf16, g and da2 as fp32
@@ -334,6 +337,7 @@ class ADDAgent:
                        **k16, **rd.mask_args(0, 0, Mb))
             self._gemm(p, Mb, d2, d1, L.ptr(W["e1_16"]), d1, 1, m.p16("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **k16, **rd.mask_args(1, 0, Mb))
             p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
+            d_bwd = len(p.calls)
             rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1_16"]), d1, L.ptr(W["G16"]), DS, Mb), 1: (L.ptr(W["a2_16"]), d2, L.ptr(W["e1_16"]), d1, Mb)},
                         grads_zeroed=True, top_bias_done=True, x16_ptr=nd16, accumulate_dw=True)
         else:
@@ -344,17 +348,31 @@ class ADDAgent:
             self._gemm(p, Mb, d1, DS, L.ptr(W["G"]), DS, 1, m.p("disc", "W0"), DS, 1, L.ptr(W["e1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
             self._gemm(p, Mb, d2, d1, L.ptr(W["e1"]), d1, 1, m.p("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **rd.mask_args(1, 0, Mb))
             p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
+            d_bwd = len(p.calls)
             rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1"]), d1, L.ptr(W["G"]), DS, Mb), 1: (L.ptr(W["a2"]), d2, L.ptr(W["e1"]), d1, Mb)},
                         grads_zeroed=True, top_bias_done=True, accumulate_dw=True)
         self._update_marks.append(("disc", len(p.calls)))
-        # Launch / exchange schedule of one optimiser step: (stream, first call, last call, gradient range to all-reduce after it).
-        # Actor and critic hand over everything but their first layer as soon as it is final; the collectives are issued
-        # in the order they become ready, because one communicator runs them in issue order.
+        # Launch / exchange schedule of one optimiser step: entries (stream, first call, last call, gradient range to all-reduce after
+        # it, entry whose completion the stream waits for before it starts, entry it waits for before the all-reduce), issued in
+        # list order.  Actor and critic hand over everything but their first layer as soon as it is final; the collectives are
+        # issued in the order they become ready, because one communicator runs them in issue order.
+        # The discriminator's section is the longest chain of the step, so its independent pieces run side by side on two
+        # streams: the logit loss and its backward step through the head (stream 3) beside the gradient-penalty chain (stream 2),
+        # then the top layer's weight gradient (stream 3, own split-K scratch) beside the dX GEMM and the first layer's.
         (_, end_a), (_, end_c), (_, end_d) = self._update_marks
         ea, ec = ra.early_mark, rc.early_mark
         br = m.bucket_ranges
-        self._update_schedule = [(0, 0, ea, br["actor_tail"]), (1, end_a, ec, br["critic_tail"]), (2, end_c, end_d, br["disc"]),
-                                 (0, ea, end_a, None), (1, ec, end_c, None)]  # the two first layers: one bucket after the join
+        dw_first, dw_last = rd.dw_marks[len(m.disc.hidden) - 1]
+        sched = [(0, 0, ea, br["actor_tail"], None, None), (1, end_a, ec, br["critic_tail"], None, None),
+                 (2, end_c, d_head, None, None, None),          # 2: L2 terms, forward
+                 (3, d_head, d_gp, None, 2, None),              # 3: logit loss, head backward -> top dz
+                 (2, d_gp, d_bwd, None, None, None),            # 4: gradient-penalty chain
+                 (3, d_bwd, dw_first, None, None, None),        # 5: (bf16 storage: the top dz rounded to bf16)
+                 (3, dw_first, dw_last, None, 4, None),         # 6: top-layer weight gradient (needs the chain's a2 / e1)
+                 (2, dw_last, end_d, br["disc"], 5, 6),         # 7: dX, first-layer weight gradient
+                 (0, ea, end_a, None, None, None), (1, ec, end_c, None, None, None)]  # the two first layers: one bucket after the join
+        self._update_schedule = sched
+        self._sched_events = sorted({e[4] for e in sched if e[4] is not None} | {e[5] for e in sched if e[5] is not None})
 
         # ---- build-train-data: critic over the T+1 obs slots and the N obs_timeout rows, discriminator over the T*N
         # differences, in chunks of _eval_rows rows (plans prebuilt once like the act / update plans)
@@ -623,23 +641,36 @@ class ADDAgent:
         total = self.T * self.N
         num_batches = int(np.ceil(float(min(self._total_samples, total)) / self.Mb))
         W["stats"].zero_()
-        steps = 0
-        for _ in range(self._update_epochs):
-            for _ in range(num_batches):
+        steps, n_steps = 0, self._update_epochs * num_batches
+        main, side = torch.cuda.current_stream(), self._side_streams[0]
+        self._next_minibatch_indices()
+        L.call("addhip_gather_minibatch", self._gather_c, st)
+        while steps < n_steps:
+            self._run_update_sections()
+            steps += 1
+            gathered = None
+            if steps < n_steps:
+                # the next minibatch is gathered on a side stream beside this step's optimiser (the sections have joined: the
+                # minibatch buffers are free; the gather reads nothing the optimiser writes)
                 self._next_minibatch_indices()
-                L.call("addhip_gather_minibatch", self._gather_c, st)
-                self._run_update_sections()
-                if self._grad_clip > 0.0:
-                    L.call("addhip_grad_clip", L.ptr(m.grads), m.count, self._grad_clip, L.ptr(W["scratch"]), None, st)
-                m.opt_step += 1
-                if self._opt_type == "SGD":
-                    L.call("addhip_sgd", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), m.count, self._lr, 0.9, self._wd, m.opt_step, st)
-                else:
-                    L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, self._lr, 0.9, 0.999, 1e-8,
-                           self._wd, m.opt_step, st)
-                if self._storage16:
-                    m.refresh_shadow(st)
-                steps += 1
+                joined = torch.cuda.Event()
+                joined.record(main)
+                side.wait_event(joined)
+                L.call("addhip_gather_minibatch", self._gather_c, side.cuda_stream)
+                gathered = torch.cuda.Event()
+                gathered.record(side)
+            if self._grad_clip > 0.0:
+                L.call("addhip_grad_clip", L.ptr(m.grads), m.count, self._grad_clip, L.ptr(W["scratch"]), None, st)
+            m.opt_step += 1
+            if self._opt_type == "SGD":
+                L.call("addhip_sgd", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), m.count, self._lr, 0.9, self._wd, m.opt_step, st)
+            else:
+                L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, self._lr, 0.9, 0.999, 1e-8,
+                       self._wd, m.opt_step, st)
+            if self._storage16:
+                m.refresh_shadow(st)
+            if gathered is not None:
+                main.wait_event(gathered)
         return steps
 
     def _run_update_sections(self):
@@ -664,9 +695,17 @@ class ADDAgent:
         pending = []
         for s in self._side_streams:
             s.wait_event(fork)
-        for si, first, last, bucket in self._update_schedule:
+        events = {}
+        for k, (si, first, last, bucket, after, join) in enumerate(self._update_schedule):
             s = streams[si]
+            if after is not None:
+                s.wait_event(events[after])
             plan.run(s.cuda_stream, first, last)
+            if join is not None:
+                s.wait_event(events[join])
+            if k in self._sched_events:
+                events[k] = torch.cuda.Event()
+                events[k].record(s)
             if overlap and bucket is not None:
                 with torch.cuda.stream(s):
                     pending.append(D.all_reduce_sum_async(m.grads[bucket[0]:bucket[1]]))

@@ -250,19 +250,22 @@ class NetRunner:
             self.h16 = [torch.zeros(rows, h, dtype=torch.bfloat16, device=device) for h in net.hidden]
             self.dz16 = [torch.zeros(rows, h, dtype=torch.bfloat16, device=device) for h in net.hidden]
         self.early_mark = None
-        self._bits_valid = False
+        self.dw_marks = {}      # layer -> (first, last) plan call index of its weight-gradient group (GEMMs + split-K combine)
+        self.aux_slabs = None   # (layer, buffer): that layer's weight-gradient group uses its own split-K scratch, so that it
+        self._bits_valid = False  # may run on another stream than the rest of the backward pass
         # ReLU sign bits of the hidden activations (1 bit per element): what the backward GEMMs read as their mask instead of
         # the fp32 activations themselves (64 MB -> 2 MB per 16384 x 1024 layer)
         self.hb = [torch.zeros(rows, (h + 31) // 32, dtype=torch.int32, device=device) for h in net.hidden]
         self.h = [torch.zeros(rows, h, device=device) for h in net.hidden]
         self.dz = [torch.zeros(rows, h, device=device) for h in net.hidden]
 
-    @staticmethod
-    def _row_chunks(rows):
+    def _row_chunks(self, rows):
         """A few rows past a multiple of 128 (the discriminator's extra zero-difference sample: Mb + 1 rows) would cost a
-        whole extra wave of 128-row tiles; they go into a second, tiny launch instead.  -> [(first_row, count), ...]"""
+        whole extra wave of 128-row tiles; they go into a second, tiny launch instead.  -> [(first_row, count), ...]
+        (not in bf16-storage mode: its GEMM keeps 4 workgroups per CU in flight, so eight more tiles cost less than the
+        launch, which sits on the discriminator's serial chain)"""
         rem = rows % 128
-        if rows > 128 and 0 < rem <= 8:
+        if rows > 128 and 0 < rem <= 8 and not self.storage16:
             return [(0, rows - rem), (rows - rem, rem)]
         return [(0, rows)]
 
@@ -327,17 +330,20 @@ class NetRunner:
             inp = (x16_ptr if s16 else x_ptr) if i == 0 else L.ptr(acts[i - 1])
             s = split_k_for(out_d, in_ld, rows)
             slab = out_d * in_ld
-            g = gemm(out_d, in_ld, rows, L.ptr(dz[i]), out_d, 0, inp, in_ld, 0, L.ptr(self.slabs), in_ld, split_k=s, **kw)
+            slabs = self.aux_slabs[1] if self.aux_slabs is not None and self.aux_slabs[0] == i else self.slabs
+            dw_first = len(plan.calls)
+            g = gemm(out_d, in_ld, rows, L.ptr(dz[i]), out_d, 0, inp, in_ld, 0, L.ptr(slabs), in_ld, split_k=s, **kw)
             plan.hold(g)
             plan.add("addhip_gemm_f32", g)
             total = s
             if extra_dw and i in extra_dw:
                 a_ptr, lda, b_ptr, ldb, erows = extra_dw[i]
-                g2 = gemm(out_d, in_ld, erows, a_ptr, lda, 0, b_ptr, ldb, 0, L.ptr(self.slabs) + 4 * s * slab, in_ld, split_k=s, **kw)
+                g2 = gemm(out_d, in_ld, erows, a_ptr, lda, 0, b_ptr, ldb, 0, L.ptr(slabs) + 4 * s * slab, in_ld, split_k=s, **kw)
                 plan.hold(g2)
                 plan.add("addhip_gemm_f32", g2)
                 total = 2 * s
-            plan.add("addhip_slab_reduce", L.ptr(self.slabs), total, slab, m.g(net.name, f"W{i}"), slab, 1.0, int(accumulate_dw))
+            plan.add("addhip_slab_reduce", L.ptr(slabs), total, slab, m.g(net.name, f"W{i}"), slab, 1.0, int(accumulate_dw))
+            self.dw_marks[i] = (dw_first, len(plan.calls))
             if i == 1:
                 # every gradient of this net except W0 / b0 is final here (b1 came with the dX GEMM of layer 2, the head's
                 # with the loss kernels): an early bucket for the data-parallel exchange

@@ -138,7 +138,9 @@ def _check_param_summary(g, prefix, named, steps, lr=1e-4, long_run=False):
     for name, val in named.items():
         f = np.asarray(val, np.float64).reshape(-1)
         ref_l2 = float(g[f"{prefix}.{name}.l2"])
-        assert abs(np.sqrt(np.square(f).sum()) - ref_l2) <= (6e-4 if long_run else 2e-4) * max(ref_l2, 1e-12), (prefix, name)
+        # (long runs: + one lr of absolute slack -- a 29-element bias whose gradients are atomically accumulated sums near 0 moves
+        # by +-lr per step on rounding noise, which is a visible fraction of its own small norm)
+        assert abs(np.sqrt(np.square(f).sum()) - ref_l2) <= (6e-4 if long_run else 2e-4) * max(ref_l2, 1e-12) + (lr if long_run else 0.0), (prefix, name)
         stride = max(1, f.size // 64)
         d = np.abs(np.asarray(val, F).reshape(-1)[::stride][:64] - g[f"{prefix}.{name}.sample"])
         if long_run:  # a whole iteration (40 steps): rounding noise compounds; bound it against the distance travelled (<= lr*steps)
