@@ -19,10 +19,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE = 128 * BK * 2;      // bytes per operand tile in LDS (16 KB, either image)
-constexpr int STAGE = 2 * TILE;         // A tile, B tile
 constexpr int EPI_RUNTIME = -1;
+// 128x128 tile configurations (gemm_bf16_kernel): 0 = 4 waves of 64x64, two 64-deep LDS stages, 2 workgroups per CU;
+// 1 = the same tile, one stage, 3-4 workgroups per CU covering for each other.  (The 256x256 tile: gemm_bf16_q_kernel below.)
+template <int CFG> struct Cfg {
+  static constexpr int MT = 2;                           // 32-row accumulator blocks per wave (2 column blocks always)
+  static constexpr int WN = 2;                           // waves across N
+  static constexpr int NW = 4;                           // waves per workgroup
+  static constexpr int BM = (NW / WN) * MT * 32, BN = WN * 64;
+  static constexpr int BKS = 64;                         // k per stage
+  static constexpr int TILE_A = BM * BKS * 2, TILE_B = BN * BKS * 2, STAGE = TILE_A + TILE_B;
+  static constexpr int STAGES = CFG == 1 ? 1 : 2;
+  static constexpr int PPW = TILE_A / 1024 / NW;          // 1 KiB DMA pieces per wave, operand and stage (BM == BN)
+  static constexpr int EPI_BYTES = NW * 32 * (64 * 4 + 16);  // NW x 32 x ERS
+  static constexpr int LDS_BYTES = STAGES * STAGE > EPI_BYTES ? STAGES * STAGE : EPI_BYTES;
+};
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -42,30 +53,33 @@ __device__ __forceinline__ u16 to_bf16(float v) {
 // and the same XOR is applied by the fragment reads.
 //
 // k-contiguous operand P[r*ld + k] (activations, weights, transposed weight shadows):
-//   image [128 rows][64 k], 128-B rows of 8 chunks; chunk c of row r sits at chunk position c ^ ((r >> 1) & 7)
-//   (a ds_read_b128 lane group = 16 rows at one k chunk then covers all 64 banks); one piece = 8 rows.
+//   image [rows][64 k], 128-B rows of 8 chunks, chunk c of row r at chunk position c ^ ((r >> 1) & 7), one piece = 8 rows; or
+//   image [rows][32 k],  64-B rows of 4 chunks, chunk c of row r at chunk position c ^ ((r >> 2) & 3), one piece = 16 rows
+//   (either way a ds_read_b128 lane group = 16 rows at one k chunk covers all 64 banks).
 // m/n-contiguous operand P[k*ld + r] (the weight-gradient GEMMs dW = dz^T x: both operands row-major over the minibatch):
-//   image [64 k][128 rows], 256-B rows of 16 chunks; chunk ch of k-row kr sits at position ch ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
-//   one piece = 4 k-rows.  MFMA fragments (8 consecutive k of one row per lane) come out of it by two ds_read_b64_tr_b16
+//   image [64 k][rows], 256-B or 512-B rows of 16-byte chunks; chunk ch of k-row kr sits at position ch ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+//   one piece = 4 or 2 k-rows.  MFMA fragments (8 consecutive k of one row per lane) come out of it by two ds_read_b64_tr_b16
 //   (each delivers a 4 k x 16 rows block transposed), conflict-free with this XOR.
-__device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
+template <int BKS> __device__ __forceinline__ int kc_swz(int row) { return BKS == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 __device__ __forceinline__ int mc_swz(int kr) { return ((kr & 3) << 2) | ((kr >> 2) & 3); }
 
-template <bool KC>
+template <bool KC, int ROWS, int BKS, int PPW>
 struct Stager {
-  unsigned off[4];   // byte offset of this lane's 16-byte chunk from the stage's (uniform) source base, pieces 4*wave .. 4*wave+3
-  int kq[4];         // the k (relative to the stage's first k) the chunk starts at (KC) / lies on (MC): tail guard
+  unsigned off[PPW];  // byte offset of this lane's 16-byte chunk from the stage's (uniform) source base, pieces PPW*wave .. PPW*wave+PPW-1
+  int kq[PPW];        // the k (relative to the stage's first k) the chunk starts at (KC) / lies on (MC): tail guard
   // rows_left = R - r0 (>= 1; a multiple of 8 for MC)
   __device__ __forceinline__ void init(int wave, int lane, int ld, int rows_left) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = 4 * wave + i;
+    for (int i = 0; i < PPW; ++i) {
+      const int piece = PPW * wave + i;
       if (KC) {
-        const int row = 8 * piece + (lane >> 3), c = (lane & 7) ^ kc_swz(row);
+        constexpr int LPR = BKS / 8;  // lanes (16-byte chunks) per row of the image
+        const int row = (64 / LPR) * piece + lane / LPR, c = (lane % LPR) ^ kc_swz<BKS>(row);
         off[i] = 2u * ((unsigned)min(row, rows_left - 1) * (unsigned)ld + 8u * c);
         kq[i] = 8 * c;
       } else {
-        const int kr = 4 * piece + (lane >> 4), ch = (lane & 15) ^ mc_swz(kr);
+        constexpr int LPR = ROWS / 8;  // lanes per k-row of the image
+        const int kr = (64 / LPR) * piece + lane / LPR, ch = (lane % LPR) ^ mc_swz(kr);
         off[i] = 2u * ((unsigned)kr * (unsigned)ld + (unsigned)min(8 * ch, rows_left - 8));
         kq[i] = kr;
       }
@@ -75,156 +89,70 @@ struct Stager {
   template <bool GUARD>
   __device__ __forceinline__ void issue(const char* src, char* dst, int wave, int kleft) const {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PPW; ++i) {
       const char* s = src + off[i];
       if (GUARD && kq[i] >= kleft) s = reinterpret_cast<const char*>(&g_zero_chunk);  // K % 8 == 0: a chunk is in or out as a whole
-      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(dst + (4 * wave + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(dst + (PPW * wave + i) * 1024), 16, 0, 0);
     }
   }
 };
 
 // fragment (rows row0 .. row0+31 of the tile, k 16*ks .. 16*ks+15): lane (li, lh) gets row row0+li, k 16*ks + 8*lh .. +7
+template <int BKS>
 struct FragKC {
   unsigned base, x;  // row byte offset, lh ^ swizzle
-  __device__ __forceinline__ void init(int w0, int li, int lh) { base = (unsigned)(w0 + li) * 128u; x = (unsigned)(lh ^ kc_swz(li)); }  // w0 % 64 == 0
+  __device__ __forceinline__ void init(int w0, int li, int lh) { base = (unsigned)(w0 + li) * (2u * BKS); x = (unsigned)(lh ^ kc_swz<BKS>(li)); }  // w0 % 32 == 0
   __device__ __forceinline__ bf16x8 get(const char* tile, int a, int ks) const {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + base + a * (32 * 128) + (((2u * ks) ^ x) << 4)));
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + base + a * (32 * 2 * BKS) + (((2u * ks) ^ x) << 4)));
   }
 };
+template <int ROWS, int MT>
 struct FragMC {
-  unsigned addr[2][2];  // [a][j]: this lane's address for the j-th 4-k block of fragment a at ks = 0
+  static constexpr unsigned RS = ROWS * 2;  // bytes per k-row of the image
+  unsigned addr[MT][2];  // [a][j]: this lane's address for the j-th 4-k block of fragment a at ks = 0
   __device__ __forceinline__ void init(int w0, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int kr = 8 * (g >> 1) + 4 * j + q;                  // + 16*ks: leaves mc_swz(kr) unchanged
         const int ch = (w0 + a * 32 + 16 * (g & 1)) / 8 + (p >> 1);
-        addr[a][j] = 256u * kr + 16u * (ch ^ mc_swz(kr)) + 8u * (p & 1);
+        addr[a][j] = RS * kr + 16u * (ch ^ mc_swz(kr)) + 8u * (p & 1);
       }
   }
   __device__ __forceinline__ bf16x8 get(const char* tile, int a, int ks) const {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(tile + addr[a][0] + ks * (16 * 256)));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(tile + addr[a][1] + ks * (16 * 256)));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(tile + addr[a][0] + ks * (16 * RS)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(tile + addr[a][1] + ks * (16 * RS)));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
   }
 };
-template <bool KC> struct FragSel { typedef FragKC type; };
-template <> struct FragSel<false> { typedef FragMC type; };
+template <bool KC, int ROWS, int MT, int BKS> struct FragSel { typedef FragKC<BKS> type; };
+template <int ROWS, int MT, int BKS> struct FragSel<false, ROWS, MT, BKS> { typedef FragMC<ROWS, MT> type; };
 
-template <bool AKC, bool BKC, int EPI, bool SB>
-__global__ __launch_bounds__(256, SB ? ((AKC && BKC) ? 4 : 3) : 2) void gemm_bf16_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(1024))) char lds[SB ? 4 * 32 * (64 * 4 + 16) : 2 * STAGE];
-
-  // XCD-aware remap (blocks b and b+8 share an XCD): each XCD gets a contiguous run of tiles, N-tile fastest
-  const int total = tiles_m * tiles_n;
-  const int orig = blockIdx.x;
-  const int q = total >> 3, r = total & 7, xcd = orig & 7;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int split = g.split_k > 1 ? g.split_k : 1;
-  const int kchunk = ((g.K + split - 1) / split + BK - 1) / BK * BK;
-  const int kbeg = blockIdx.z * kchunk;
-  const int kend = min(g.K, kbeg + kchunk);
-  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-  const int nk_full = kend > kbeg ? (kend - kbeg) / BK : 0;
-
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+// Epilogue of a wave's (MT*32) x 64 accumulator block whose first element is (row0, col0) of C.  In the accumulators a lane owns
+// ONE column (col0+b*32+li) and register x is row (x&3)+8*(x>>2)+4*lh of the 32x32 tile: bias, ReLU, mask, sign bits and the
+// bias-gradient column sums are done in that layout, then each 32-row slice goes through a wave-private LDS buffer and leaves as
+// 16-byte stores along the rows (2-byte and 4-byte stores straight from the accumulators cost 4-8x the store instructions,
+// which is what a short-K launch then spends its time on).  The caller has passed a barrier behind the last LDS stage.
+constexpr int ERS = 64 * 4 + 16;  // bytes per staged row: 64 fp32 + one 16-byte pad
+template <int MT, int EPI>
+__device__ __forceinline__ void epilogue(const addhip_gemm_t& g, f32x16 (&acc)[MT][2], char* lds, int wave, int lane, int row0, int col0) {
   const int li = lane & 31, lh = lane >> 5;
-
-  // stage sources: (tile's first row, first k of the split) and the step between stages
-  const char* srcA = reinterpret_cast<const char*>(g.A) + 2 * (AKC ? (size_t)m0 * g.lda + kbeg : (size_t)kbeg * g.lda + m0);
-  const char* srcB = reinterpret_cast<const char*>(g.B) + 2 * (BKC ? (size_t)n0 * g.ldb + kbeg : (size_t)kbeg * g.ldb + n0);
-  const size_t stepA = 2 * (AKC ? (size_t)BK : (size_t)BK * g.lda), stepB = 2 * (BKC ? (size_t)BK : (size_t)BK * g.ldb);
-  Stager<AKC> sa;
-  Stager<BKC> sb;
-  sa.init(wave, lane, g.lda, g.M - m0);
-  sb.init(wave, lane, g.ldb, g.N - n0);
-  typename FragSel<AKC>::type fa_;
-  typename FragSel<BKC>::type fb_;
-  if constexpr (AKC) fa_.init(wm0, li, lh); else fa_.init(wm0, lane);
-  if constexpr (BKC) fb_.init(wn0, li, lh); else fb_.init(wn0, lane);
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
-
-  auto stage = [&](int kt, int buf) {
-    char* dst = lds + buf * STAGE;
-    const int kleft = kend - (kbeg + kt * BK);
-    if (kt < nk_full) {
-      sa.template issue<false>(srcA + kt * stepA, dst, wave, kleft);
-      sb.template issue<false>(srcB + kt * stepB, dst + TILE, wave, kleft);
-    } else {
-      sa.template issue<true>(srcA + kt * stepA, dst, wave, kleft);
-      sb.template issue<true>(srcB + kt * stepB, dst + TILE, wave, kleft);
-    }
-  };
-  // Double-buffered (!SB): one barrier per 64-deep stage.  Its vmcnt(0) retires this wave's share of stage kt (issued one whole
-  // compute phase earlier), the barrier itself makes every wave's share visible and proves stage kt-1's buffer is no longer
-  // being read, so the DMA of stage kt+1 into that buffer is issued right behind it and stays in flight under the 16 MFMAs
-  // of stage kt.  Single-buffered (SB): issue, wait + barrier, compute, barrier; the CU's other workgroups fill the waits.
-  if (!SB && nk > 0) stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = SB ? 0 : (kt & 1);
-    if (SB) {
-      if (kt > 0) __syncthreads();
-      stage(kt, 0);
-    }
-    __syncthreads();
-    if (!SB && kt + 1 < nk) stage(kt + 1, cur ^ 1);
-    const char* a_cur = lds + cur * STAGE;
-    const char* b_cur = a_cur + TILE;
-    // (the compiler sinks each k-step's fragment reads to just behind the issue of the MFMAs that consume the previous ones)
-    bf16x8 fa[2][2], fb[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) fa[0][a] = fa_.get(a_cur, a, 0);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) fb[0][b] = fb_.get(b_cur, b, 0);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      if (ks + 1 < BK / 16) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) fa[(ks + 1) & 1][a] = fa_.get(a_cur, a, ks + 1);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) fb[(ks + 1) & 1][b] = fb_.get(b_cur, b, ks + 1);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
-    }
-  }
-
-  // epilogue.  In the accumulators a lane owns ONE column (n0+wn0+b*32+li) and register x is row (x&3)+8*(x>>2)+4*lh of the
-  // 32x32 tile: bias, ReLU, mask, sign bits and the bias-gradient column sums are done in that layout, then each 32-row
-  // half of the wave's 64x64 block goes through a wave-private LDS buffer and leaves as 16-byte stores along the rows
-  // (2-byte and 4-byte stores straight from the accumulators cost 4-8x the store instructions, which is what a
-  // short-K launch then spends its time on).
   const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
   float* C = g.C ? g.C + (size_t)blockIdx.z * (size_t)g.M * g.ldc : nullptr;
   u16* C16 = reinterpret_cast<u16*>(g.C16);
-  constexpr int ERS = 64 * 4 + 16;  // bytes per staged row: 64 fp32 + one 16-byte pad
-  __syncthreads();                  // every wave is done with the last stage
   char* ebuf = lds + wave * (32 * ERS);
   const bool c_vec = C && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (g.ldc & 3) == 0;
   const bool c16_vec = C16 && (reinterpret_cast<uintptr_t>(C16) & 15) == 0 && (g.ldc16 & 7) == 0;
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int rtile = m0 + wm0 + a * 32;
+  for (int a = 0; a < MT; ++a) {
+    const int rtile = row0 + a * 32;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int cgroup = n0 + wn0 + b * 32, col = cgroup + li;
+      const int cgroup = col0 + b * 32, col = cgroup + li;
       const bool col_ok = col < g.N;
       const float bias = (col_ok && (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU)) ? g.bias[col] : 0.f;
       // sign-bit word of tile row `lane` (lanes 0..31), fetched once and handed out by readlane
@@ -262,7 +190,7 @@ __global__ __launch_bounds__(256, SB ? ((AKC && BKC) ? 4 : 3) : 2) void gemm_bf1
       }
     }
     if (C) {  // 16 lanes x 4 columns per row, 4 rows per instruction
-      const int c4 = (lane & 15) * 4, col = n0 + wn0 + c4;
+      const int c4 = (lane & 15) * 4, col = col0 + c4;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rloc = (lane >> 4) + 4 * i, row = rtile + rloc;
@@ -281,7 +209,7 @@ __global__ __launch_bounds__(256, SB ? ((AKC && BKC) ? 4 : 3) : 2) void gemm_bf1
       }
     }
     if (C16) {  // 8 lanes x 8 columns per row, 8 rows per instruction
-      const int c8 = (lane & 7) * 8, col = n0 + wn0 + c8;
+      const int c8 = (lane & 7) * 8, col = col0 + c8;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rloc = (lane >> 3) + 8 * i, row = rtile + rloc;
@@ -302,6 +230,268 @@ __global__ __launch_bounds__(256, SB ? ((AKC && BKC) ? 4 : 3) : 2) void gemm_bf1
       }
     }
   }
+}
+
+template <bool AKC, bool BKC, int EPI, int CFG>
+__global__ __launch_bounds__(256, CFG == 1 ? ((AKC && BKC) ? 4 : 3) : 2) void gemm_bf16_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
+  typedef Cfg<CFG> Q;
+  constexpr bool SB = Q::STAGES == 1;
+  constexpr int BM = Q::BM, BN = Q::BN, MT = Q::MT, STAGE = Q::STAGE, TILE = Q::TILE_A;  // TILE: offset of the B tile in a stage
+  constexpr int BK = Q::BKS;
+  __shared__ __attribute__((aligned(1024))) char lds[Q::LDS_BYTES];
+
+  // XCD-aware remap (blocks b and b+8 share an XCD): each XCD gets a contiguous run of tiles, N-tile fastest
+  const int total = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q = total >> 3, r = total & 7, xcd = orig & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  const int kchunk = ((g.K + split - 1) / split + BK - 1) / BK * BK;
+  const int kbeg = blockIdx.z * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  const int nk_full = kend > kbeg ? (kend - kbeg) / BK : 0;
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm0 = (wave / Q::WN) * (MT * 32), wn0 = (wave % Q::WN) * 64;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // stage sources: (tile's first row, first k of the split) and the step between stages
+  const char* srcA = reinterpret_cast<const char*>(g.A) + 2 * (AKC ? (size_t)m0 * g.lda + kbeg : (size_t)kbeg * g.lda + m0);
+  const char* srcB = reinterpret_cast<const char*>(g.B) + 2 * (BKC ? (size_t)n0 * g.ldb + kbeg : (size_t)kbeg * g.ldb + n0);
+  const size_t stepA = 2 * (AKC ? (size_t)BK : (size_t)BK * g.lda), stepB = 2 * (BKC ? (size_t)BK : (size_t)BK * g.ldb);
+  Stager<AKC, BM, BK, Q::PPW> sa;
+  Stager<BKC, BN, BK, Q::PPW> sb;
+  sa.init(wave, lane, g.lda, g.M - m0);
+  sb.init(wave, lane, g.ldb, g.N - n0);
+  typename FragSel<AKC, BM, MT, BK>::type fa_;
+  typename FragSel<BKC, BN, 2, BK>::type fb_;
+  if constexpr (AKC) fa_.init(wm0, li, lh); else fa_.init(wm0, lane);
+  if constexpr (BKC) fb_.init(wn0, li, lh); else fb_.init(wn0, lane);
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
+
+  auto stage = [&](int kt, int buf) {
+    char* dst = lds + buf * STAGE;
+    const int kleft = kend - (kbeg + kt * BK);
+    if (kt < nk_full) {
+      sa.template issue<false>(srcA + kt * stepA, dst, wave, kleft);
+      sb.template issue<false>(srcB + kt * stepB, dst + TILE, wave, kleft);
+    } else {
+      sa.template issue<true>(srcA + kt * stepA, dst, wave, kleft);
+      sb.template issue<true>(srcB + kt * stepB, dst + TILE, wave, kleft);
+    }
+  };
+  auto compute = [&](int buf) {
+    const char* a_cur = lds + buf * STAGE;
+    const char* b_cur = a_cur + TILE;
+    // (the compiler sinks each k-step's fragment reads to just behind the issue of the MFMAs that consume the previous ones)
+    bf16x8 fa[2][MT], fb[2][2];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) fa[0][a] = fa_.get(a_cur, a, 0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) fb[0][b] = fb_.get(b_cur, b, 0);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      if (ks + 1 < BK / 16) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) fa[(ks + 1) & 1][a] = fa_.get(a_cur, a, ks + 1);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fb[(ks + 1) & 1][b] = fb_.get(b_cur, b, ks + 1);
+      }
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
+    }
+  };
+  {
+    // Double-buffered (!SB): one barrier per 64-deep stage.  Its vmcnt(0) retires this wave's share of stage kt (issued one whole
+    // compute phase earlier), the barrier itself makes every wave's share visible and proves stage kt-1's buffer is no longer
+    // being read, so the DMA of stage kt+1 into that buffer is issued right behind it and stays in flight under the 16 MFMAs
+    // of stage kt.  Single-buffered (SB): issue, wait + barrier, compute, barrier; the CU's other workgroups fill the waits.
+    if (!SB && nk > 0) stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = SB ? 0 : (kt & 1);
+      if (SB) {
+        if (kt > 0) __syncthreads();
+        stage(kt, 0);
+      }
+      __syncthreads();
+      if (!SB && kt + 1 < nk) stage(kt + 1, cur ^ 1);
+      compute(cur);
+    }
+  }
+
+  __syncthreads();  // every wave is done with the last stage: LDS becomes the waves' private epilogue buffers
+  epilogue<MT, EPI>(g, acc, lds, wave, lane, m0 + wm0, n0 + wn0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves (2 x 4) of 128x64, one workgroup per CU.  Why it exists: every K stage of these GEMMs holds rows that
+// no CU has touched yet (the minibatch operand is streamed once), so a stage's DMA takes an HBM round trip, ~1.5 us under
+// load (measured: a launch that only loads runs as long as one that only computes), and the L2 -> LDS path serves a CU about
+// 0.3 requests per clock whether they are 128-byte lines or halves.  The 128x128 kernel can only put other workgroups' MFMAs
+// under that latency and needs 64 B/clk/CU; this one needs 32 B/clk/CU, asks for whole lines only, and keeps its own DMA
+// several phases ahead of the MFMAs behind counted vmcnt waits and raw barriers (no vmcnt(0) inside the loop).
+//
+// A 64-deep K tile arrives as four 16 KB units of 128 rows x 64 k (whole 128-byte lines of a k-contiguous operand):
+//   u0 = AQ0, u1 = BQ0, u2 = BQ1, u3 = AQ1;  AQi = the i-th 64-row half of both wave-rows' 128 rows, BQj = the j-th 32-column
+//   half of all four wave-columns' 64 columns,
+// and is consumed in four phases, one 64x32 quadrant of every wave's block each: (A half, B half) = (0,0) (0,1) (1,0) (1,1),
+// 8 MFMAs per wave and phase.  Phase f (counting through all tiles) issues unit f+AHEAD into ring slot (f+AHEAD) % NS, waits
+// until units <= f+2 have landed (this wave's share; the barrier covers the others'), passes the barrier, requests the
+// fragments the NEXT phase needs from LDS, then issues this phase's MFMAs on fragments requested one phase ago.
+// Slot reuse: unit v is read in phase v-1 or v-2; those reads have returned before their wave reaches the next barrier, so
+// a slot may be overwritten two phases later: AHEAD = NS - 1.
+constexpr int Q_NS = 8, Q_AHEAD = Q_NS - 1, Q_UNIT = 16384;
+
+// DMA addressing of one operand's units: 16 pieces per unit, 2 per wave
+template <bool KC, int GS>  // GS = rows of one wave's share in a unit (A: 64, B: 32); the shares of consecutive waves lie 2*GS apart in the tile
+struct QStager {
+  unsigned off[2];
+  __device__ __forceinline__ void init(int wave, int lane, int ld) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = 2 * wave + i;
+      if (KC) {
+        const int lr = 8 * piece + (lane >> 3), c = (lane & 7) ^ kc_swz<64>(lr);
+        const int tr = (lr / GS) * (2 * GS) + (lr % GS);
+        off[i] = 2u * ((unsigned)tr * (unsigned)ld + 8u * c);
+      } else {
+        const int kr = 4 * piece + (lane >> 4), ch = (lane & 15) ^ mc_swz(kr);
+        const int lm = 8 * ch, tm = (lm / GS) * (2 * GS) + (lm % GS);
+        off[i] = 2u * ((unsigned)kr * (unsigned)ld + (unsigned)tm);
+      }
+    }
+  }
+  __device__ __forceinline__ void issue(const char* src, char* slot, int wave) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(src + off[i]), (lptr_t)(slot + (2 * wave + i) * 1024), 16, 0, 0);
+  }
+};
+
+template <bool AKC, bool BKC, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_q_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(1024))) char lds[Q_NS * Q_UNIT];
+  static_assert(Q_NS * Q_UNIT >= 8 * 32 * ERS, "the epilogue buffers must fit");
+  const int total = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q = total >> 3, r = total & 7, xcd = orig & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  const int kchunk = ((g.K + split - 1) / split + 63) / 64 * 64;
+  const int kbeg = blockIdx.z * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+  const int nk = kend > kbeg ? (kend - kbeg) / 64 : 0;  // the host sends only K % 64 == 0 here
+  const int U = 4 * nk;
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const char* srcA = reinterpret_cast<const char*>(g.A) + 2 * (AKC ? (size_t)m0 * g.lda + kbeg : (size_t)kbeg * g.lda + m0);
+  const char* srcB = reinterpret_cast<const char*>(g.B) + 2 * (BKC ? (size_t)n0 * g.ldb + kbeg : (size_t)kbeg * g.ldb + n0);
+  const size_t tileA = 2 * (AKC ? (size_t)64 : (size_t)64 * g.lda), tileB = 2 * (BKC ? (size_t)64 : (size_t)64 * g.ldb);   // next K tile
+  const size_t halfA = 2 * (AKC ? (size_t)64 * g.lda : (size_t)64), halfB = 2 * (BKC ? (size_t)32 * g.ldb : (size_t)32);   // second half
+  QStager<AKC, 64> sa;
+  QStager<BKC, 32> sb;
+  sa.init(wave, lane, g.lda);
+  sb.init(wave, lane, g.ldb);
+  typename FragSel<AKC, 128, 2, 64>::type fa_;
+  typename FragSel<BKC, 128, 1, 64>::type fb_;
+  if constexpr (AKC) fa_.init(wm * 64, li, lh); else fa_.init(wm * 64, lane);
+  if constexpr (BKC) fb_.init(wn * 32, li, lh); else fb_.init(wn * 32, lane);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
+
+  auto issue_unit = [&](int u) {  // u < U
+    const int t = u >> 2, w = u & 3;
+    char* slot = lds + (u % Q_NS) * Q_UNIT;
+    if (w == 0) sa.issue(srcA + t * tileA, slot, wave);
+    else if (w == 3) sa.issue(srcA + t * tileA + halfA, slot, wave);
+    else sb.issue(srcB + t * tileB + (w == 2 ? halfB : 0), slot, wave);
+  };
+  // units <= f+2 landed, as far as this wave's own loads go: at most min(AHEAD, U-1-f) - 2 later units (2 loads each) outstanding
+  auto wait_landed = [&](int f) {
+    const int later = min(Q_AHEAD, U - 1 - f) - 2;
+    if (later >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (later == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  static_assert(Q_AHEAD - 2 == 5, "wait_landed's immediates are written for AHEAD = 7");
+
+  bf16x8 fa[2][4][2];  // [A half][k step][block]
+  bf16x8 fb[2][4];     // [B half][k step]
+  auto read_a = [&](int i, int u) {
+    const char* slot = lds + (u % Q_NS) * Q_UNIT;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[i][ks][a] = fa_.get(slot, a, ks);
+  };
+  auto read_b = [&](int j, int u) {
+    const char* slot = lds + (u % Q_NS) * Q_UNIT;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb[j][ks] = fb_.get(slot, 0, ks);
+  };
+
+  if (nk > 0) {
+#pragma unroll
+    for (int u = 0; u < Q_AHEAD; ++u)
+      if (u < U) issue_unit(u);
+    wait_landed(-1);  // units 0 and 1
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_a(0, 0);
+    read_b(0, 1);
+  }
+  for (int t = 0; t < nk; ++t) {
+    const int f0 = 4 * t;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int f = f0 + p;
+      if (f + Q_AHEAD < U) issue_unit(f + Q_AHEAD);
+      wait_landed(f);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // fragments of the next phase (their units landed before the barrier just passed)
+      if (p == 0) read_b(1, f0 + 2);
+      if (p == 1) read_a(1, f0 + 3);
+      if (p == 3 && t + 1 < nk) {
+        read_a(0, f0 + 4);
+        read_b(0, f0 + 5);
+      }
+      const int i = p >> 1, j = p & 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) acc[2 * i + a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks][a], fb[j][ks], acc[2 * i + a][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  epilogue<4, EPI>(g, acc, lds, wave, lane, m0 + wm * 128, n0 + wn * 64);
 }
 
 // fp32 -> bf16 (round to nearest even), row by row: dst[r*ld_dst + c] = bf16(src[r*ld_src + c]), cols % 4 == 0
@@ -389,17 +579,28 @@ int gemm_bf16_dispatch(const addhip_gemm_t& g, hipStream_t st) {
     return (set_error("gemm: bf16-stored B needs 16-byte chunks (K or N, and ldb, multiples of 8)"), -1);
   if (!g.C && !g.C16) return (set_error("gemm: no output"), -1);
   if (g.split_k > 1 && (!g.C || g.C16)) return (set_error("gemm: split-K slabs are fp32"), -1);
-  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int split = g.split_k > 1 ? g.split_k : 1;
-  dim3 grid(tiles_m * tiles_n, 1, split), block(256);
-  // single LDS stage x 4 (3 with a transposed operand) workgroups per CU when the launch has the workgroups to fill that,
-  // double-buffered stages x 2 workgroups per CU otherwise (measured: 1024-tile launches 7-17 % faster single-buffered,
-  // 512-workgroup launches 3-5 % faster double-buffered)
-  const bool single = (long long)tiles_m * tiles_n * split >= 768;
-#define ADDHIP_LAUNCH(AK, BKc, EPI)                                                                          \
-  do {                                                                                                       \
-    if (single) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKc, EPI, true>), grid, block, 0, st, g, tiles_m, tiles_n); \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKc, EPI, false>), grid, block, 0, st, g, tiles_m, tiles_n);       \
+  // 128x128 tiles: a single LDS stage x 4 (3 with a transposed operand) workgroups per CU when the launch has the workgroups to
+  // fill that, double-buffered stages x 2 workgroups per CU if not (measured: 1024-tile launches 7-17 % faster single-buffered,
+  // 512-workgroup launches 3-5 % faster double-buffered).  256x256 tiles (gemm_bf16_q_kernel, one workgroup per CU) only for
+  // whole-tile shapes that fill the chip AND are deep in K: at 4096^3 it runs 1040 TFLOP/s on random operands, but with the
+  // 1024-deep K of the training step's launches its prologue and 256x256 write-out are not amortised (725 TFLOP/s isolated, the
+  // same as the 128x128 kernel) and, holding a CU's LDS alone, it keeps the other streams' launches off the CU (update phase
+  // 47.8 vs 46.3 ms) -- so the step never selects it.  ADDHIP_BF16_BIG=1 / 0 forces it on (eligible shapes) / off.
+  const long long t256 = (long long)(g.M / 256) * (g.N / 256);
+  const bool eligible = g.M % 256 == 0 && g.N % 256 == 0 && g.K % 64 == 0;
+  const char* force = getenv("ADDHIP_BF16_BIG");
+  bool big = eligible && t256 * split >= 192 && g.K / split >= 2048;
+  if (force) big = eligible && force[0] == '1';
+  const int BM = big ? 256 : 128, BN = BM;
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  const int cfg = big ? 2 : ((long long)tiles_m * tiles_n * split >= 768 ? 1 : 0);
+  dim3 grid(tiles_m * tiles_n, 1, split), block(big ? 512 : 256);
+#define ADDHIP_LAUNCH(AK, BKc, EPI)                                                                                      \
+  do {                                                                                                                   \
+    if (cfg == 2) hipLaunchKernelGGL((gemm_bf16_q_kernel<AK, BKc, EPI>), grid, block, 0, st, g, tiles_m, tiles_n);       \
+    else if (cfg == 1) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKc, EPI, 1>), grid, block, 0, st, g, tiles_m, tiles_n); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKc, EPI, 0>), grid, block, 0, st, g, tiles_m, tiles_n);               \
   } while (0)
   if (g.a_kcontig && g.b_kcontig) {
     if (g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_BIAS_RELU);

@@ -296,6 +296,19 @@ def test_gemm_bf16_storage(a_kc, b_kc):
         run_gemm_bf16(32, 512, 4096, 0, 0, split_k=32)
 
 
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])
+def test_gemm_bf16_storage_256_tiles(a_kc, b_kc, monkeypatch):
+    """The 256x256-tile kernel (gemm_bf16_q_kernel: unit ring, counted vmcnt, quadrant phases), forced on for shapes the
+    dispatcher would give to the 128x128 kernel: every operand layout, every epilogue, split-K, one and several K tiles."""
+    monkeypatch.setenv("ADDHIP_BF16_BIG", "1")
+    run_gemm_bf16(512, 768, 64, a_kc, b_kc)
+    run_gemm_bf16(256, 256, 1024 + 64, a_kc, b_kc)
+    if a_kc:
+        for epi in (1, 2, 3):
+            run_gemm_bf16(512, 256, 448, 1, b_kc, epilogue=epi)
+    run_gemm_bf16(256, 512, 4096, a_kc, b_kc, split_k=6)
+
+
 def test_to_bf16_rounds_to_nearest_even():
     import torch
     import add_gym_amd._lib as L
