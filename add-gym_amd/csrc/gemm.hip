@@ -15,6 +15,7 @@
 // Replaces: torch.nn.Linear forward/backward inside PPOModel.eval_actor/eval_critic
 // (ppo_model.py:13-21), ADDModel.eval_disc (add_model.py:12-15) and their autograd.
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -94,7 +95,7 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int kk, i
   return make_float4(p[0], p[ROWS + 4], p[2 * (ROWS + 4)], p[3 * (ROWS + 4)]);
 }
 
-constexpr int EPI_RUNTIME = -1;  // epilogue chosen from the descriptor at run time (cold combinations)
+using addhip_epi::EPI_RUNTIME;
 
 // EPI: compile-time epilogue (ADDHIP_EPI_*) or EPI_RUNTIME; NORM: fused (a-mean)/std on A
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int BK, int EPI, bool NORM>
@@ -105,8 +106,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
   static_assert(FM >= 1 && FN >= 1, "wave tile must hold a 32x32 accumulator");
   using TA = Tile<BM, AKC, BK>;
   using TB = Tile<BN, BKC, BK>;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (TA::SIZE + TB::SIZE)];
   constexpr int STAGE = TA::SIZE + TB::SIZE;
+  constexpr int EPI_FLOATS = 4 * addhip_epi::EpiBuf<FN>::WAVE_BYTES / 4;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE > EPI_FLOATS ? 2 * STAGE : EPI_FLOATS];
 
   // XCD-aware remap (blocks b and b+8 share an XCD): give each XCD a contiguous run of tiles,
   // N-tile fastest, so the N-tiles of one A row-panel hit the same L2.  Bijective for any count.
@@ -184,60 +186,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
     __syncthreads();
   }
 
-  // epilogue: lane owns column n0+wn0+b*32+li; register x is row (x&3)+8*(x>>2)+4*lh of the 32x32 tile
-  const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
-  const bool accum = g.accumulate != 0;  // K slices add into one C (hardware fp32 atomics) instead of writing slabs
-  float* C = g.C + (accum ? (size_t)0 : (size_t)blockIdx.z * (size_t)g.M * g.ldc);
-#pragma unroll
-  for (int b = 0; b < FN; ++b) {
-    const int col = n0 + wn0 + b * 32 + li;
-    const bool col_ok = col < g.N;
-    const float bias = (col_ok && (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU)) ? g.bias[col] : 0.f;
-#pragma unroll
-    for (int a = 0; a < FM; ++a) {
-      const int rbase = m0 + wm0 + a * 32 + 4 * lh;
-      float mk[16];
-      float cs = 0.f;  // MASK: column sum of this lane's 16 stored values (bias gradient)
-      // word of the ReLU sign bits this lane's 32-column group lives in (relu_bits / mask_bits)
-      const int cgroup = n0 + wn0 + b * 32;
-      if (epi == ADDHIP_EPI_MASK) {  // all 16 mask loads in flight before any use
-        if (g.mask_bits) {  // 1 bit per element: the 32 lanes of a half read the same word
-#pragma unroll
-          for (int x = 0; x < 16; ++x) {
-            const int row = rbase + (x & 3) + 8 * (x >> 2);
-            const unsigned wbits = (cgroup < g.N && row < g.M) ? g.mask_bits[(size_t)row * g.ldbits + (cgroup >> 5)] : 0u;
-            mk[x] = ((wbits >> li) & 1u) ? 1.f : 0.f;
-          }
-        } else {
-#pragma unroll
-          for (int x = 0; x < 16; ++x) {
-            const int row = rbase + (x & 3) + 8 * (x >> 2);
-            mk[x] = (col_ok && row < g.M) ? g.mask[(size_t)row * g.ldmask + col] : 0.f;
-          }
-        }
-      }
-#pragma unroll
-      for (int x = 0; x < 16; ++x) {
-        const int row = rbase + (x & 3) + 8 * (x >> 2);
-        float v = g.alpha * acc[a][b][x] + bias;
-        if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-        if (epi == ADDHIP_EPI_MASK) v = mk[x] > 0.f ? v : 0.f;
-        if (col_ok && row < g.M) {
-          if (accum) unsafeAtomicAdd(&C[(size_t)row * g.ldc + col], v);
-          else C[(size_t)row * g.ldc + col] = v;
-          if (epi == ADDHIP_EPI_MASK) cs += v;
-        }
-        if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {  // uniform branch; lanes 0-31 hold one row, lanes 32-63 the row 4 below
-          const unsigned long long pos = __ballot(col_ok && row < g.M && v > 0.f);
-          if (li == 0 && row < g.M && cgroup < g.N) g.relu_bits[(size_t)row * g.ldbits + (cgroup >> 5)] = lh ? (unsigned)(pos >> 32) : (unsigned)pos;
-        }
-      }
-      if (epi == ADDHIP_EPI_MASK && g.colsum) {
-        cs += __shfl_xor(cs, 32, 64);  // the two lane halves hold the other rows of the same column
-        if (lh == 0 && col_ok) atomicAdd(&g.colsum[col], cs);
-      }
-    }
-  }
+  // epilogue (gemm_epilogue.h): every wave's block leaves through its private slice of the (now idle) stage buffers
+  // (the loop's last barrier is behind every read of them)
+  addhip_epi::gemm_epilogue<FM, FN, EPI>(g, acc, reinterpret_cast<char*>(lds) + wave * addhip_epi::EpiBuf<FN>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0);
 }
 
 template <int BM, int BN, int WM, int WN, int BK>

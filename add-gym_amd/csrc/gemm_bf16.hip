@@ -12,6 +12,7 @@
 //
 // Replaces (in bf16 mode): the torch.nn.Linear forward/backward of PPOModel / ADDModel (ppo_model.py:13-21, add_model.py:12-15).
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -19,7 +20,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
-constexpr int EPI_RUNTIME = -1;
+using addhip_epi::EPI_RUNTIME;
+using addhip_epi::EpiBuf;
+using addhip_epi::gemm_epilogue;
 // 128x128 tile configurations (gemm_bf16_kernel): 0 = 4 waves of 64x64, two 64-deep LDS stages, 2 workgroups per CU;
 // 1 = the same tile, one stage, 3-4 workgroups per CU covering for each other.  (The 256x256 tile: gemm_bf16_q_kernel below.)
 template <int CFG> struct Cfg {
@@ -132,106 +135,6 @@ struct FragMC {
 template <bool KC, int ROWS, int MT, int BKS> struct FragSel { typedef FragKC<BKS> type; };
 template <int ROWS, int MT, int BKS> struct FragSel<false, ROWS, MT, BKS> { typedef FragMC<ROWS, MT> type; };
 
-// Epilogue of a wave's (MT*32) x 64 accumulator block whose first element is (row0, col0) of C.  In the accumulators a lane owns
-// ONE column (col0+b*32+li) and register x is row (x&3)+8*(x>>2)+4*lh of the 32x32 tile: bias, ReLU, mask, sign bits and the
-// bias-gradient column sums are done in that layout, then each 32-row slice goes through a wave-private LDS buffer and leaves as
-// 16-byte stores along the rows (2-byte and 4-byte stores straight from the accumulators cost 4-8x the store instructions,
-// which is what a short-K launch then spends its time on).  The caller has passed a barrier behind the last LDS stage.
-constexpr int ERS = 64 * 4 + 16;  // bytes per staged row: 64 fp32 + one 16-byte pad
-template <int MT, int EPI>
-__device__ __forceinline__ void epilogue(const addhip_gemm_t& g, f32x16 (&acc)[MT][2], char* lds, int wave, int lane, int row0, int col0) {
-  const int li = lane & 31, lh = lane >> 5;
-  const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
-  float* C = g.C ? g.C + (size_t)blockIdx.z * (size_t)g.M * g.ldc : nullptr;
-  u16* C16 = reinterpret_cast<u16*>(g.C16);
-  char* ebuf = lds + wave * (32 * ERS);
-  const bool c_vec = C && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (g.ldc & 3) == 0;
-  const bool c16_vec = C16 && (reinterpret_cast<uintptr_t>(C16) & 15) == 0 && (g.ldc16 & 7) == 0;
-#pragma unroll
-  for (int a = 0; a < MT; ++a) {
-    const int rtile = row0 + a * 32;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int cgroup = col0 + b * 32, col = cgroup + li;
-      const bool col_ok = col < g.N;
-      const float bias = (col_ok && (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU)) ? g.bias[col] : 0.f;
-      // sign-bit word of tile row `lane` (lanes 0..31), fetched once and handed out by readlane
-      unsigned mword = 0u;
-      if (epi == ADDHIP_EPI_MASK && g.mask_bits && lane < 32 && cgroup < g.N && rtile + lane < g.M)
-        mword = g.mask_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)];
-      unsigned rword = 0u;  // lanes 0..31: the ReLU sign-bit word of tile row `lane`
-      float cs = 0.f;
-#pragma unroll
-      for (int x = 0; x < 16; ++x) {
-        const int r0 = (x & 3) + 8 * (x >> 2), rloc = r0 + 4 * lh, row = rtile + rloc;
-        const bool ok = col_ok && row < g.M;
-        float v = g.alpha * acc[a][b][x] + bias;
-        if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-        if (epi == ADDHIP_EPI_MASK) {
-          if (g.mask_bits) {
-            const unsigned w0 = __builtin_amdgcn_readlane(mword, r0), w1 = __builtin_amdgcn_readlane(mword, r0 + 4);
-            v = (((lh ? w1 : w0) >> li) & 1u) ? v : 0.f;
-          } else {
-            v = (ok && g.mask[(size_t)row * g.ldmask + col] > 0.f) ? v : 0.f;
-          }
-          if (ok) cs += v;
-        }
-        if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {
-          const unsigned long long pos = __ballot(ok && v > 0.f);
-          rword = lane == r0 ? (unsigned)pos : lane == r0 + 4 ? (unsigned)(pos >> 32) : rword;
-        }
-        *reinterpret_cast<float*>(ebuf + rloc * ERS + (b * 32 + li) * 4) = v;
-      }
-      if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits && lane < 32 && cgroup < g.N && rtile + lane < g.M)
-        g.relu_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)] = rword;
-      if (epi == ADDHIP_EPI_MASK && g.colsum) {
-        cs += __shfl_xor(cs, 32, 64);
-        if (lh == 0 && col_ok) atomicAdd(&g.colsum[col], cs);
-      }
-    }
-    if (C) {  // 16 lanes x 4 columns per row, 4 rows per instruction
-      const int c4 = (lane & 15) * 4, col = col0 + c4;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rloc = (lane >> 4) + 4 * i, row = rtile + rloc;
-        const float4 v = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c4 * 4);
-        if (row < g.M) {
-          float* dst = C + (size_t)row * g.ldc + col;
-          if (c_vec && col + 3 < g.N) {
-            *reinterpret_cast<float4*>(dst) = v;
-          } else {
-            const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (col + j < g.N) dst[j] = e[j];
-          }
-        }
-      }
-    }
-    if (C16) {  // 8 lanes x 8 columns per row, 8 rows per instruction
-      const int c8 = (lane & 7) * 8, col = col0 + c8;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rloc = (lane >> 3) + 8 * i, row = rtile + rloc;
-        const float4 lo = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4);
-        const float4 hi = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4 + 16);
-        if (row < g.M) {
-          u16* dst = C16 + (size_t)row * g.ldc16 + col;
-          const u16 e[8] = {to_bf16(lo.x), to_bf16(lo.y), to_bf16(lo.z), to_bf16(lo.w), to_bf16(hi.x), to_bf16(hi.y), to_bf16(hi.z), to_bf16(hi.w)};
-          if (c16_vec && col + 7 < g.N) {
-            *reinterpret_cast<uint4*>(dst) = make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
-                                                         e[6] | ((unsigned)e[7] << 16));
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (col + j < g.N) dst[j] = e[j];
-          }
-        }
-      }
-    }
-  }
-}
-
 template <bool AKC, bool BKC, int EPI, int CFG>
 __global__ __launch_bounds__(256, CFG == 1 ? ((AKC && BKC) ? 4 : 3) : 2) void gemm_bf16_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
   typedef Cfg<CFG> Q;
@@ -333,7 +236,7 @@ __global__ __launch_bounds__(256, CFG == 1 ? ((AKC && BKC) ? 4 : 3) : 2) void ge
   }
 
   __syncthreads();  // every wave is done with the last stage: LDS becomes the waves' private epilogue buffers
-  epilogue<MT, EPI>(g, acc, lds, wave, lane, m0 + wm0, n0 + wn0);
+  gemm_epilogue<MT, 2, EPI>(g, acc, lds + wave * EpiBuf<2>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -383,7 +286,7 @@ struct QStager {
 template <bool AKC, bool BKC, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_q_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
   __shared__ __attribute__((aligned(1024))) char lds[Q_NS * Q_UNIT];
-  static_assert(Q_NS * Q_UNIT >= 8 * 32 * ERS, "the epilogue buffers must fit");
+  static_assert(Q_NS * Q_UNIT >= 8 * EpiBuf<2>::WAVE_BYTES, "the epilogue buffers must fit");
   const int total = tiles_m * tiles_n;
   const int orig = blockIdx.x;
   const int q = total >> 3, r = total & 7, xcd = orig & 7;
@@ -491,7 +394,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_q_kernel(addhip_gemm_t g, in
     }
   }
   __syncthreads();
-  epilogue<4, EPI>(g, acc, lds, wave, lane, m0 + wm * 128, n0 + wn * 64);
+  gemm_epilogue<4, 2, EPI>(g, acc, lds + wave * EpiBuf<2>::WAVE_BYTES, lane, m0 + wm * 128, n0 + wn * 64);
 }
 
 // fp32 -> bf16 (round to nearest even), row by row: dst[r*ld_dst + c] = bf16(src[r*ld_src + c]), cols % 4 == 0

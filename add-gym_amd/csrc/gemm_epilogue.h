@@ -1,0 +1,123 @@
+// Shared epilogue of the MFMA GEMM kernels (gemm.hip, gemm_split.hip, gemm_bf16.hip): one implementation of the bias / ReLU /
+// mask epilogues, the ReLU sign bits, the fused bias-gradient column sums and the write-out of C (fp32, optionally added by
+// atomics) and C16 (bf16, round to nearest even).
+#pragma once
+#include "common.h"
+
+namespace addhip_epi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int EPI_RUNTIME = -1;  // epilogue chosen from the descriptor at run time (cold combinations)
+
+// fp32 -> bf16, round to nearest even (no NaN special-casing: the callers' values are finite)
+__device__ __forceinline__ unsigned short epi_bf16(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// Epilogue of a wave's (MT*32) x (NT*32) accumulator block (v_mfma_f32_32x32x* layout) whose first element is (row0, col0) of C.  In the accumulators a lane owns
+// ONE column (col0+b*32+li) and register x is row (x&3)+8*(x>>2)+4*lh of the 32x32 tile: bias, ReLU, mask, sign bits and the
+// bias-gradient column sums are done in that layout, then each 32-row slice goes through a wave-private LDS buffer and leaves as
+// 16-byte stores along the rows (2-byte and 4-byte stores straight from the accumulators cost 4-8x the store instructions,
+// which is what a short-K launch then spends its time on).  The caller has passed a barrier behind the last LDS stage.
+template <int NT> struct EpiBuf { static constexpr int ERS = NT * 128 + 16, WAVE_BYTES = 32 * ERS; };  // bytes per staged row (+ one 16-byte pad), per wave
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&acc)[MT][NT], char* ebuf, int lane, int row0, int col0) {
+  constexpr int ERS = EpiBuf<NT>::ERS;
+  typedef unsigned short u16;
+  const int li = lane & 31, lh = lane >> 5;
+  const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
+  const bool accum = g.accumulate != 0;  // K slices add into one C (hardware fp32 atomics) instead of writing slabs
+  float* C = g.C ? g.C + (accum ? (size_t)0 : (size_t)blockIdx.z * (size_t)g.M * g.ldc) : nullptr;
+  u16* C16 = reinterpret_cast<u16*>(g.C16);
+  const bool c_vec = C && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (g.ldc & 3) == 0;
+  const bool c16_vec = C16 && (reinterpret_cast<uintptr_t>(C16) & 15) == 0 && (g.ldc16 & 7) == 0;
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    const int rtile = row0 + a * 32;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int cgroup = col0 + b * 32, col = cgroup + li;
+      const bool col_ok = col < g.N;
+      const float bias = (col_ok && (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU)) ? g.bias[col] : 0.f;
+      // sign-bit word of tile row `lane` (lanes 0..31), fetched once and handed out by readlane
+      unsigned mword = 0u;
+      if (epi == ADDHIP_EPI_MASK && g.mask_bits && lane < 32 && cgroup < g.N && rtile + lane < g.M)
+        mword = g.mask_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)];
+      unsigned rword = 0u;  // lanes 0..31: the ReLU sign-bit word of tile row `lane`
+      float cs = 0.f;
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int r0 = (x & 3) + 8 * (x >> 2), rloc = r0 + 4 * lh, row = rtile + rloc;
+        const bool ok = col_ok && row < g.M;
+        float v = g.alpha * acc[a][b][x] + bias;
+        if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        if (epi == ADDHIP_EPI_MASK) {
+          if (g.mask_bits) {
+            const unsigned w0 = __builtin_amdgcn_readlane(mword, r0), w1 = __builtin_amdgcn_readlane(mword, r0 + 4);
+            v = (((lh ? w1 : w0) >> li) & 1u) ? v : 0.f;
+          } else {
+            v = (ok && g.mask[(size_t)row * g.ldmask + col] > 0.f) ? v : 0.f;
+          }
+          if (ok) cs += v;
+        }
+        if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {
+          const unsigned long long pos = __ballot(ok && v > 0.f);
+          rword = lane == r0 ? (unsigned)pos : lane == r0 + 4 ? (unsigned)(pos >> 32) : rword;
+        }
+        *reinterpret_cast<float*>(ebuf + rloc * ERS + (b * 32 + li) * 4) = v;
+      }
+      if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits && lane < 32 && cgroup < g.N && rtile + lane < g.M)
+        g.relu_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)] = rword;
+      if (epi == ADDHIP_EPI_MASK && g.colsum) {
+        cs += __shfl_xor(cs, 32, 64);
+        if (lh == 0 && col_ok) atomicAdd(&g.colsum[col], cs);
+      }
+    }
+    if (C) {  // NT*8 lanes x 4 columns per row
+      constexpr int CPR = NT * 8;
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) {
+        const int idx = lane + 64 * i, rloc = idx / CPR, c4 = (idx % CPR) * 4, row = rtile + rloc, col = col0 + c4;
+        const float4 v = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c4 * 4);
+        if (row < g.M) {
+          float* dst = C + (size_t)row * g.ldc + col;
+          if (c_vec && !accum && col + 3 < g.N) {
+            *reinterpret_cast<float4*>(dst) = v;
+          } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (col + j < g.N) {
+                if (accum) unsafeAtomicAdd(&dst[j], e[j]);
+                else dst[j] = e[j];
+              }
+          }
+        }
+      }
+    }
+    if (C16) {  // NT*4 lanes x 8 columns per row
+      constexpr int CPR = NT * 4;
+#pragma unroll
+      for (int i = 0; i < NT * 2; ++i) {
+        const int idx = lane + 64 * i, rloc = idx / CPR, c8 = (idx % CPR) * 8, row = rtile + rloc, col = col0 + c8;
+        const float4 lo = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4);
+        const float4 hi = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4 + 16);
+        if (row < g.M) {
+          u16* dst = C16 + (size_t)row * g.ldc16 + col;
+          const u16 e[8] = {epi_bf16(lo.x), epi_bf16(lo.y), epi_bf16(lo.z), epi_bf16(lo.w), epi_bf16(hi.x), epi_bf16(hi.y), epi_bf16(hi.z), epi_bf16(hi.w)};
+          if (c16_vec && col + 7 < g.N) {
+            *reinterpret_cast<uint4*>(dst) = make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
+                                                         e[6] | ((unsigned)e[7] << 16));
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (col + j < g.N) dst[j] = e[j];
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace addhip_epi

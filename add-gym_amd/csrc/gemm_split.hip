@@ -14,6 +14,7 @@
 // with a 16-byte pad per row (row stride 112 B = 28 dwords: a ds_read_b128 lane group covers all 64 banks); K advances 16
 // per stage, LDS double-buffered, the next stage prefetched global -> VGPR while the current one feeds the MFMAs.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include <type_traits>
 
 namespace {
@@ -22,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int EPI_RUNTIME = -1;
+using addhip_epi::EPI_RUNTIME;
 
 template <int PLANES>
 struct Img {
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
   static_assert(!NORM || AKC, "fused normalisation needs a k-contiguous A");
   using I = Img<PLANES>;
   constexpr int STAGE = 2 * I::SIZE;
-  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  constexpr int EPI_BYTES = 4 * addhip_epi::EpiBuf<2>::WAVE_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES];
   constexpr int NORM_MAXK = 512;  // fused normalisation: the first layer's K (= obs_stride)
   __shared__ __attribute__((aligned(16))) float nmean[NORM ? NORM_MAXK : 4], nstd[NORM ? NORM_MAXK : 4];
 
@@ -268,60 +270,10 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
       for (int b = 0; b < 2; ++b) mfma_group(a, b, fa, fb);
   }
 
-  // epilogue: lane owns column n0+wn0+b*32+li; register x is row (x&3)+8*(x>>2)+4*lh of the 32x32 tile
-  const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
-  const bool accum = g.accumulate != 0;  // K slices add into one C (hardware fp32 atomics) instead of writing slabs
-  float* C = g.C + (accum ? (size_t)0 : (size_t)blockIdx.z * (size_t)g.M * g.ldc);
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int col = n0 + wn0 + b * 32 + li;
-    const bool col_ok = col < g.N;
-    const float bias = (col_ok && (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU)) ? g.bias[col] : 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int rbase = m0 + wm0 + a * 32 + 4 * lh;
-      float mk[16];
-      float cs = 0.f;
-      // word of the ReLU sign bits this lane's 32-column group lives in (relu_bits / mask_bits)
-      const int cgroup = n0 + wn0 + b * 32;
-      if (epi == ADDHIP_EPI_MASK) {  // all 16 mask loads in flight before any use
-        if (g.mask_bits) {  // 1 bit per element: the 32 lanes of a half read the same word
-#pragma unroll
-          for (int x = 0; x < 16; ++x) {
-            const int row = rbase + (x & 3) + 8 * (x >> 2);
-            const unsigned wbits = (cgroup < g.N && row < g.M) ? g.mask_bits[(size_t)row * g.ldbits + (cgroup >> 5)] : 0u;
-            mk[x] = ((wbits >> li) & 1u) ? 1.f : 0.f;
-          }
-        } else {
-#pragma unroll
-          for (int x = 0; x < 16; ++x) {
-            const int row = rbase + (x & 3) + 8 * (x >> 2);
-            mk[x] = (col_ok && row < g.M) ? g.mask[(size_t)row * g.ldmask + col] : 0.f;
-          }
-        }
-      }
-#pragma unroll
-      for (int x = 0; x < 16; ++x) {
-        const int row = rbase + (x & 3) + 8 * (x >> 2);
-        float v = g.alpha * acc[a][b][x] + bias;
-        if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-        if (epi == ADDHIP_EPI_MASK) v = mk[x] > 0.f ? v : 0.f;
-        if (col_ok && row < g.M) {
-          if (accum) unsafeAtomicAdd(&C[(size_t)row * g.ldc + col], v);
-          else C[(size_t)row * g.ldc + col] = v;
-          if (epi == ADDHIP_EPI_MASK) cs += v;
-        }
-        if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {  // uniform branch; lanes 0-31 hold one row, lanes 32-63 the row 4 below
-          const unsigned long long pos = __ballot(col_ok && row < g.M && v > 0.f);
-          if (li == 0 && row < g.M && cgroup < g.N) g.relu_bits[(size_t)row * g.ldbits + (cgroup >> 5)] = lh ? (unsigned)(pos >> 32) : (unsigned)pos;
-        }
-      }
-      if (epi == ADDHIP_EPI_MASK && g.colsum) {
-        cs += __shfl_xor(cs, 32, 64);
-        if (lh == 0 && col_ok) atomicAdd(&g.colsum[col], cs);
-      }
-    }
-  }
+  // epilogue (gemm_epilogue.h): every wave's block leaves through its private slice of the stage buffers, once every wave is done
+  // reading them
+  __syncthreads();
+  addhip_epi::gemm_epilogue<2, 2, EPI>(g, acc, lds + wave * addhip_epi::EpiBuf<2>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0);
 }
 
 template <int PLANES>
