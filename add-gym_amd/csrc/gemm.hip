@@ -98,8 +98,8 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int kk, i
 using addhip_epi::EPI_RUNTIME;
 
 // EPI: compile-time epilogue (ADDHIP_EPI_*) or EPI_RUNTIME; NORM: fused (a-mean)/std on A
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int BK, int EPI, bool NORM>
-__global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int BK, int EPI, bool NORM, bool SB>
+__global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
   static_assert(WM * WN == 4, "4 wavefronts");
   static_assert(!NORM || AKC, "fused normalisation needs a k-contiguous A");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
   using TB = Tile<BN, BKC, BK>;
   constexpr int STAGE = TA::SIZE + TB::SIZE;
   constexpr int EPI_FLOATS = 4 * addhip_epi::EpiBuf<FN>::WAVE_BYTES / 4;
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE > EPI_FLOATS ? 2 * STAGE : EPI_FLOATS];
+  constexpr int NSTAGE = SB ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE > EPI_FLOATS ? NSTAGE * STAGE : EPI_FLOATS];
 
   // XCD-aware remap (blocks b and b+8 share an XCD): give each XCD a contiguous run of tiles,
   // N-tile fastest, so the N-tiles of one A row-panel hit the same L2.  Bijective for any count.
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+    const int cur = SB ? 0 : (kt & 1);
     const float* a_cur = lds + cur * STAGE;
     const float* b_cur = a_cur + TA::SIZE;
     const bool more = kt + 1 < nk;
@@ -179,9 +180,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
         }
     }
+    if (SB) __syncthreads();  // one stage buffer: every wave is done reading it before the next tile goes in
     if (more) {
-      store_tile<BM, AKC, BK>(lds + (cur ^ 1) * STAGE, ra);
-      store_tile<BN, BKC, BK>(lds + (cur ^ 1) * STAGE + TA::SIZE, rb);
+      store_tile<BM, AKC, BK>(lds + (SB ? 0 : (cur ^ 1)) * STAGE, ra);
+      store_tile<BN, BKC, BK>(lds + (SB ? 0 : (cur ^ 1)) * STAGE + TA::SIZE, rb);
     }
     __syncthreads();
   }
@@ -191,14 +193,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(addhip_gemm_t g, int tiles_m,
   addhip_epi::gemm_epilogue<FM, FN, EPI>(g, acc, reinterpret_cast<char*>(lds) + wave * addhip_epi::EpiBuf<FN>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0);
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK, bool SB = false>
 int launch_cfg(const addhip_gemm_t& g, hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int split = g.split_k > 1 ? g.split_k : 1;
   dim3 grid(tiles_m * tiles_n, 1, split), block(256);
   const bool norm = g.a_mean != nullptr;
 #define ADDHIP_LAUNCH(AK, BKc, EPI, NORM) \
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AK, BKc, BK, EPI, NORM>), grid, block, 0, st, g, tiles_m, tiles_n)
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AK, BKc, BK, EPI, NORM, SB>), grid, block, 0, st, g, tiles_m, tiles_n)
   // hot combinations get a compile-time epilogue; everything else shares the run-time one
   if (g.a_kcontig && g.b_kcontig) {
     if (norm) {
@@ -411,6 +413,13 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
                       (long long)((g.M + 127) / 128) * ((g.N + 95) / 96) * (g.split_k > 1 ? g.split_k : 1) >= 256;
   if (g.precision != ADDHIP_PREC_F32) return addhip::gemm_split_dispatch(g, g.precision, st);
   if (narrow) return launch_cfg<128, 96, 4, 1, 32>(g, st);
+  // launches with enough workgroups for 4 per CU run one LDS stage (37 KB) x 4 workgroups per CU instead of two stages x 2:
+  // alone they time the same, beside the other streams' launches of an update step they overlap better (update phase -2 %)
+  {
+    static const char* sb = getenv("ADDHIP_F32_SB");
+    const bool many = (long long)tiles128 * (g.split_k > 1 ? g.split_k : 1) >= 512;
+    if (sb ? sb[0] == '1' : many) return launch_cfg<128, 128, 2, 2, 32, true>(g, st);
+  }
   return launch_cfg<128, 128, 2, 2, 32>(g, st);
 }
 
