@@ -27,6 +27,20 @@ from ..util.tb_logger import TBLogger
 from .model import Model, NetRunner, Plan
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev):
+    """The three side streams of the update step, created ONCE per process and device and shared by every agent: HIP maps streams
+    onto a few hardware queues in creation order, so a second agent's fresh streams can land on the queue of the main stream
+    and silently serialise against it (measured: the same bf16 iteration 54 ms as the first agent of a process, 79 ms as the
+    second).  The discriminator's section is the step's longest chain: its two streams get the higher priority."""
+    key = torch.device(dev).index or 0
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=-1)]
+    return _SIDE_STREAMS[key]
+
+
 class AgentMode:
     TRAIN, TEST = 0, 1
 
@@ -229,8 +243,7 @@ class ADDAgent:
             self._eval_disc = NetRunner(m, m.disc, self._eval_rows, dev, None, self._prec_small)
         else:
             self._roll_actor, self._eval_critic, self._eval_disc = self._run_actor, self._run_critic, self._run_disc
-        # (the discriminator's section is the step's longest chain: its two streams get the higher priority)
-        self._side_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=-1)]
+        self._side_streams = _side_streams(dev)
         OS, DS = self._task.obs_stride, self._task.disc_stride
         hd = m.disc.hidden
         self._W = dict(mean=z(rows, 32), d_mean=z(rows, 32), noise=z(N, L.NUM_DOF), explore_u=z(N), u=z(3, N), logits=z(rows), nv=z(1),

@@ -336,8 +336,7 @@ def main():
                             "frac": gbs2 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src, "us_per_launch": ms2 * 1e3, "envs": big,
                             "motion_library": motion, "step_tables_mb": table_mb}
             out["roofline_rigid_step"] = rigid_step_roofline(a.envs)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_envs, agent.T)
+    steps_per_iter = agent.T
     if a.precision == "fp32" and not a.no_alt:
         # Same workload with the bf16-MFMA product modes of addhip_gemm_f32 (operands, results and every other kernel stay fp32;
         # include/addhip.h ADDHIP_PREC_*), reported beside the headline, which stays on the fp32 MFMA instruction:
@@ -369,6 +368,10 @@ def main():
                                  "value": env_steps / dt3, "unit": "env-steps/s", "ms_per_step": 1000.0 * dt3 / a.steps,
                                  "matmul_precision": a.precision}
         del agent3
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # last: the oracle's 16 torch-CPU threads keep spinning after their parallel regions, and the launch-bound GPU runs above
+        # (the bf16 modes enqueue ~90 kernels per 1.1 ms optimiser step) slow down when they share the host cores with them
+        out["cpu_baseline"] = cpu_baseline(a.cpu_envs, steps_per_iter)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
