@@ -98,7 +98,7 @@ def gemm_roofline(agent, precision):
         peak = MFMA_BF16_PEAK_TFLOPS / products
         kern = ("gemm_bf16_kernel (bf16 operands in HBM, " if precision == "bf16" else "gemm_split_kernel (") + \
                "v_mfma_f32_32x32x16_bf16 x %d per k-step; small shapes stay on gemm_kernel); all GEMM launches of one optimiser step" % products
-        tr, tr_src = None, None
+        tr, tr_src = traffic("gemm_bf16_step") if precision == "bf16" else (None, None)
     return {"bound": "mfma", "kernel": kern, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": tr, "traffic_source": tr_src,
             "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"],
             "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS}
