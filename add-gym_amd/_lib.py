@@ -114,10 +114,10 @@ SIGNATURES = {
     "addhip_count_mask": [vp, i32, vp, vp],
     "addhip_critic_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
     "addhip_disc_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
-    "addhip_head_backward": [vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp],
+    "addhip_head_backward": [vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp],
     "addhip_outer_mask": [vp, vp, vp, i32, i32, i64, vp, vp],
-    "addhip_bcast_mask": [vp, vp, i32, i32, i64, vp, vp],
-    "addhip_grad_penalty": [vp, i32, i32, i32, f32, vp, vp, vp],
+    "addhip_bcast_mask": [vp, vp, i32, i32, i64, vp, vp, vp],
+    "addhip_grad_penalty": [vp, i32, i32, i32, f32, vp, vp, vp, vp],
     "addhip_weighted_col_sum": [vp, vp, i32, i32, i64, vp, f32, i32, vp],
     "addhip_l2_grad": [vp, vp, i64, f32, vp, vp],
     "addhip_grad_clip": [vp, i64, f32, vp, vp, vp],

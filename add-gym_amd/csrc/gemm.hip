@@ -369,8 +369,7 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   ADDHIP_REQUIRE(gp, "null gemm descriptor");
   addhip_gemm_t g = *gp;
   ADDHIP_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem %d x %d x %d", g.M, g.N, g.K);
-  ADDHIP_REQUIRE(g.A && g.B && (g.C || (g.operands_bf16 && g.C16)), "gemm: null operand");
-  ADDHIP_REQUIRE(g.operands_bf16 || !g.C16, "gemm: a bf16 result copy (C16) is written by the bf16-storage path only");
+  ADDHIP_REQUIRE(g.A && g.B && (g.C || g.C16), "gemm: null operand");
   ADDHIP_REQUIRE(aligned16(g.A) && aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0), "gemm: operands must be 16-byte aligned with ld %% 4 == 0");
   if (g.a_kcontig) ADDHIP_REQUIRE(g.K % 4 == 0, "gemm: K must be a multiple of 4 for a k-contiguous A");
   else ADDHIP_REQUIRE(g.M % 4 == 0, "gemm: M must be a multiple of 4 for an m-contiguous A");

@@ -27,6 +27,15 @@ __device__ __forceinline__ float block_sum(float v, float* sh /*[4]*/) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// fp32 -> bf16, round to nearest even (finite inputs), as addhip_to_bf16
+__device__ __forceinline__ unsigned short bf16_rne(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ uint2 bf16_pack4(float4 o) {
+  return make_uint2((unsigned)bf16_rne(o.x) | ((unsigned)bf16_rne(o.y) << 16), (unsigned)bf16_rne(o.z) | ((unsigned)bf16_rne(o.w) << 16));
+}
+
 inline int row_grid(long long rows) {  // 4 waves (rows) per 256-thread block, grid-stride
   long long g = (rows + 3) / 4;
   return (int)(g < 2048 ? g : 2048);
@@ -310,11 +319,6 @@ __global__ void diffnorm_merge_kernel(float* mean_abs, long long* count, float* 
 }
 
 // ------------------------------------------------------------------ minibatch gather
-// fp32 -> bf16, round to nearest even (finite inputs), as addhip_to_bf16
-__device__ __forceinline__ unsigned short bf16_rne(float v) {
-  const unsigned u = __float_as_uint(v);
-  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
 __global__ __launch_bounds__(256) void gather_kernel(addhip_gather_t g) {
   const int lane = threadIdx.x & 63;
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < g.count; r += gridDim.x * 4) {
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(256) void disc_head_kernel(const float* H, int ld, 
   if (threadIdx.x == 0) { atomicAdd(&stats[0], t0); atomicAdd(&stats[2], t2); atomicAdd(&stats[4], t4); }
 }
 
-__global__ void outer_mask_kernel(const float* v, const float* w, const float* H, int ld, int K, long long rows, float* out) {
+__global__ void outer_mask_kernel(const float* v, const float* w, const float* H, int ld, int K, long long rows, float* out, unsigned short* out16) {
   const long long n = rows * (K / 4);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     long long r = i / (K / 4);
@@ -469,7 +473,8 @@ __global__ void outer_mask_kernel(const float* v, const float* w, const float* H
     float4 ww = *reinterpret_cast<const float4*>(w + k);
     float s = v ? v[r] : 1.f;
     float4 o = make_float4(h.x > 0.f ? s * ww.x : 0.f, h.y > 0.f ? s * ww.y : 0.f, h.z > 0.f ? s * ww.z : 0.f, h.w > 0.f ? s * ww.w : 0.f);
-    *reinterpret_cast<float4*>(out + r * ld + k) = o;
+    if (out) *reinterpret_cast<float4*>(out + r * ld + k) = o;
+    if (out16) *reinterpret_cast<uint2*>(out16 + r * ld + k) = bf16_pack4(o);
   }
 }
 
@@ -481,7 +486,7 @@ __global__ void outer_mask_kernel(const float* v, const float* w, const float* H
 // A lane owns the same columns for every row its wave visits, so the column sums are per-lane registers; the four waves
 // of a workgroup are combined in LDS and each workgroup issues one atomic per column.  K <= 1024.
 __global__ __launch_bounds__(256) void head_backward_kernel(const float* v, const float* w, const float* H, int ld, int K, long long rows, float* dZ,
-                                                            float* dW, float* db, float* dbt) {
+                                                            unsigned short* dZ16, float* dW, float* db, float* dbt) {
   __shared__ float red[4][1024];
   __shared__ float sh[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -500,6 +505,7 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* v, cons
         const float4 ww = *reinterpret_cast<const float4*>(w + k);
         const float4 o = make_float4(h.x > 0.f ? s * ww.x : 0.f, h.y > 0.f ? s * ww.y : 0.f, h.z > 0.f ? s * ww.z : 0.f, h.w > 0.f ? s * ww.w : 0.f);
         if (dZ) *reinterpret_cast<float4*>(dZ + r * ld + k) = o;
+        if (dZ16) *reinterpret_cast<uint2*>(dZ16 + r * ld + k) = bf16_pack4(o);
         gw[j].x += s * h.x; gw[j].y += s * h.y; gw[j].z += s * h.z; gw[j].w += s * h.w;
         gb[j].x += o.x; gb[j].y += o.y; gb[j].z += o.z; gb[j].w += o.w;
       }
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* v, cons
   if (threadIdx.x == 0 && db) atomicAdd(db, t);
 }
 
-__global__ __launch_bounds__(256) void grad_penalty_kernel(const float* g, int ld, int dim, int M, float coef, float* G, float* stats) {
+__global__ __launch_bounds__(256) void grad_penalty_kernel(const float* g, int ld, int dim, int M, float coef, float* G, unsigned short* G16, float* stats) {
   __shared__ float sh[4];
   const int lane = threadIdx.x & 63;
   float sp = 0.f;
@@ -531,7 +537,11 @@ __global__ __launch_bounds__(256) void grad_penalty_kernel(const float* g, int l
     sq = wave_sum(sq);
     float n = sqrtf(sq + 1e-8f);  // add_agent.py:176
     float f = coef * 2.f * (n - 1.f) / n / (float)M;
-    for (int c = lane; c < ld; c += 64) G[(size_t)r * ld + c] = c < dim ? f * g[(size_t)r * ld + c] : 0.f;
+    for (int c = lane; c < ld; c += 64) {
+      const float o = c < dim ? f * g[(size_t)r * ld + c] : 0.f;
+      if (G) G[(size_t)r * ld + c] = o;
+      if (G16) G16[(size_t)r * ld + c] = bf16_rne(o);
+    }
     if (lane == 0) sp += (n - 1.f) * (n - 1.f);
   }
   float t = block_sum(sp, sh);
@@ -792,26 +802,26 @@ extern "C" int addhip_disc_head(const float* H, int32_t ld, int32_t K, int32_t M
 
 extern "C" int addhip_outer_mask(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, void* stream) {
   ADDHIP_REQUIRE(v && w && H && out && rows > 0 && K % 4 == 0 && ld % 4 == 0, "outer_mask: bad arguments");
-  hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, out);
+  hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, out, (unsigned short*)nullptr);
   return addhip::check_launch("outer_mask_kernel");
 }
-extern "C" int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, void* stream) {
-  ADDHIP_REQUIRE(w && H && out && rows > 0 && K % 4 == 0 && ld % 4 == 0, "bcast_mask: bad arguments");
-  hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, (const float*)nullptr, w, H, ld, K, (long long)rows, out);
+extern "C" int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, uint16_t* out16, void* stream) {
+  ADDHIP_REQUIRE(w && H && (out || out16) && rows > 0 && K % 4 == 0 && ld % 4 == 0, "bcast_mask: bad arguments");
+  hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, (const float*)nullptr, w, H, ld, K, (long long)rows, out, out16);
   return addhip::check_launch("outer_mask_kernel(bcast)");
 }
 
-extern "C" int addhip_head_backward(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* dZ, float* dW_head,
-                                    float* db_head, float* db_top, void* stream) {
+extern "C" int addhip_head_backward(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* dZ, uint16_t* dZ16,
+                                    float* dW_head, float* db_head, float* db_top, void* stream) {
   ADDHIP_REQUIRE(v && w && H && rows > 0 && K > 0 && K <= 1024 && K % 4 == 0 && ld % 4 == 0 && ld >= K, "head_backward: bad arguments (K <= 1024)");
   const int grid = row_grid(rows) < 256 ? row_grid(rows) : 256;
-  hipLaunchKernelGGL(head_backward_kernel, dim3(grid), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, dZ, dW_head, db_head, db_top);
+  hipLaunchKernelGGL(head_backward_kernel, dim3(grid), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, dZ, dZ16, dW_head, db_head, db_top);
   return addhip::check_launch("head_backward_kernel");
 }
 
-extern "C" int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, float* stats, void* stream) {
-  ADDHIP_REQUIRE(g && G && stats && M > 0 && dim <= ld, "grad_penalty: bad arguments");
-  hipLaunchKernelGGL(grad_penalty_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, g, ld, dim, M, coef, G, stats);
+extern "C" int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, uint16_t* G16, float* stats, void* stream) {
+  ADDHIP_REQUIRE(g && (G || G16) && stats && M > 0 && dim <= ld, "grad_penalty: bad arguments");
+  hipLaunchKernelGGL(grad_penalty_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, g, ld, dim, M, coef, G, G16, stats);
   return addhip::check_launch("grad_penalty_kernel");
 }
 

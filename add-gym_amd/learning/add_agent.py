@@ -300,17 +300,19 @@ class ADDAgent:
         self._gemm(p, 32, hA, Mb, L.ptr(W["d_mean"]), 32, 0, L.ptr(ra.h[-1]), hA, 0, L.ptr(self._slabs), hA, split_k=sA)
         p.add("addhip_slab_reduce", L.ptr(self._slabs), sA, 32 * hA, m.g("actor", "Wh"), 32 * hA, 1.0, 0)
         p.add("addhip_col_sum", L.ptr(W["d_mean"]), Mb, 32, 32, m.g("actor", "bh"), 1.0, 1)
-        self._gemm(p, Mb, hA, 32, L.ptr(W["d_mean"]), 32, 1, m.p("actor", "Wh"), hA, 0, L.ptr(ra.dz[-1]), hA, L.EPI_MASK,
-                   colsum=m.g("actor", f"b{len(m.actor.hidden) - 1}"), **ra.mask_args(len(m.actor.hidden) - 1, 0, Mb))
-        ra.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True, x16_ptr=x16)
+        # (bf16-storage mode: the producers of the three top gradients write them as bf16 directly -- dz16[-1] -- and skip the fp32 copy)
+        top16 = (lambda r: dict(C16=L.ptr(r.dz16[-1]), ldc16=r.net.hidden[-1])) if s16 else (lambda r: {})
+        self._gemm(p, Mb, hA, 32, L.ptr(W["d_mean"]), 32, 1, m.p("actor", "Wh"), hA, 0, None if s16 else L.ptr(ra.dz[-1]), hA, L.EPI_MASK,
+                   colsum=m.g("actor", f"b{len(m.actor.hidden) - 1}"), **top16(ra), **ra.mask_args(len(m.actor.hidden) - 1, 0, Mb))
+        ra.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True, x16_ptr=x16, top_cast_done=True)
         self._update_marks = [("actor", len(p.calls))]  # the net's gradient is complete after this many calls
         # critic
         rc.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True, x16_ptr=x16)
         p.add("addhip_critic_head", L.ptr(rc.h[-1]), hC, hC, Mb, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(W["mb_tar"]), self._critic_loss_weight * gs,
               None, L.ptr(W["dv"]), L.ptr(W["stats"]) + 4 * 8)
-        p.add("addhip_head_backward", L.ptr(W["dv"]), m.p("critic", "Wh"), L.ptr(rc.h[-1]), hC, hC, Mb, L.ptr(rc.dz[-1]), m.g("critic", "Wh"),
-              m.g("critic", "bh"), m.g("critic", f"b{len(m.critic.hidden) - 1}"))
-        rc.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True, x16_ptr=x16)
+        p.add("addhip_head_backward", L.ptr(W["dv"]), m.p("critic", "Wh"), L.ptr(rc.h[-1]), hC, hC, Mb, None if s16 else L.ptr(rc.dz[-1]),
+              L.ptr(rc.dz16[-1]) if s16 else None, m.g("critic", "Wh"), m.g("critic", "bh"), m.g("critic", f"b{len(m.critic.hidden) - 1}"))
+        rc.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True, x16_ptr=x16, top_cast_done=True)
         self._update_marks.append(("critic", len(p.calls)))
         # discriminator: Mb agent/demo differences + one zero-difference row (row Mb of norm_diff stays 0)
         Md = Mb + 1
@@ -327,36 +329,34 @@ class ADDAgent:
         d_head = len(p.calls)
         p.add("addhip_disc_head", L.ptr(rd.h[-1]), hD, hD, Mb, L.ptr(rd.h[-1]) + 4 * Mb * hD, m.p("disc", "Wh"), m.p("disc", "bh"), ls_d,
               L.ptr(W["dlogit"]), L.ptr(W["dlogit"]) + 4 * Mb, L.ptr(W["stats"]) + 4 * 12)
-        p.add("addhip_head_backward", L.ptr(W["dlogit"]), m.p("disc", "Wh"), L.ptr(rd.h[-1]), hD, hD, Md, L.ptr(rd.dz[-1]), m.g("disc", "Wh"),
-              m.g("disc", "bh"), m.g("disc", f"b{len(m.disc.hidden) - 1}"))
+        p.add("addhip_head_backward", L.ptr(W["dlogit"]), m.p("disc", "Wh"), L.ptr(rd.h[-1]), hD, hD, Md, None if s16 else L.ptr(rd.dz[-1]),
+              L.ptr(rd.dz16[-1]) if s16 else None, m.g("disc", "Wh"), m.g("disc", "bh"), m.g("disc", f"b{len(m.disc.hidden) - 1}"))
         # gradient penalty chain (hand-derived double backward, add_agent.py:166-178): g = ((w3*m2) W2 * m1) W1
         h1, h2 = rd.h[0], rd.h[1] if len(rd.h) > 1 else None
         if len(m.disc.hidden) != 2:
             raise NotImplementedError("the gradient-penalty chain is written for the 2-hidden-layer discriminator (fc_2layers_*)")
         d1, d2 = m.disc.hidden
         d_gp = len(p.calls)
-        p.add("addhip_bcast_mask", m.p("disc", "Wh"), L.ptr(h2), d2, d2, Mb, L.ptr(W["a2"]))
+        p.add("addhip_bcast_mask", m.p("disc", "Wh"), L.ptr(h2), d2, d2, Mb, None if s16 else L.ptr(W["a2"]), L.ptr(W["a2_16"]) if s16 else None)
         if s16:
-            # the same chain on bf16 operands: a2 and G are rounded once, a1 / e1 leave their GEMMs as bf16, g and da2 as fp32
-            # (the penalty and the column sum read them)
+            # the same chain on bf16 operands: a2 and G are written as bf16 by their kernels, a1 / e1 leave their GEMMs as bf16, g and
+            # da2 as fp32 (the penalty and the column sum read them)
             k16 = dict(precision=L.PREC_BF16, operands_bf16=1)
-            p.add("addhip_to_bf16", L.ptr(W["a2"]), L.ptr(W["a2_16"]), Mb, d2, d2, d2)
             self._gemm(p, Mb, d1, d2, L.ptr(W["a2_16"]), d2, 1, m.p16t("disc", "W1"), d2, 1, None, d1, L.EPI_MASK, C16=L.ptr(W["a1_16"]), ldc16=d1,
                        **k16, **rd.mask_args(0, 0, Mb))
             self._gemm(p, Mb, DS, d1, L.ptr(W["a1_16"]), d1, 1, m.p16t("disc", "W0"), d1, 1, L.ptr(W["g"]), DS, **k16)
-            p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, L.ptr(W["G"]), L.ptr(W["stats"]) + 4 * 20)
-            p.add("addhip_to_bf16", L.ptr(W["G"]), L.ptr(W["G16"]), Mb, DS, DS, DS)
+            p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, None, L.ptr(W["G16"]), L.ptr(W["stats"]) + 4 * 20)
             self._gemm(p, Mb, d1, DS, L.ptr(W["G16"]), DS, 1, m.p16("disc", "W0"), DS, 1, None, d1, L.EPI_MASK, C16=L.ptr(W["e1_16"]), ldc16=d1,
                        **k16, **rd.mask_args(0, 0, Mb))
             self._gemm(p, Mb, d2, d1, L.ptr(W["e1_16"]), d1, 1, m.p16("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **k16, **rd.mask_args(1, 0, Mb))
             p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
             d_bwd = len(p.calls)
             rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1_16"]), d1, L.ptr(W["G16"]), DS, Mb), 1: (L.ptr(W["a2_16"]), d2, L.ptr(W["e1_16"]), d1, Mb)},
-                        grads_zeroed=True, top_bias_done=True, x16_ptr=nd16, accumulate_dw=True)
+                        grads_zeroed=True, top_bias_done=True, x16_ptr=nd16, accumulate_dw=True, top_cast_done=True)
         else:
             self._gemm(p, Mb, d1, d2, L.ptr(W["a2"]), d2, 1, m.p("disc", "W1"), d1, 0, L.ptr(W["a1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
             self._gemm(p, Mb, DS, d1, L.ptr(W["a1"]), d1, 1, m.p("disc", "W0"), DS, 0, L.ptr(W["g"]), DS)
-            p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, L.ptr(W["G"]), L.ptr(W["stats"]) + 4 * 20)
+            p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, L.ptr(W["G"]), None, L.ptr(W["stats"]) + 4 * 20)
             # second-order terms: da1 = G W1^T ; e1 = da1 * m1 ; da2 = (e1 W2^T) * m2
             self._gemm(p, Mb, d1, DS, L.ptr(W["G"]), DS, 1, m.p("disc", "W0"), DS, 1, L.ptr(W["e1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
             self._gemm(p, Mb, d2, d1, L.ptr(W["e1"]), d1, 1, m.p("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **rd.mask_args(1, 0, Mb))

@@ -307,12 +307,13 @@ class NetRunner:
                 plan.add("addhip_gemm_f32", g)
             prev, ld, k = L.ptr(self.h[i]), h, h
 
-    def backward(self, plan, x_ptr, rows, extra_dw=None, grads_zeroed=False, top_bias_done=False, x16_ptr=None, accumulate_dw=False):
+    def backward(self, plan, x_ptr, rows, extra_dw=None, grads_zeroed=False, top_bias_done=False, x16_ptr=None, accumulate_dw=False, top_cast_done=False):
         """dz[-1] must hold d loss / d (pre-activation of the last hidden layer).  extra_dw: {layer: (A_ptr, lda, B_ptr, ldb)}
         second product accumulated into dW of that layer (the gradient-penalty terms).  grads_zeroed: the caller cleared the
         whole gradient buffer at the start of the step (no per-bias memsets here); top_bias_done: the kernel that produced
         dz[-1] also accumulated the top layer's bias gradient.  storage16 runners: x16_ptr = bf16 copy of the input rows, the
-        extra_dw operands are bf16 too, and the fp32 top gradient is rounded to bf16 once at the start.  accumulate_dw: the
+        extra_dw operands are bf16 too, and the fp32 top gradient is rounded to bf16 once at the start (top_cast_done: its producer
+        already wrote dz16[-1]).  accumulate_dw: the
         weight gradients are ADDED to what the gradient buffer holds (L2 terms written there earlier in the step)."""
         net, m = self.net, self.m
         n = len(net.hidden)
@@ -323,7 +324,8 @@ class NetRunner:
         acts = self.h16 if s16 else self.h
         if s16:
             assert x16_ptr is not None and grads_zeroed
-            plan.add("addhip_to_bf16", L.ptr(self.dz[n - 1]), L.ptr(self.dz16[n - 1]), rows, net.hidden[n - 1], net.hidden[n - 1], net.hidden[n - 1])
+            if not top_cast_done:
+                plan.add("addhip_to_bf16", L.ptr(self.dz[n - 1]), L.ptr(self.dz16[n - 1]), rows, net.hidden[n - 1], net.hidden[n - 1], net.hidden[n - 1])
         for i in reversed(range(n)):
             out_d = net.hidden[i]
             in_ld = net.in_ld if i == 0 else net.hidden[i - 1]

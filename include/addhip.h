@@ -358,17 +358,18 @@ int addhip_disc_head(const float* H, int32_t ld, int32_t K, int32_t M, const flo
  * dZ[r,k] = (H[r,k] > 0) ? v[r]*w[k] : 0 (the layer's pre-activation gradient; what addhip_outer_mask writes), and the
  * column sums that autograd would produce for the head weight (sum_r v[r] H[r,k]), the head bias (sum_r v[r]) and the
  * layer's bias (sum_r dZ[r,k]), ACCUMULATED by atomics into dW_head[K], db_head[1], db_top[K] (caller zeroes; any output
- * may be NULL).  Replaces outer_mask + weighted_col_sum + 2 x col_sum and three of their four passes over H.  K <= 1024. */
+ * may be NULL).  Replaces outer_mask + weighted_col_sum + 2 x col_sum and three of their four passes over H.  K <= 1024.
+ * dZ16 (optional): the same dZ rounded to bf16 (nearest even), what the bf16-storage backward GEMMs read. */
 int addhip_head_backward(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows,
-                         float* dZ, float* dW_head, float* db_head, float* db_top, void* stream);
+                         float* dZ, uint16_t* dZ16, float* dW_head, float* db_head, float* db_top, void* stream);
 
 /* out[m,k] = v[m] * w[k] * (H[m,k] > 0)    (back through a 1-wide head into the last hidden layer) */
 int addhip_outer_mask(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows,
                       float* out, void* stream);
-/* out[m,k] = w[k] * (H[m,k] > 0)          (a2 of the gradient-penalty chain) */
-int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, void* stream);
-/* gradient penalty (add_agent.py:166-178): n=sqrt(|g|^2+1e-8); G = coef*2(n-1)/n * g / M; stats[0] += sum (n-1)^2 */
-int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, float* stats, void* stream);
+/* out[m,k] = w[k] * (H[m,k] > 0)          (a2 of the gradient-penalty chain); out and/or its bf16 copy out16 */
+int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, uint16_t* out16, void* stream);
+/* gradient penalty (add_agent.py:166-178): n=sqrt(|g|^2+1e-8); G = coef*2(n-1)/n * g / M (fp32 G and/or its bf16 copy G16); stats[0] += sum (n-1)^2 */
+int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, uint16_t* G16, float* stats, void* stream);
 /* out[k] (+)= scale * sum_m v[m]*(mask? (Hmask[m,k]>0):1)*X[m,k]   (dw of 1-wide heads) */
 int addhip_weighted_col_sum(const float* v, const float* X, int32_t ld, int32_t K, int64_t rows, float* out,
                             float scale, int32_t accumulate, void* stream);

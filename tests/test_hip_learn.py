@@ -330,14 +330,25 @@ def test_critic_and_disc_heads_and_grad_penalty():
     # the fused backward of a scalar head: same dZ, plus the head-weight / head-bias / layer-bias gradients, accumulated
     out2 = torch.full((M + 1, K), 7.0, device="cuda")
     gW, gb, gt_ = torch.full((K,), 0.25, device="cuda"), torch.full((1,), 0.25, device="cuda"), torch.full((K,), 0.25, device="cuda")
-    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, L.ptr(out2), L.ptr(gW), L.ptr(gb), L.ptr(gt_), L.current_stream())
+    out16 = torch.full((M + 1, K), 7.0, device="cuda", dtype=torch.bfloat16)
+    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, L.ptr(out2), L.ptr(out16), L.ptr(gW), L.ptr(gb), L.ptr(gt_), L.current_stream())
     torch.cuda.synchronize()
-    assert torch.equal(out2, out)
+    assert torch.equal(out2, out) and torch.equal(out16, out.to(torch.bfloat16))  # the optional bf16 copy: the same values, rounded to nearest even
     dl64, H64, o64 = dl.cpu().numpy().astype(np.float64), H.astype(np.float64), out.cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(gW.cpu().numpy() - 0.25, dl64 @ H64, rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(gb.cpu().numpy() - 0.25, dl64.sum(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(gt_.cpu().numpy() - 0.25, o64.sum(0), rtol=1e-4, atol=1e-6)
-    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, None, None, None, None, L.current_stream())  # every output optional
+    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, None, None, None, None, None, L.current_stream())  # every output optional
+    # a2 of the gradient-penalty chain: fp32 and / or bf16
+    a2, a2_16 = torch.zeros(M, K, device="cuda"), torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
+    L.call("addhip_bcast_mask", L.ptr(dw), L.ptr(dH), K, K, M, L.ptr(a2), L.ptr(a2_16), L.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(a2.cpu().numpy(), np.where(H[:M] > 0, dw.cpu().numpy()[None, :], 0).astype(F))
+    assert torch.equal(a2_16, a2.to(torch.bfloat16))
+    a2_16b = torch.zeros_like(a2_16)
+    L.call("addhip_bcast_mask", L.ptr(dw), L.ptr(dH), K, K, M, None, L.ptr(a2_16b), L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(a2_16b, a2_16)
     # critic head without its dZ pass (dZ = NULL)
     dv2, st4 = torch.zeros(M, device="cuda"), torch.zeros(4, device="cuda")
     L.call("addhip_critic_head", L.ptr(dH), K, K, M, L.ptr(dw), L.ptr(db), P(T(tar)), 1.0, None, L.ptr(dv2), L.ptr(st4), L.current_stream())
@@ -353,8 +364,10 @@ def test_critic_and_disc_heads_and_grad_penalty():
     gp = torch.mean((n - 1) ** 2)
     (20.0 * 0.5 * gp).backward()
     G, st3 = torch.ones(M, 116, device="cuda"), torch.zeros(8, device="cuda")
-    L.call("addhip_grad_penalty", P(T(g)), 116, 114, M, 10.0, L.ptr(G), L.ptr(st3), L.current_stream())
+    G16 = torch.ones(M, 116, device="cuda", dtype=torch.bfloat16)
+    L.call("addhip_grad_penalty", P(T(g)), 116, 114, M, 10.0, L.ptr(G), L.ptr(G16), L.ptr(st3), L.current_stream())
     torch.cuda.synchronize()
+    assert torch.equal(G16, G.to(torch.bfloat16))
     np.testing.assert_allclose(st3.cpu().numpy()[0] / M, gp.item(), rtol=1e-5)
     np.testing.assert_allclose(G.cpu().numpy()[:, :114], gt.grad.numpy(), rtol=1e-4, atol=1e-8)
     assert np.all(G.cpu().numpy()[:, 114:] == 0)
