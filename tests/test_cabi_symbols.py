@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/addhip.h but not exported by libaddhip.so"
     bound = set(L.SIGNATURES) | {"addhip_last_error", "addhip_version", "addhip_abi_sizes"}  # (load() checks the struct sizes)
     assert declared == bound, (declared ^ bound)
-    assert lib.addhip_version() >= 2
+    assert lib.addhip_version() >= 3
 
 
 def test_missing_library_fails_loudly(monkeypatch):
