@@ -404,7 +404,7 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   const long long tiles128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
   // the bf16-MFMA paths pay off from half a chip of 128x128 tiles (measured: 16384x128x1024 77 -> 53 us, 4096x512x1024 64 -> 50 us)
   if (g.precision != ADDHIP_PREC_F32 && tiles128 >= 128 && tiles128 < 256) return addhip::gemm_split_dispatch(g, g.precision, st);
-  if (tiles128 < 256) return launch_cfg<64, 128, 2, 2, 16>(g, st);
+  if (tiles128 <= 256) return launch_cfg<64, 128, 2, 2, 16>(g, st);  // (a bare chip of 128x128 tiles = one 4-wave workgroup per CU: two 64x128 ones overlap better)
   // N just past a multiple of 96 but far from one of 128 (the 272-wide first-layer weight gradient): 96-wide tiles waste
   // 6 % of their columns instead of 29 %
   const int waste128 = (g.N + 127) / 128 * 128 - g.N, waste96 = (g.N + 95) / 96 * 96 - g.N;
@@ -416,8 +416,7 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   // alone they time the same, beside the other streams' launches of an update step they overlap better (update phase -2 %)
   {
     static const char* sb = getenv("ADDHIP_F32_SB");
-    const bool many = (long long)tiles128 * (g.split_k > 1 ? g.split_k : 1) >= 512;
-    if (sb ? sb[0] == '1' : many) return launch_cfg<128, 128, 2, 2, 32, true>(g, st);
+    if (sb ? sb[0] == '1' : tiles128 >= 512) return launch_cfg<128, 128, 2, 2, 32, true>(g, st);
   }
   return launch_cfg<128, 128, 2, 2, 32>(g, st);
 }
