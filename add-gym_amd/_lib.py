@@ -72,7 +72,7 @@ class RigidModelT(C.Structure):
     _fields_ = [("num_bodies", C.c_int32), ("num_points", C.c_int32), ("body", f32p), ("topo", f32p), ("points", f32p), ("dt", C.c_float),
                 ("substeps", C.c_int32), ("gravity", C.c_float), ("contact_stiffness", C.c_float), ("contact_damping", C.c_float),
                 ("friction", C.c_float), ("friction_vel_eps", C.c_float), ("limit_stiffness", C.c_float), ("max_torque", C.c_float),
-                ("limit_margin", C.c_float), ("termination_mask", C.c_uint32), ("env_scale", f32p)]
+                ("limit_margin", C.c_float), ("termination_mask", C.c_uint32), ("env_scale", f32p), ("chains", f32p)]
 
 
 RIGID_BODY_W, RIGID_TOPO_W = 32, 8

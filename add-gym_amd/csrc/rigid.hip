@@ -107,7 +107,8 @@ __device__ __forceinline__ float comp(V3 v, int ax) { return ax == 0 ? v.x : (ax
 __device__ __forceinline__ V3 unit(int ax) { return {ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f}; }
 
 // child -> parent rotation  R = Rfix * Rot(axis, theta)
-__device__ __forceinline__ M3 joint_rot(const cfloat* rf, int ax, float s, float c) {
+template <typename P>
+__device__ __forceinline__ M3 joint_rot(P rf, int ax, float s, float c) {
   M3 R;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -490,6 +491,415 @@ __global__ __launch_bounds__(WG) void rigid_step_kernel(addhip_rigid_model_t M, 
 #undef LD
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Four lanes per environment ("limb lanes").  The one-lane kernel above is bound by the instruction stream of a single wave
+// (30 bodies x 3 passes x 4 substeps, one wave per CU and only num_envs / 64 CUs busy).  Here the depth-first body order is cut
+// into its chains (maximal runs whose parent is the previous body: for G1 left leg | right leg | waist + left arm | right arm)
+// and each chain gets its own lane of a quad, so that a wave walks 10 body-steps instead of 30 and four times as many waves
+// share the work.  Step s of a pass is local body s - start of every chain (a chain hanging off another chain's body starts
+// one step after that body).  What crosses lanes, by quad-wide shuffles at the few steps where chains meet:
+//   pass 1 / pass 3 (outward): the attach body's carried state (velocity, up-vector, height / acceleration);
+//   pass 2 (inward): a chain's articulated inertia and bias force, expressed in its attach body's frame, is added to that
+//   body's before it is processed; the chains hanging off the root are summed over the quad, and all four lanes then do the
+//   root's own work and the 6x6 solve redundantly (no divergence, no broadcast).
+// The model tables cannot be scalar loads any more (the lanes of a wave are on four different bodies): they are staged in
+// LDS once per workgroup (body rows padded to 33 floats so that the four rows fall on different banks).
+// Chain table (addhip_rigid_model_t.chains, 4 x 16 int32): len, start step, attach lane (-1: root), body indices.
+constexpr int L4_S = 10;                 // steps per pass = max(start + len) over the chains
+constexpr int L4_ENVS = 16;              // environments per 64-lane workgroup
+constexpr int L4_BW = BW + 1;
+constexpr int L4_STATE = L4_ENVS * (36 + 36 + 32);
+constexpr int L4_MODEL = MAXB * L4_BW + MAXB * TW + 64 + MAXP * 4;
+constexpr int P_SIN = 0, P_COS = L4_S, P_U = 2 * L4_S, P_DINV = 8 * L4_S, P_UU = 9 * L4_S, P_BV = 10 * L4_S, P_BNZ = 16 * L4_S, P_BH = 19 * L4_S;
+constexpr int P_TOTAL = 20 * L4_S;
+constexpr int L4_LDS_FLOATS = L4_STATE + L4_MODEL + P_TOTAL * 64;
+
+__device__ __forceinline__ float quad_from(float v, int src_lane_in_quad) { return __shfl(v, (threadIdx.x & ~3) | src_lane_in_quad, 64); }
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+__device__ __forceinline__ void art_to_array(const ArtI& I, const Sp6& f, float* v) {
+  const float t[27] = {I.A.xx, I.A.xy, I.A.xz, I.A.yy, I.A.yz, I.A.zz, I.B.m[0], I.B.m[1], I.B.m[2], I.B.m[3], I.B.m[4], I.B.m[5], I.B.m[6], I.B.m[7], I.B.m[8],
+                       I.C.xx, I.C.xy, I.C.xz, I.C.yy, I.C.yz, I.C.zz, f.a.x, f.a.y, f.a.z, f.l.x, f.l.y, f.l.z};
+#pragma unroll
+  for (int i = 0; i < 27; ++i) v[i] = t[i];
+}
+__device__ __forceinline__ void art_add_array(ArtI& I, Sp6& f, const float* v) {
+  I.A.xx += v[0]; I.A.xy += v[1]; I.A.xz += v[2]; I.A.yy += v[3]; I.A.yz += v[4]; I.A.zz += v[5];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) I.B.m[i] += v[6 + i];
+  I.C.xx += v[15]; I.C.xy += v[16]; I.C.xz += v[17]; I.C.yy += v[18]; I.C.yz += v[19]; I.C.zz += v[20];
+  f.a.x += v[21]; f.a.y += v[22]; f.a.z += v[23]; f.l.x += v[24]; f.l.y += v[25]; f.l.z += v[26];
+}
+
+// rigid-body inertia and bias force of a body moving with (w, vl), gravity along -nz
+__device__ __forceinline__ void body_inertia(const float* bc, V3 w, V3 vl, V3 nz, float gravity, ArtI& I, Sp6& p) {
+  const float mass = bc[12];
+  const V3 mc{bc[13], bc[14], bc[15]};
+  I.A = {bc[16], bc[17], bc[18], bc[19], bc[20], bc[21]};
+  I.B = {{0.f, -mc.z, mc.y, mc.z, 0.f, -mc.x, -mc.y, mc.x, 0.f}};
+  I.C = {mass, 0.f, 0.f, mass, 0.f, mass};
+  const V3 hn = mul(I.A, w) + cross(mc, vl);
+  const V3 hl = mass * vl - cross(mc, w);
+  const V3 gl = (-gravity) * nz;
+  p.a = cross(w, hn) + cross(vl, hl) - cross(mc, gl);
+  p.l = cross(w, hl) - mass * gl;
+}
+
+// ground contacts of one body's collision spheres, folded into its articulated inertia / bias force (linearly implicit)
+__device__ __forceinline__ void body_contacts(const float* pts, int npt, int link, V3 w, V3 vl, V3 nz, float hk, float h, float kc, float cn, float mu,
+                                              float veps, ArtI& I, Sp6& p, unsigned& touch) {
+  for (int j = 0; j < npt; ++j) {
+    const float* pt = pts + j * 4;
+    const V3 r{pt[0], pt[1], pt[2]};
+    const float d = pt[3] - (hk + dot(nz, r));
+    if (d > 0.f) {
+      touch |= 1u << link;
+      const V3 vp = vl + cross(w, r);
+      const float vn = dot(nz, vp);
+      const V3 vt = vp - vn * nz;
+      const float fn0 = fmaxf(kc * d - cn * vn, 0.f);
+      const float ct = mu * fn0 / fmaxf(sqrtf(dot(vt, vt)), veps);
+      const float fne = fmaxf(fn0 - h * kc * vn, 0.f);
+      const V3 f = fne * nz - ct * vt;
+      const float an = h * h * kc + h * cn - h * ct, at = h * ct;   // A = an nz nz^T + at 1
+      const S3 Am{an * nz.x * nz.x + at, an * nz.x * nz.y, an * nz.x * nz.z, an * nz.y * nz.y + at, an * nz.y * nz.z, an * nz.z * nz.z + at};
+      const M3 rA = skew_mul(r, full(Am));
+      const M3 rArT = mul_skew(rA, V3{-r.x, -r.y, -r.z});
+#pragma unroll
+      for (int i = 0; i < 9; ++i) I.B.m[i] += rA.m[i];
+      I.A.xx += rArT.m[0]; I.A.xy += rArT.m[1]; I.A.xz += rArT.m[2]; I.A.yy += rArT.m[4]; I.A.yz += rArT.m[5]; I.A.zz += rArT.m[8];
+      I.C.xx += Am.xx; I.C.xy += Am.xy; I.C.xz += Am.xz; I.C.yy += Am.yy; I.C.yz += Am.yz; I.C.zz += Am.zz;
+      p.a = p.a - cross(r, f);
+      p.l = p.l - f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M, float* __restrict__ sim_pose, float* __restrict__ sim_vel,
+                                                         const float* __restrict__ target, int tstride, int n, unsigned char* __restrict__ contact_flag,
+                                                         unsigned* __restrict__ contact_bits) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x, e = lane >> 2, q = lane & 3;
+  const int env0 = blockIdx.x * L4_ENVS;
+  const int env = env0 + e;
+  const int live = min(L4_ENVS, n - env0);
+  float* st_pose = lds;
+  float* st_vel = lds + L4_ENVS * 36;
+  float* st_tgt = lds + L4_ENVS * 72;
+  float* mbody = lds + L4_STATE;
+  int* mtopo = reinterpret_cast<int*>(mbody + MAXB * L4_BW);
+  int* mchain = mtopo + MAXB * TW;
+  float* mpts = reinterpret_cast<float*>(mchain + 64);
+  float* pl = lds + L4_STATE + L4_MODEL;
+#define SP(c) st_pose[e * 36 + (c)]
+#define SV(c) st_vel[e * 36 + (c)]
+#define TG(c) st_tgt[e * 32 + (c)]
+#define PL(f, i) pl[((f) + (i)) * 64 + lane]
+  const int nb = M.num_bodies;
+  for (int idx = lane; idx < live * 36; idx += 64) {
+    st_pose[idx] = sim_pose[(size_t)env0 * 36 + idx];
+    st_vel[idx] = sim_vel[(size_t)env0 * 36 + idx];
+  }
+  for (int idx = lane; idx < live * 32; idx += 64) {
+    const int row = idx >> 5, col = idx & 31;
+    st_tgt[idx] = col < 29 ? target[(size_t)(env0 + row) * tstride + col] : 0.f;
+  }
+  for (int idx = lane; idx < nb * BW; idx += 64) mbody[(idx / BW) * L4_BW + idx % BW] = M.body[idx];
+  for (int idx = lane; idx < nb * TW; idx += 64) mtopo[idx] = M.topo[idx];
+  mchain[lane] = M.chains[lane];
+  for (int idx = lane; idx < M.num_points * 4; idx += 64) mpts[idx] = M.points[idx];
+  __syncthreads();
+  const bool on = e < live;  // quads past the last env run on a resting default state (kept in step, never written back)
+  if (!on) {
+    for (int c = q; c < 36; c += 4) { SP(c) = (c == 3) ? 1.f : (c == 2 ? 10.f : 0.f); SV(c) = 0.f; }
+    for (int c = q; c < 32; c += 4) TG(c) = 0.f;
+  }
+  __syncthreads();
+
+  const int* ch = mchain + q * 16;
+  const int clen = ch[0], cstart = ch[1], cattach = ch[2];
+  // steps at which a chain that hangs off another chain starts (pass 1 / 3 take the attach body's state there, pass 2 hands
+  // the chain's inertia over one step earlier): wave-uniform bit masks
+  unsigned hang_start = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (mchain[r * 16 + 2] >= 0 && mchain[r * 16] > 0) hang_start |= 1u << mchain[r * 16 + 1];
+
+  const float h = M.dt / (float)M.substeps;
+  const float kc = M.contact_stiffness, cn = M.contact_damping, veps = M.friction_vel_eps;
+  const float gscale = (M.env_scale && on) ? M.env_scale[2 * env] : 1.f;
+  const float mu = (M.env_scale && on) ? M.env_scale[2 * env + 1] : M.friction;
+  unsigned touch = 0;
+
+  V3 pos{SP(0), SP(1), SP(2)};
+  float qw = SP(3), qx = SP(4), qy = SP(5), qz = SP(6);
+  V3 vw{SV(0), SV(1), SV(2)}, ww{SV(3), SV(4), SV(5)};
+
+  for (int sub = 0; sub < M.substeps; ++sub) {
+    touch = 0;
+    M3 R0 = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+              2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
+              2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)}};
+    // ---------------- pass 1 (outward)
+    const V3 rw = mulT(R0, ww), rv = mulT(R0, vw);
+    const V3 rnz{R0.m[6], R0.m[7], R0.m[8]};
+    const float rh = pos.z;
+    V3 cw = rw, cv = rv, cnz = rnz;
+    float chh = rh;
+    for (int s = 0; s < L4_S; ++s) {
+      if (hang_start & (1u << s)) {  // wave-uniform
+        const int src = cattach >= 0 ? cattach : q;
+        const float t[10] = {quad_from(cw.x, src), quad_from(cw.y, src), quad_from(cw.z, src), quad_from(cv.x, src), quad_from(cv.y, src),
+                             quad_from(cv.z, src), quad_from(cnz.x, src), quad_from(cnz.y, src), quad_from(cnz.z, src), quad_from(chh, src)};
+        if (cattach >= 0 && cstart == s) { cw = {t[0], t[1], t[2]}; cv = {t[3], t[4], t[5]}; cnz = {t[6], t[7], t[8]}; chh = t[9]; }
+      }
+      const int i = s - cstart;
+      if (i >= 0 && i < clen) {
+        const int k = ch[3 + i];
+        const float* bc = mbody + k * L4_BW;
+        const int* tp = mtopo + k * TW;
+        const int ax = tp[1], dof = tp[2];
+        const float qj = SP(7 + dof), qd = SV(6 + dof);
+        float sn, cs;
+        if (sub == 0) {
+          sincosf(qj, &sn, &cs);
+          PL(P_SIN, i) = sn; PL(P_COS, i) = cs;
+        } else {
+          sn = PL(P_SIN, i); cs = PL(P_COS, i);
+        }
+        const M3 R = joint_rot(bc + 3, ax, sn, cs);
+        const V3 r{bc[0], bc[1], bc[2]};
+        V3 w = mulT(R, cw);
+        const V3 vl = mulT(R, cv - cross(r, cw));
+        if (ax == 0) w.x += qd; else if (ax == 1) w.y += qd; else w.z += qd;
+        const V3 nz = mulT(R, cnz);
+        chh = chh + dot(cnz, r);
+        PL(P_BV, 6 * i) = w.x; PL(P_BV, 6 * i + 1) = w.y; PL(P_BV, 6 * i + 2) = w.z;
+        PL(P_BV, 6 * i + 3) = vl.x; PL(P_BV, 6 * i + 4) = vl.y; PL(P_BV, 6 * i + 5) = vl.z;
+        PL(P_BNZ, 3 * i) = nz.x; PL(P_BNZ, 3 * i + 1) = nz.y; PL(P_BNZ, 3 * i + 2) = nz.z;
+        PL(P_BH, i) = chh;
+        cw = w; cv = vl; cnz = nz;
+      }
+    }
+    // ---------------- pass 2 (inward)
+    float carry[27];  // this chain's articulated inertia and bias force in the frame of the body it was last handed to
+#pragma unroll
+    for (int i = 0; i < 27; ++i) carry[i] = 0.f;
+    for (int s = L4_S - 1; s >= 0; --s) {
+      const int i = s - cstart;
+      const bool act = i >= 0 && i < clen;
+      float hang[27];
+#pragma unroll
+      for (int x = 0; x < 27; ++x) hang[x] = 0.f;
+      if (hang_start & (1u << (s + 1))) {  // a chain hanging off a body of this step has just finished: hand its inertia over
+        for (int r = 0; r < 4; ++r) {
+          const int ra = mchain[r * 16 + 2];
+          if (ra >= 0 && mchain[r * 16 + 1] == s + 1 && mchain[r * 16] > 0) {  // wave-uniform
+#pragma unroll
+            for (int x = 0; x < 27; ++x) {
+              const float t = quad_from(carry[x], r);
+              if (q == ra) hang[x] += t;
+            }
+          }
+        }
+      }
+      if (act) {
+        const int k = ch[3 + i];
+        const float* bc = mbody + k * L4_BW;
+        const int* tp = mtopo + k * TW;
+        const int ax = tp[1], dof = tp[2], pt0 = tp[5], npt = tp[6], link = tp[7];
+        const V3 w{PL(P_BV, 6 * i), PL(P_BV, 6 * i + 1), PL(P_BV, 6 * i + 2)}, vl{PL(P_BV, 6 * i + 3), PL(P_BV, 6 * i + 4), PL(P_BV, 6 * i + 5)};
+        const V3 nz{PL(P_BNZ, 3 * i), PL(P_BNZ, 3 * i + 1), PL(P_BNZ, 3 * i + 2)};
+        const float hk = PL(P_BH, i);
+        ArtI I;
+        Sp6 p;
+        body_inertia(bc, w, vl, nz, M.gravity, I, p);
+        if (i + 1 < clen) art_add_array(I, p, carry);  // the next body of this chain
+        art_add_array(I, p, hang);                      // chains hanging off this body (zeros otherwise)
+        if (hk < bc[29]) body_contacts(mpts + pt0 * 4, npt, link, w, vl, nz, hk, h, kc, cn, mu, veps, I, p, touch);
+        // joint: PD torque with the implicit diagonal (stable PD unless the torque clamp is active), limit spring
+        const float qj = SP(7 + dof), qd = SV(6 + dof);
+        const float lo = bc[22], hi = bc[23], damp = bc[24], arm = bc[25], flim = fminf(bc[26], M.max_torque), kp = gscale * bc[27], kv = gscale * bc[28];
+        const float tgt = fminf(fmaxf(TG(dof), lo + M.limit_margin), hi - M.limit_margin);
+        const float tpd = kp * (tgt - qj) - kv * qd;
+        float tau, dadd;
+        if (fabsf(tpd) > flim) { tau = fminf(fmaxf(tpd, -flim), flim) - damp * qd; dadd = arm + h * damp; }
+        else { tau = kp * (tgt - qj - h * qd) - (kv + damp) * qd; dadd = arm + h * (kv + damp) + h * h * kp; }
+        if (qj < lo) { tau += M.limit_stiffness * (lo - qj - h * qd); dadd += h * h * M.limit_stiffness; }
+        if (qj > hi) { tau += M.limit_stiffness * (hi - qj - h * qd); dadd += h * h * M.limit_stiffness; }
+        V3 Ua, Ul;
+        if (ax == 0) { Ua = {I.A.xx, I.A.xy, I.A.xz}; Ul = {I.B.m[0], I.B.m[1], I.B.m[2]}; }
+        else if (ax == 1) { Ua = {I.A.xy, I.A.yy, I.A.yz}; Ul = {I.B.m[3], I.B.m[4], I.B.m[5]}; }
+        else { Ua = {I.A.xz, I.A.yz, I.A.zz}; Ul = {I.B.m[6], I.B.m[7], I.B.m[8]}; }
+        const float Dinv = 1.f / (comp(Ua, ax) + dadd);
+        const float u = tau - comp(p.a, ax);
+        PL(P_U, 6 * i) = Ua.x; PL(P_U, 6 * i + 1) = Ua.y; PL(P_U, 6 * i + 2) = Ua.z; PL(P_U, 6 * i + 3) = Ul.x; PL(P_U, 6 * i + 4) = Ul.y; PL(P_U, 6 * i + 5) = Ul.z;
+        PL(P_DINV, i) = Dinv; PL(P_UU, i) = u;
+        I.A.xx -= Dinv * Ua.x * Ua.x; I.A.xy -= Dinv * Ua.x * Ua.y; I.A.xz -= Dinv * Ua.x * Ua.z; I.A.yy -= Dinv * Ua.y * Ua.y; I.A.yz -= Dinv * Ua.y * Ua.z; I.A.zz -= Dinv * Ua.z * Ua.z;
+        I.C.xx -= Dinv * Ul.x * Ul.x; I.C.xy -= Dinv * Ul.x * Ul.y; I.C.xz -= Dinv * Ul.x * Ul.z; I.C.yy -= Dinv * Ul.y * Ul.y; I.C.yz -= Dinv * Ul.y * Ul.z; I.C.zz -= Dinv * Ul.z * Ul.z;
+        {
+          const float ua[3] = {Ua.x, Ua.y, Ua.z}, ul[3] = {Ul.x, Ul.y, Ul.z};
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) I.B.m[3 * a + b] -= Dinv * ua[a] * ul[b];
+        }
+        const V3 ev = unit(ax);
+        const V3 ca = qd * cross(w, ev), cl = qd * cross(vl, ev);
+        const float ud = u * Dinv;
+        p.a = p.a + mul(I.A, ca) + mul(I.B, cl) + ud * Ua;
+        p.l = p.l + mulT(I.B, ca) + mul(I.C, cl) + ud * Ul;
+        // to the parent's coordinates:  X^T Ia X,  X^T pa   (X = rot(R^T) xlt(r))
+        const M3 R = joint_rot(bc + 3, ax, PL(P_SIN, i), PL(P_COS, i));
+        const V3 r{bc[0], bc[1], bc[2]};
+        ArtI P;
+        P.A = rot_sym(R, I.A);
+        P.C = rot_sym(R, I.C);
+        const M3 Bp = matmul(matmul(R, I.B), transpose(R));
+        const M3 rC = skew_mul(r, full(P.C));
+        M3 Bn;
+#pragma unroll
+        for (int a = 0; a < 9; ++a) Bn.m[a] = Bp.m[a] + rC.m[a];
+        const M3 t1 = skew_mul(r, transpose(Bn));
+        const M3 t2 = mul_skew(Bp, r);
+        P.A.xx += t1.m[0] - t2.m[0]; P.A.xy += t1.m[1] - t2.m[1]; P.A.xz += t1.m[2] - t2.m[2];
+        P.A.yy += t1.m[4] - t2.m[4]; P.A.yz += t1.m[5] - t2.m[5]; P.A.zz += t1.m[8] - t2.m[8];
+        P.B = Bn;
+        Sp6 pp;
+        pp.l = mul(R, p.l);
+        pp.a = mul(R, p.a) + cross(r, pp.l);
+        art_to_array(P, pp, carry);
+      }
+    }
+    // ---------------- root: the chains hanging off it, its own inertia and contacts, a0 = -IA0^-1 pA0 (6x6 SPD, Cholesky)
+    float a0[6];
+    {
+      ArtI I;
+      Sp6 p;
+      body_inertia(mbody, rw, rv, rnz, M.gravity, I, p);
+      float tot[27];
+#pragma unroll
+      for (int x = 0; x < 27; ++x) tot[x] = quad_sum((cattach < 0 && clen > 0) ? carry[x] : 0.f);
+      art_add_array(I, p, tot);
+      if (rh < mbody[29]) body_contacts(mpts + mtopo[5] * 4, mtopo[6], mtopo[7], rw, rv, rnz, rh, h, kc, cn, mu, veps, I, p, touch);
+      float A[6][6];
+      A[0][0] = I.A.xx; A[0][1] = I.A.xy; A[0][2] = I.A.xz; A[1][1] = I.A.yy; A[1][2] = I.A.yz; A[2][2] = I.A.zz;
+      A[3][3] = I.C.xx; A[3][4] = I.C.xy; A[3][5] = I.C.xz; A[4][4] = I.C.yy; A[4][5] = I.C.yz; A[5][5] = I.C.zz;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) A[a][3 + b] = I.B.m[3 * a + b];
+      float b[6] = {-p.a.x, -p.a.y, -p.a.z, -p.l.x, -p.l.y, -p.l.z};
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int j = a; j < 6; ++j) {
+          float sum = A[a][j];
+#pragma unroll
+          for (int t = 0; t < a; ++t) sum -= A[t][a] * A[t][j];
+          A[a][j] = (j == a) ? sqrtf(fmaxf(sum, 1e-20f)) : sum / A[a][a];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        float sum = b[a];
+#pragma unroll
+        for (int t = 0; t < a; ++t) sum -= A[t][a] * b[t];
+        b[a] = sum / A[a][a];
+      }
+#pragma unroll
+      for (int a = 5; a >= 0; --a) {
+        float sum = b[a];
+#pragma unroll
+        for (int t = a + 1; t < 6; ++t) sum -= A[a][t] * b[t];
+        b[a] = sum / A[a][a];
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) a0[a] = b[a];
+    }
+    // ---------------- pass 3 (outward): accelerations; joints are integrated as they are visited
+    V3 caa{a0[0], a0[1], a0[2]}, cal{a0[3], a0[4], a0[5]};
+    for (int s = 0; s < L4_S; ++s) {
+      if (hang_start & (1u << s)) {
+        const int src = cattach >= 0 ? cattach : q;
+        const float t[6] = {quad_from(caa.x, src), quad_from(caa.y, src), quad_from(caa.z, src), quad_from(cal.x, src), quad_from(cal.y, src), quad_from(cal.z, src)};
+        if (cattach >= 0 && cstart == s) { caa = {t[0], t[1], t[2]}; cal = {t[3], t[4], t[5]}; }
+      }
+      const int i = s - cstart;
+      if (i >= 0 && i < clen) {
+        const int k = ch[3 + i];
+        const float* bc = mbody + k * L4_BW;
+        const int* tp = mtopo + k * TW;
+        const int ax = tp[1], dof = tp[2];
+        const float s0 = PL(P_SIN, i), c0 = PL(P_COS, i);
+        const M3 R = joint_rot(bc + 3, ax, s0, c0);
+        const V3 r{bc[0], bc[1], bc[2]};
+        const V3 w{PL(P_BV, 6 * i), PL(P_BV, 6 * i + 1), PL(P_BV, 6 * i + 2)}, vl{PL(P_BV, 6 * i + 3), PL(P_BV, 6 * i + 4), PL(P_BV, 6 * i + 5)};
+        const float qd = SV(6 + dof);
+        const V3 ev = unit(ax);
+        V3 aa = mulT(R, caa) + qd * cross(w, ev);
+        const V3 al = mulT(R, cal - cross(r, caa)) + qd * cross(vl, ev);
+        const V3 Ua{PL(P_U, 6 * i), PL(P_U, 6 * i + 1), PL(P_U, 6 * i + 2)}, Ul{PL(P_U, 6 * i + 3), PL(P_U, 6 * i + 4), PL(P_U, 6 * i + 5)};
+        const float qdd = (PL(P_UU, i) - dot(Ua, aa) - dot(Ul, al)) * PL(P_DINV, i);
+        if (ax == 0) aa.x += qdd; else if (ax == 1) aa.y += qdd; else aa.z += qdd;
+        caa = aa; cal = al;
+        const float qdn = qd + h * qdd;
+        SV(6 + dof) = qdn;
+        const float dq = h * qdn;
+        SP(7 + dof) = SP(7 + dof) + dq;
+        const float d2 = dq * dq;
+        const float sd = dq * (1.f + d2 * (-1.f / 6.f + d2 * (1.f / 120.f - d2 * (1.f / 5040.f))));
+        const float cd = 1.f + d2 * (-0.5f + d2 * (1.f / 24.f - d2 * (1.f / 720.f)));
+        PL(P_SIN, i) = s0 * cd + c0 * sd;
+        PL(P_COS, i) = c0 * cd - s0 * sd;
+      }
+    }
+    // ---------------- root: semi-implicit Euler (all four lanes, identically)
+    {
+      const V3 aw = mul(R0, V3{a0[0], a0[1], a0[2]});
+      const V3 al = mul(R0, V3{a0[3], a0[4], a0[5]}) + cross(ww, vw);
+      ww = ww + h * aw;
+      vw = vw + h * al;
+      pos = pos + h * vw;
+      const float wn = sqrtf(dot(ww, ww));
+      const float half = 0.5f * h * wn;
+      const float kq = wn > 1e-12f ? sinf(half) / wn : 0.5f * h;
+      const float dw = cosf(half), dx = kq * ww.x, dy = kq * ww.y, dz = kq * ww.z;
+      const float nw = dw * qw - dx * qx - dy * qy - dz * qz;
+      const float nx = dw * qx + dx * qw + dy * qz - dz * qy;
+      const float ny = dw * qy - dx * qz + dy * qw + dz * qx;
+      const float nzq = dw * qz + dx * qy - dy * qx + dz * qw;
+      const float inv = rsqrtf(nw * nw + nx * nx + ny * ny + nzq * nzq);
+      qw = nw * inv; qx = nx * inv; qy = ny * inv; qz = nzq * inv;
+    }
+  }
+  // ---- write back
+  touch |= __shfl_xor(touch, 1, 64);
+  touch |= __shfl_xor(touch, 2, 64);
+  if (q == 0) {
+    SP(0) = pos.x; SP(1) = pos.y; SP(2) = pos.z; SP(3) = qw; SP(4) = qx; SP(5) = qy; SP(6) = qz;
+    SV(0) = vw.x; SV(1) = vw.y; SV(2) = vw.z; SV(3) = ww.x; SV(4) = ww.y; SV(5) = ww.z;
+    SV(35) = 0.f;
+    if (on) {
+      if (contact_bits) contact_bits[env] = touch;
+      if (contact_flag) contact_flag[env] = (touch & M.termination_mask) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  for (int idx = lane; idx < live * 36; idx += 64) {
+    sim_pose[(size_t)env0 * 36 + idx] = st_pose[idx];
+    sim_vel[(size_t)env0 * 36 + idx] = st_vel[idx];
+  }
+#undef SP
+#undef SV
+#undef TG
+#undef PL
+}
+
 }  // namespace
 
 extern "C" int addhip_rigid_step(const addhip_rigid_model_t* m, float* sim_pose, float* sim_vel, const float* target, int32_t target_stride,
@@ -500,6 +910,17 @@ extern "C" int addhip_rigid_step(const addhip_rigid_model_t* m, float* sim_pose,
   ADDHIP_REQUIRE(m->body && m->topo && (m->points || m->num_points == 0), "rigid_step: model tables missing");
   ADDHIP_REQUIRE(m->num_points >= 0 && m->num_points <= MAXP, "rigid_step: at most %d collision points", MAXP);
   ADDHIP_REQUIRE(m->substeps >= 1 && m->substeps <= 64 && m->dt > 0.f, "rigid_step: bad dt / substeps");
+  if (m->chains) {  // four lanes per environment
+    static bool attr4_set = false;
+    const size_t shmem4 = sizeof(float) * L4_LDS_FLOATS;
+    if (!attr4_set) {
+      ADDHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem4));
+      attr4_set = true;
+    }
+    hipLaunchKernelGGL(rigid_step4_kernel, dim3((num_envs + L4_ENVS - 1) / L4_ENVS), dim3(64), shmem4, (hipStream_t)stream, *m, sim_pose, sim_vel, target,
+                       target_stride, num_envs, contact_flag, contact_bits);
+    return addhip::check_launch("rigid_step4_kernel");
+  }
   static bool attr_set = false;
   const size_t shmem = sizeof(float) * LDS_FLOATS;
   if (!attr_set) {

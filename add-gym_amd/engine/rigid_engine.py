@@ -78,11 +78,14 @@ class RigidEntity(BaseEntity):
         self._d_body = torch.tensor(t.body, device=dev)
         self._d_topo = torch.tensor(t.topo, device=dev)
         self._d_points = torch.tensor(t.points if t.num_points else np.zeros((1, 4), np.float32), device=dev)
+        # four lanes per env (one per chain of the tree) unless the tree does not fit or the option asks for the one-lane kernel
+        chains = t.chain_table() if int(o.get("lanes_per_env", 4)) == 4 else None
+        self._d_chains = torch.tensor(chains, device=dev) if chains is not None else None
         self.c_struct = L.RigidModelT(t.num_bodies, t.num_points, L.ptr(self._d_body), L.ptr(self._d_topo), L.ptr(self._d_points),
                                       float(o["dt"]), int(o["substeps"]), float(o["gravity"]), float(o["contact_stiffness"]),
                                       float(o["contact_damping"]), float(o["friction"]), float(o["friction_vel_eps"]),
                                       float(o["limit_stiffness"]), float(o["max_torque"]), float(o["position_limit_margin"]), int(self._term_mask),
-                                      L.ptr(self.env_scale))
+                                      L.ptr(self.env_scale), L.ptr(self._d_chains))
         self._dirty = False
 
     def set_termination_links(self, allowed_link_names):
@@ -278,7 +281,7 @@ class RigidScene(BaseScene):
 
 class RigidBodyEngine(BaseEngine):
     DEFAULTS = dict(substeps=4, gravity=9.81, contact_stiffness=2.0e4, contact_damping=3.0e2, friction=1.0, friction_vel_eps=0.01,
-                    limit_stiffness=2.0e3, max_torque=200.0, position_limit_margin=1e-4, domain_randomization=None)
+                    limit_stiffness=2.0e3, max_torque=200.0, position_limit_margin=1e-4, domain_randomization=None, lanes_per_env=4)
 
     def __init__(self, **cfg):
         self.cfg = cfg

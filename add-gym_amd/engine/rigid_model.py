@@ -103,6 +103,41 @@ class RigidModelTables:
         self.num_bodies, self.num_points = nb, len(points)
         self.total_mass = float(body[:, 12].sum())
 
+    MAX_CHAIN_STEPS = 10
+
+    def chain_table(self):
+        """The depth-first body order cut into chains (maximal runs whose parent is the previous body) for the four-lanes-per-env
+        kernel: int32 [4][16] = len, start step, attach lane (-1: the root), body indices -- or None when the tree needs more than
+        four chains or more than MAX_CHAIN_STEPS steps (the one-lane kernel handles any tree).  G1: left leg | right leg |
+        waist + left arm | right arm."""
+        runs = []
+        for k in range(1, self.num_bodies):
+            if runs and self.topo[k, 0] == k - 1 and runs[-1][-1] == k - 1:
+                runs[-1].append(k)
+            else:
+                runs.append([k])
+        if len(runs) > 4:
+            return None
+        tab = np.zeros((4, 16), np.int32)
+        tab[:, 2] = -1
+        where = {}  # body -> (lane, step)
+        for lane, run in enumerate(runs):
+            par = int(self.topo[run[0], 0])
+            if par == 0:
+                start, attach = 0, -1
+            else:
+                if par not in where:
+                    return None
+                attach, pstep = where[par]
+                start = pstep + 1
+            if start + len(run) > self.MAX_CHAIN_STEPS:
+                return None
+            tab[lane, 0], tab[lane, 1], tab[lane, 2] = len(run), start, attach
+            tab[lane, 3:3 + len(run)] = run
+            for i, b in enumerate(run):
+                where[b] = (lane, start + i)
+        return tab
+
     def set_gains(self, kp, kv):
         """kp / kv per dof in breadth-first dof order (29 values) -> columns 27 / 28 of the traversal-ordered rows."""
         for k in range(1, self.num_bodies):

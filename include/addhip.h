@@ -188,6 +188,10 @@ typedef struct {
   /* domain randomisation (build-defined extension; the reference has none): per-env multipliers [N,2] = (PD gain scale applied to kp
    * and kv, ground friction coefficient replacing `friction`), or NULL */
   const float* env_scale;
+  /* optional (NULL = one lane per environment): the depth-first body order cut into at most four chains (maximal runs whose
+   * parent is the previous body), one lane of a quad each: int32 [4][16] = len, start step, attach lane (-1 = the root),
+   * body indices; a chain hanging off body j of another chain starts at that body's step + 1; max(start + len) <= 10 */
+  const int32_t* chains;
 } addhip_rigid_model_t;
 /* One control step for every env, in place on the packed state rows (pose[N,36], vel[N,36]); target [N,target_stride] = joint
  * position targets (breadth-first dof order).  contact_flag [N] (or NULL): 1 if a link selected by termination_mask touched

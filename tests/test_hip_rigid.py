@@ -52,12 +52,16 @@ def get(ent):
     return RB.State.from_packed(ent.pose.cpu().numpy().astype(np.float64), ent.vel.cpu().numpy().astype(np.float64))
 
 
+@pytest.mark.parametrize("lanes", [4, 1])
 @pytest.mark.parametrize("case", ["contact", "flight"])
-def test_one_control_step_matches_the_float64_oracle(case):
+def test_one_control_step_matches_the_float64_oracle(case, lanes):
+    """Both kernels: four lanes per env (one per chain of the tree; the default) and one lane per env; 70 envs = ragged last
+    workgroup of either."""
     import torch
 
-    n = 64
-    eng, scene, plane, ent, m, kp, kv = make_entity(n)
+    n = 70
+    eng, scene, plane, ent, m, kp, kv = make_entity(n, lanes_per_env=lanes)
+    assert (ent._d_chains is not None) == (lanes == 4)
     rng = np.random.RandomState(3 if case == "contact" else 4)
     st = rand_states(rng, n, 0.25, 0.85) if case == "contact" else rand_states(rng, n, 2.0, 3.0)
     # fp32 inputs on both sides

@@ -7,8 +7,10 @@ import add_gym_amd
 import add_gym_amd._lib as L
 from tests.test_hip_rigid import make_entity
 
+lanes = int(os.environ.get("LANES", "4"))  # 4: one lane per chain of the tree (default), 1: the one-lane kernel
+print(f"lanes per env: {lanes}")
 for n in [int(a) for a in sys.argv[1:]] or [4096, 16384, 65536]:
-    eng, scene, plane, ent, m, kp, kv = make_entity(n)
+    eng, scene, plane, ent, m, kp, kv = make_entity(n, lanes_per_env=lanes)
     pose0 = ent.pose.clone(); pose0[:, 2] = 0.79
     tgt = (torch.randn(n, 32, device="cuda") * 0.1).contiguous()
     ent.control_dofs_position(tgt)
