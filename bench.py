@@ -124,8 +124,8 @@ def env_step_at_scale(num_envs=65536, motion="synthetic:1x3600"):
 
 def rigid_step_roofline(num_envs):
     """The rigid-body engine's control step alone (addhip_rigid_step: `substeps` articulated-body sweeps per launch) on standing
-    robots.  Neither HBM- nor MFMA-bound: one lane per env, dependent fp32 VALU chains, one wave per SIMD; reported against the
-    fp32 vector peak with the kernel's arithmetic counted from its own operation list."""
+    robots.  Neither HBM- nor MFMA-bound: four lanes per env (one per chain of the tree), dependent fp32 VALU chains, a wave or two per
+    CU; reported against the fp32 vector peak with the kernel's arithmetic counted from its own operation list."""
     import torch
     import add_gym_amd  # noqa: F401
     from add_gym_amd.config import load_config
@@ -156,11 +156,12 @@ def rigid_step_roofline(num_envs):
     sub = int(ent._opts["substeps"])
     flop = RIGID_FLOP_PER_SUBSTEP * sub * num_envs
     tf = flop / (ms * 1e-3) / 1e12
-    return {"bound": "valu-latency", "kernel": "rigid_step_kernel (addhip_rigid_step, %d substeps per launch)" % sub, "achieved": tf, "peak": VALU_F32_PEAK_TFLOPS,
+    lanes = 4 if getattr(ent, "_d_chains", None) is not None else 1
+    return {"bound": "valu-latency", "kernel": "rigid_step%s_kernel (addhip_rigid_step, %d lane(s) per env, %d substeps per launch)" % ("4" if lanes == 4 else "", lanes, sub), "achieved": tf, "peak": VALU_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tf / VALU_F32_PEAK_TFLOPS, "traffic": None, "us_per_launch": ms * 1e3, "envs": num_envs,
             "env_steps_per_s": num_envs / (ms * 1e-3), "flop_per_env_substep": RIGID_FLOP_PER_SUBSTEP,
             "algorithmic_bytes_per_env_step": 2 * 2 * 36 * 4 + 29 * 4 + 5,
-            "note": "latency-bound by construction: every env is one lane walking a 30-body tree three times per substep"}
+            "note": "issue-bound by construction: a 30-body tree walked three times per substep, cut into four chains on four lanes of a quad"}
 
 
 def time_env_step(agent, reps=50, chunk=10):
