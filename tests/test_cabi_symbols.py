@@ -28,3 +28,13 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libaddhip.so")
     with pytest.raises(L.AddhipError):
         L.load()
+
+
+def test_smoke_calls_bind():
+    """__graft_entry__.smoke() calls test functions by name: their signatures must accept the arguments it passes."""
+    import importlib
+    import inspect
+    import __graft_entry__ as G
+
+    for module, fn, args, _ in G.SMOKE_CALLS:
+        inspect.signature(getattr(importlib.import_module(module), fn)).bind(*args)
