@@ -393,7 +393,8 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
     ADDHIP_REQUIRE(!g.accumulate, "gemm: accumulate is not built for bf16-stored operands");
     return addhip::gemm_bf16_dispatch(g, st);
   }
-  if (g.M <= SMALL_M && g.a_kcontig && !g.a_mean && g.split_k <= 1) {
+  ADDHIP_REQUIRE(g.C || g.split_k <= 1, "gemm: split-K slabs are fp32 (C)");
+  if (g.M <= SMALL_M && g.a_kcontig && !g.a_mean && g.split_k <= 1 && !g.C16) {  // (the few-row kernel writes fp32 C only)
     if (g.b_kcontig) hipLaunchKernelGGL(gemm_small_m_kernel<true>, dim3((g.N + 3) / 4), dim3(256), 0, st, g);
     else hipLaunchKernelGGL(gemm_small_m_kernel<false>, dim3((g.N + 31) / 32), dim3(256), 0, st, g);
     return addhip::check_launch("gemm_small_m_kernel");

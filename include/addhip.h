@@ -234,8 +234,9 @@ typedef struct {
   int32_t accumulate;
   /* bf16 STORAGE (agent.matmul_precision = bf16).  operands_bf16 != 0: A and B point at bf16 values (lda / ldb count bf16 elements; K or the
    * contiguous extent, and the leading dimensions, multiples of 8), products by v_mfma_f32_32x32x16_bf16 with fp32 accumulation, no
-   * conversion anywhere.  C16 (optional): a second copy of the result rounded to bf16 (nearest even), leading dimension ldc16; with it C
-   * may be NULL.  Epilogues, sign bits, column sums and split-K slabs (fp32) as for fp32 operands; no fused normalisation. */
+   * conversion anywhere.  Epilogues, sign bits, column sums and split-K slabs (fp32) as for fp32 operands; no fused normalisation.
+   * C16 (optional, with fp32 operands too): a second copy of the result rounded to bf16 (nearest even), leading dimension ldc16; with
+   * it C may be NULL (not with split-K slabs, which are fp32). */
   int32_t operands_bf16;
   uint16_t* C16;
   int32_t ldc16;

@@ -309,6 +309,31 @@ def test_gemm_bf16_storage_256_tiles(a_kc, b_kc, monkeypatch):
     run_gemm_bf16(256, 512, 4096, a_kc, b_kc, split_k=6)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x2"])
+def test_gemm_fp32_operands_write_a_bf16_copy(precision):
+    """C16 with fp32 operands (what the bf16-storage plan uses for the actor head's dX): the fp32 result rounded to nearest even,
+    with and without the fp32 C, also for a few-row launch (which must not take the fp32-only few-row kernel)."""
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import gemm
+
+    prec = {"fp32": L.PREC_F32, "bf16x2": L.PREC_BF16X2}[precision]
+    rng = np.random.RandomState(5)
+    for M, N, K in ((4100, 512, 32), (5, 512, 64)):
+        A, B = T(rng.uniform(-1, 1, (M, K)).astype(F)), T(rng.uniform(-1, 1, (N, K)).astype(F))
+        C = torch.zeros(M, N, device="cuda")
+        C16 = torch.full((M, N), 9.0, device="cuda", dtype=torch.bfloat16)
+        C16b = torch.full((M, N), 9.0, device="cuda", dtype=torch.bfloat16)
+        g = gemm(M, N, K, L.ptr(A), K, 1, L.ptr(B), K, 1, L.ptr(C), N, precision=prec, C16=L.ptr(C16), ldc16=N)
+        L.call("addhip_gemm_f32", g, L.current_stream())
+        g2 = gemm(M, N, K, L.ptr(A), K, 1, L.ptr(B), K, 1, None, N, precision=prec, C16=L.ptr(C16b), ldc16=N)
+        L.call("addhip_gemm_f32", g2, L.current_stream())
+        torch.cuda.synchronize()
+        ref = A.double() @ B.double().t()
+        assert float((C.double() - ref).abs().max()) < (1e-5 if precision == "fp32" else 2e-3)
+        assert torch.equal(C16, C.to(torch.bfloat16)) and torch.equal(C16b, C16)
+
+
 def test_to_bf16_rounds_to_nearest_even():
     import torch
     import add_gym_amd._lib as L
