@@ -103,3 +103,31 @@ def test_stand_holds_on_stiff_ankles_and_tips_slowly_on_the_robot_gains():
     for _ in range(200):
         s1, _ = RB.step(m, RB.RigidParams(max_torque=1e9, substeps=1), kp, kv, s1, np.zeros((1, 29)))
     assert abs(s1.root_pos[0, 2] - s.root_pos[0, 2]) < 0.005 and s1.root_quat[0, 0] > 0.9998
+
+
+def test_chain_table_of_the_four_lane_kernel():
+    """RigidModelTables.chain_table(): G1 cuts into left leg | right leg | waist + left arm | right arm (the right arm hangs off the
+    torso = step 2 of lane 2, so it starts at step 3); every body appears once, in depth-first order along its chain; a tree
+    that needs more than 10 steps or 4 chains has no table (the one-lane kernel handles it)."""
+    import add_gym_amd  # noqa: F401
+    from add_gym_amd.engine.rigid_model import RigidModelTables
+
+    t = RigidModelTables(G1_XML)
+    tab = t.chain_table()
+    assert tab.shape == (4, 16) and tab.dtype == np.int32
+    assert tab[:, 0].tolist() == [6, 6, 10, 7] and tab[:, 1].tolist() == [0, 0, 0, 3] and tab[:, 2].tolist() == [-1, -1, -1, 2]
+    bodies = np.concatenate([tab[q, 3:3 + tab[q, 0]] for q in range(4)])
+    assert sorted(bodies.tolist()) == list(range(1, t.num_bodies))
+    for q in range(4):
+        run = tab[q, 3:3 + tab[q, 0]]
+        assert np.all(np.diff(run) == 1) and all(t.topo[k, 0] == k - 1 for k in run[1:])
+        par = int(t.topo[run[0], 0])
+        if tab[q, 2] < 0:
+            assert par == 0
+        else:
+            a = int(tab[q, 2])
+            assert par == tab[a, 3 + (tab[q, 1] - 1 - tab[a, 1])]  # the attach body sits one step before this chain's start
+    assert (tab[:, 0] + tab[:, 1]).max() <= RigidModelTables.MAX_CHAIN_STEPS
+    t2 = copy.copy(t)
+    t2.MAX_CHAIN_STEPS = 9
+    assert t2.chain_table() is None
