@@ -230,6 +230,48 @@ def test_relu_sign_bits_roundtrip(N, precision):
     torch.testing.assert_close(cs_b, cs_f, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("N", [1024, 1000, 104])
+def test_relu_sign_bits_roundtrip_bf16_storage(N):
+    """The same round trip with bf16-stored operands and bf16 results (gemm_bf16_kernel's shared epilogue: sign-bit words assembled per
+    row and stored by one lane per row; read back one word per row and handed out by readlane): bits == (h > 0) for the bf16 h that
+    was stored, and the MASK epilogue gives the same dX from the bits as from an fp32 mask."""
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import gemm
+
+    M, K = 16384 + 9, 128
+    rng = np.random.RandomState(6)
+    bf = lambda a: torch.tensor(a).to(torch.bfloat16).cuda()
+    dA, dB, dbias = bf(rng.uniform(-1, 1, (M, K)).astype(F)), bf(rng.uniform(-1, 1, (N, K)).astype(F)), T(rng.uniform(-1, 1, N).astype(F))
+    ldb = (N + 31) // 32
+    ld16 = (N + 7) // 8 * 8
+    H = torch.zeros(M, N, device="cuda")
+    H16 = torch.zeros(M, ld16, device="cuda", dtype=torch.bfloat16)
+    bits = torch.full((M, ldb), -1, dtype=torch.int32, device="cuda")
+    st = L.current_stream()
+    k16 = dict(precision=L.PREC_BF16, operands_bf16=1)
+    L.call("addhip_gemm_f32", gemm(M, N, K, L.ptr(dA), K, 1, L.ptr(dB), K, 1, L.ptr(H), N, 2, L.ptr(dbias), relu_bits=L.ptr(bits), ldbits=ldb,
+                                   C16=L.ptr(H16), ldc16=ld16, **k16), st)
+    torch.cuda.synchronize()
+    h = H.cpu().numpy()
+    w = bits.cpu().numpy().astype(np.uint32)
+    got = ((w[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(M, ldb * 32)
+    assert np.array_equal(got[:, :N], (h > 0).astype(np.uint32)) and np.all(got[:, N:] == 0)
+    assert torch.equal(H16[:, :N], H.to(torch.bfloat16)) and 0.3 < got[:, :N].mean() < 0.7
+    K2 = 256
+    dY, W2t = bf(rng.uniform(-1, 1, (M, K2)).astype(F)), bf(rng.uniform(-1, 1, (N, K2)).astype(F))  # W^T [in, out]: k-contiguous
+    out_f, out_b = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda")
+    out16 = torch.zeros(M, ld16, device="cuda", dtype=torch.bfloat16)
+    cs_f, cs_b = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    L.call("addhip_gemm_f32", gemm(M, N, K2, L.ptr(dY), K2, 1, L.ptr(W2t), K2, 1, L.ptr(out_f), N, 3, mask=L.ptr(H), ldmask=N, colsum=L.ptr(cs_f), **k16), st)
+    L.call("addhip_gemm_f32", gemm(M, N, K2, L.ptr(dY), K2, 1, L.ptr(W2t), K2, 1, L.ptr(out_b), N, 3, mask_bits=L.ptr(bits), ldbits=ldb,
+                                   colsum=L.ptr(cs_b), C16=L.ptr(out16), ldc16=ld16, **k16), st)
+    torch.cuda.synchronize()
+    assert torch.equal(out_b, out_f) and float((out_f != 0).float().mean()) > 0.3
+    assert torch.equal(out16[:, :N], out_b.to(torch.bfloat16))
+    torch.testing.assert_close(cs_b, cs_f, rtol=1e-4, atol=1e-3)
+
+
 def run_gemm_bf16(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, seed=0, both_outputs=True):
     """Operands STORED as bf16 (addhip_gemm_t.operands_bf16): the products are exact, so against float64 on the same bf16 values the
     only error is the fp32 accumulation; the optional bf16 result copy must be the fp32 result rounded to nearest even."""
