@@ -11,9 +11,10 @@ def _init_distributed():
     """main.py:128-176: auto-detect torchrun, bind the rank to its GPU, init RCCL."""
     if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ or int(os.environ["WORLD_SIZE"]) == 1:
         return False
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))  # one process per GPU
-    torch.distributed.init_process_group(backend="nccl")  # "nccl" is RCCL on ROCm
+    from . import launch
+
+    launch.bind_device(int(os.environ.get("LOCAL_RANK", 0)))  # one process per GPU; a LOCAL_RANK past the visible devices is an error
+    torch.distributed.init_process_group(backend=launch.backend())  # "nccl" is RCCL on ROCm
     return True
 
 
@@ -49,10 +50,19 @@ def main(argv=None):
 
     argv = list(sys.argv[1:] if argv is None else argv)
     name = "train"
+    gpus = 1
     for a in list(argv):
         if a.startswith("--config-name="):
             name = a.split("=", 1)[1]
             argv.remove(a)
+        elif a.startswith("--gpus="):  # `python -m add_gym_amd.main --gpus=8 ...` == torchrun --nproc_per_node=8 (sagemaker-entrypoint.sh:139-147)
+            gpus = int(a.split("=", 1)[1])
+            argv.remove(a)
+    if gpus > 1 and "RANK" not in os.environ:
+        from . import launch
+
+        launch.check_world_fits(gpus, torch.cuda.device_count())  # counting devices does not initialise the GPU
+        raise SystemExit(launch.spawn_ranks(["-m", "add_gym_amd.main", f"--config-name={name}"] + argv, gpus))
     cfg = load_config(name, argv)
     if cfg["mode"] == "train":
         distributed = _init_distributed()

@@ -245,6 +245,18 @@ def cpu_baseline(num_envs, steps_per_iter):
 
 def main():
     a = parse()
+    from add_gym_amd import launch
+
+    if not launch.launched_by_a_launcher():
+        if a.gpus > 1:
+            # `python bench.py --gpus N` with no launcher around it: this process becomes the launcher (it never touches the GPU;
+            # counting devices does not initialise HIP) and every rank is a fresh child of this same file.
+            import torch
+
+            launch.check_world_fits(a.gpus, torch.cuda.device_count())
+            raise SystemExit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], a.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%s ranks" % (a.gpus, os.environ["WORLD_SIZE"]))
     # stdout carries exactly one thing: the JSON line.  Libraries that print there (RCCL's version banner at communicator
     # creation, for one) are sent to stderr for the whole run; the line itself goes to the saved descriptor.
     sys.stdout.flush()
@@ -256,9 +268,8 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the hot path is HIP-only)")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    launch.check_world_fits(world, torch.cuda.device_count())
+    launch.bind_device(local_rank)
     distributed = world > 1 or a.exercise_exchange
     if distributed and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -268,7 +279,7 @@ def main():
     if distributed:
         # "nccl" is RCCL on ROCm.  ADDHIP_DIST_BACKEND=gloo exists only to rehearse the multi-rank plumbing on a box with
         # fewer GPUs than ranks (several ranks then share a device); it is never the measured configuration.
-        dist.init_process_group(backend=os.environ.get("ADDHIP_DIST_BACKEND", "nccl"))
+        dist.init_process_group(backend=launch.backend())
     import add_gym_amd  # noqa: F401
     from add_gym_amd.config import load_config
     from add_gym_amd.learning.add_agent import ADDAgent
@@ -318,6 +329,8 @@ def main():
         "config": {"workload": "G1 walk-like synthetic motion, num_envs=%d/GPU, fp32 PPO + ADD discriminator (BASELINE configs[1])" % a.envs,
                    "envs_per_gpu": a.envs, "steps_per_iter": agent.T, "update_epochs": agent._update_epochs, "minibatch_rows": agent.Mb,
                    "params": agent.calc_num_params(), "parallelism": "dp%d (envs sharded, gradient all-reduce)" % world},
+        "dist": {"backend": dist.get_backend() if distributed else None, "group_size": dist.get_world_size() if distributed else 1,
+                 "launcher": "torchrun/env" if "TORCHELASTIC_RUN_ID" in os.environ else ("bench.py --gpus" if launch.launched_by_a_launcher() else None)},
     }
     if rank == 0:
         print(f"[bench] timed region done: {env_steps / dt:.0f} env-steps/s; measuring kernels + cpu baseline", file=sys.stderr, flush=True)

@@ -76,3 +76,29 @@ def test_two_ranks_share_the_gpu_over_gloo_agent_level(tmp_path):
     assert res["params_equal_after_iter"] and res["params_moved"], res
     assert res["obs_norm_equal"] and res["obs_norm_count"] == res["expected_count"], res
     assert res["finite"], res
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_starts_two_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it — the shape of the driver's N-GPU command — must itself start one
+    process per rank (the reference's launcher: sagemaker-entrypoint.sh:139-147 -> add_gym/main.py:128-176) and report the group it
+    ran in.  One GPU here, so the two ranks share it under the gloo rehearsal switch; without the switch the launcher must refuse."""
+    if not _gpu_untouched():
+        pytest.skip("this process already holds the GPU: run tests/test_00_dist_gpu.py first (it does, in directory order)")
+    import torch
+
+    base = {k: v for k, v in _env().items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ADDHIP_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs", "256", "--steps", "1", "--warmup", "1", "--no-alt", "--no-cpu-baseline"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, env=base, cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "one process per GPU" in r.stderr, r.stderr[-2000:]
+    r = subprocess.run(cmd, env=dict(base, ADDHIP_DIST_BACKEND="gloo"), cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["dist"]["group_size"] == 2 and res["dist"]["backend"] == "gloo", res
+    assert res["dist"]["launcher"] == "bench.py --gpus"
+    assert res["config"]["envs_per_gpu"] == 256 and res["scaling"] == "weak"
+    assert abs(res["value"] - 2 * 256 * res["config"]["steps_per_iter"] / (res["ms_per_step"] * 1e-3)) <= 1e-6 * res["value"]
+    assert "REHEARSAL" in res["data"] and "roofline" in res
