@@ -75,6 +75,11 @@ class RigidModelT(C.Structure):
                 ("limit_margin", C.c_float), ("termination_mask", C.c_uint32), ("env_scale", f32p), ("chains", f32p)]
 
 
+class RigidDrT(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("resample_interval", C.c_int32), ("push_interval", C.c_int32), ("gain_lo", C.c_float), ("gain_hi", C.c_float),
+                ("friction_lo", C.c_float), ("friction_hi", C.c_float), ("push_velocity", C.c_float)]
+
+
 RIGID_BODY_W, RIGID_TOPO_W = 32, 8
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
 PREC_F32, PREC_BF16, PREC_BF16X2, PREC_BF16X3 = 0, 1, 2, 3
@@ -89,6 +94,7 @@ SIGNATURES = {
     "addhip_motion_lookup": [P(MotionT), vp, vp, i32, vp, vp, vp, vp],
     "addhip_kin_engine_step": [vp, vp, vp, i32, i32, f32, f32, vp],
     "addhip_rigid_step": [P(RigidModelT), vp, vp, vp, i32, i32, vp, vp, vp],
+    "addhip_rigid_randomize": [P(RigidDrT), vp, vp, i32, vp, i32, vp],
     "addhip_gemm_f32": [P(GemmT), vp],
     "addhip_to_bf16": [vp, vp, i64, i32, i32, i32, vp],
     "addhip_to_bf16_t": [vp, vp, i32, i32, i32, i32, vp],
@@ -145,9 +151,10 @@ def load():
     lib.addhip_last_error.restype = C.c_char_p
     lib.addhip_version.restype = C.c_int
     lib.addhip_abi_sizes.argtypes, lib.addhip_abi_sizes.restype = [C.POINTER(C.c_int32), C.c_int32], C.c_int
-    sizes = (C.c_int32 * 8)()
-    mine = [C.sizeof(t) for t in (MotionT, TaskT, EnvT, StepOutT, SamplerT, GemmT, GatherT, RigidModelT)]
-    if lib.addhip_abi_sizes(sizes, 8) != 8 or list(sizes) != mine:
+    structs = (MotionT, TaskT, EnvT, StepOutT, SamplerT, GemmT, GatherT, RigidModelT, RigidDrT)
+    sizes = (C.c_int32 * len(structs))()
+    mine = [C.sizeof(t) for t in structs]
+    if lib.addhip_abi_sizes(sizes, len(structs)) != len(structs) or list(sizes) != mine:
         raise AddhipError(f"struct layouts of this binding {mine} do not match {LIB_PATH} {list(sizes)}: rebuild the library")
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -21,6 +21,7 @@
 // 4 branch accumulators x 27 floats = 532 floats (133 KB per workgroup) + 11 KB of model constants staged once per workgroup;
 // body velocities / up-vectors live in private (scratch) arrays that stay in L2.
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -900,7 +901,69 @@ __global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M,
 #undef PL
 }
 
+
+// ------------------------------------------------------------------ domain randomisation (build-defined extension; the reference has none)
+// One launch per control step, BEFORE the physics step, driven by a device-resident control-step counter so that a captured
+// hipGraph replays it unchanged: step index s = counter[0]; when due, env_scale[N,2] is redrawn (Philox stream (8<<40)+s) and the
+// root's horizontal velocity is kicked (stream (9<<40)+s); one Philox call serves two envs.  The last workgroup to finish (ticket in
+// counter[1]) leaves counter = {s+1, 0}: every workgroup has read s before it takes its ticket.
+__global__ __launch_bounds__(256) void rigid_dr_kernel(addhip_rigid_dr_t d, float* env_scale, float* sim_vel, int n, unsigned long long* counter,
+                                                       int advance) {
+  const unsigned long long s = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool scale = advance ? (s > 0 && d.resample_interval > 0 && s % (unsigned)d.resample_interval == 0) : true;
+  const bool push = advance && s > 0 && d.push_interval > 0 && s % (unsigned)d.push_interval == 0;
+  if (scale || push) {
+    const float gw = d.gain_hi - d.gain_lo, fw = d.friction_hi - d.friction_lo;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; 2 * q < n; q += (long long)gridDim.x * blockDim.x) {
+      const long long e0 = 2 * q;
+      const bool two = e0 + 1 < n;
+      if (scale) {
+        const U4 r = philox((uint64_t)q, (8ull << 40) + s, d.seed);
+        env_scale[2 * e0 + 0] = d.gain_lo + u01(r.x) * gw;
+        env_scale[2 * e0 + 1] = d.friction_lo + u01(r.y) * fw;
+        if (two) {
+          env_scale[2 * e0 + 2] = d.gain_lo + u01(r.z) * gw;
+          env_scale[2 * e0 + 3] = d.friction_lo + u01(r.w) * fw;
+        }
+      }
+      if (push) {
+        const U4 r = philox((uint64_t)q, (9ull << 40) + s, d.seed);
+        float* v0 = sim_vel + e0 * 36;
+        v0[0] += (2.f * u01(r.x) - 1.f) * d.push_velocity;
+        v0[1] += (2.f * u01(r.y) - 1.f) * d.push_velocity;
+        if (two) {
+          v0[36] += (2.f * u01(r.z) - 1.f) * d.push_velocity;
+          v0[37] += (2.f * u01(r.w) - 1.f) * d.push_velocity;
+        }
+      }
+    }
+  }
+  if (advance) {
+    __syncthreads();  // every wave of this workgroup holds s
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned long long ticket = atomicAdd(counter + 1, 1ull);
+      if (ticket == gridDim.x - 1) {
+        __hip_atomic_store(counter, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(counter + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int addhip_rigid_randomize(const addhip_rigid_dr_t* dr, float* env_scale, float* sim_vel, int32_t num_envs, uint64_t* step_counter,
+                                      int32_t advance, void* stream) {
+  ADDHIP_REQUIRE(dr && env_scale && sim_vel && step_counter && num_envs > 0, "rigid_randomize: bad arguments");
+  ADDHIP_REQUIRE(dr->resample_interval >= 0 && dr->push_interval >= 0, "rigid_randomize: negative interval");
+  ADDHIP_REQUIRE(dr->gain_lo > 0.f && dr->gain_hi >= dr->gain_lo && dr->friction_lo >= 0.f && dr->friction_hi >= dr->friction_lo, "rigid_randomize: bad ranges");
+  long long g = ((num_envs + 1) / 2 + 255) / 256;
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(rigid_dr_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *dr, env_scale, sim_vel, num_envs,
+                     reinterpret_cast<unsigned long long*>(step_counter), (int)(advance != 0));
+  return addhip::check_launch("rigid_dr_kernel");
+}
 
 extern "C" int addhip_rigid_step(const addhip_rigid_model_t* m, float* sim_pose, float* sim_vel, const float* target, int32_t target_stride,
                                  int32_t num_envs, uint8_t* contact_flag, uint32_t* contact_bits, void* stream) {

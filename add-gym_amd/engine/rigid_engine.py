@@ -61,31 +61,49 @@ class RigidEntity(BaseEntity):
         self._own_target = torch.zeros(n, 32, device=device)
         self._target = self._own_target
         # domain randomisation (build-defined extension, off by default; the reference has none): per-env PD gain scale and
-        # ground friction, redrawn every `resample_interval` control steps, plus random horizontal pushes of the root
+        # ground friction, redrawn every `resample_interval` control steps, plus random horizontal pushes of the root.  Drawn on the
+        # device by addhip_rigid_randomize from a device-resident control-step counter: part of a captured rollout like any other launch
         dr = self._opts.get("domain_randomization") or {}
         self._dr = dict(dr) if dr.get("enabled", False) else None
         self.env_scale = None
         self._steps = 0
         if self._dr is not None:
+            d = self._dr
             self.env_scale = torch.ones(n, 2, device=device)
-            self._dr_u = torch.zeros(n, 2, device=device)
-            self._dr_seed = int(self._dr.get("seed", 0))
-            self._resample_scales()
+            self._d_steps = torch.zeros(2, dtype=torch.int64, device=device)  # [control-step index, ticket scratch]
+            g0, g1 = d.get("gain_scale", [1.0, 1.0])
+            f0, f1 = d.get("friction", [self._opts["friction"]] * 2)
+            self._dr_c = L.RigidDrT(int(d.get("seed", 0)), int(d.get("resample_interval", 0)), int(d.get("push_interval", 0)), float(g0), float(g1),
+                                    float(f0), float(f1), float(d.get("push_velocity", 0.5)))
+            L.call("addhip_rigid_randomize", self._dr_c, L.ptr(self.env_scale), L.ptr(self.vel), n, L.ptr(self._d_steps), 0, L.current_stream())
+        self._tables_on_device = None
         self._upload()
 
     def _upload(self):
+        """Model tables -> device.  The device buffers are allocated ONCE and refreshed in place, so the addresses a captured rollout
+        has baked into its launches stay valid when gains change; the scalar fields of c_struct (termination mask, step sizes) are
+        launch arguments by value, so `model_version` tells a holder of captured launches to re-capture."""
         t, o, dev = self.tables, self._opts, self._device
-        self._d_body = torch.tensor(t.body, device=dev)
-        self._d_topo = torch.tensor(t.topo, device=dev)
-        self._d_points = torch.tensor(t.points if t.num_points else np.zeros((1, 4), np.float32), device=dev)
         # four lanes per env (one per chain of the tree) unless the tree does not fit or the option asks for the one-lane kernel
         chains = t.chain_table() if int(o.get("lanes_per_env", 4)) == 4 else None
-        self._d_chains = torch.tensor(chains, device=dev) if chains is not None else None
+        host = dict(body=t.body, topo=t.topo, points=t.points if t.num_points else np.zeros((1, 4), np.float32), chains=chains)
+        if self._tables_on_device is None:
+            self._tables_on_device = {k: (torch.tensor(v, device=dev) if v is not None else None) for k, v in host.items()}
+        else:
+            for k, v in host.items():
+                d = self._tables_on_device[k]
+                if (v is None) != (d is None) or (v is not None and tuple(v.shape) != tuple(d.shape)):
+                    raise RuntimeError(f"rigid model table '{k}' changed shape after build")
+                if v is not None:
+                    d.copy_(torch.as_tensor(v))
+        dv = self._tables_on_device
+        self._d_body, self._d_topo, self._d_points, self._d_chains = dv["body"], dv["topo"], dv["points"], dv["chains"]
         self.c_struct = L.RigidModelT(t.num_bodies, t.num_points, L.ptr(self._d_body), L.ptr(self._d_topo), L.ptr(self._d_points),
                                       float(o["dt"]), int(o["substeps"]), float(o["gravity"]), float(o["contact_stiffness"]),
                                       float(o["contact_damping"]), float(o["friction"]), float(o["friction_vel_eps"]),
                                       float(o["limit_stiffness"]), float(o["max_torque"]), float(o["position_limit_margin"]), int(self._term_mask),
                                       L.ptr(self.env_scale), L.ptr(self._d_chains))
+        self.model_version = getattr(self, "model_version", 0) + 1
         self._dirty = False
 
     def set_termination_links(self, allowed_link_names):
@@ -217,31 +235,11 @@ class RigidEntity(BaseEntity):
     links = property(lambda s: s._links)
     n_dofs = property(lambda s: s._n_dofs)
 
-    def _resample_scales(self):
-        """env_scale[:, 0] ~ U(gain_scale range), env_scale[:, 1] ~ U(friction range); Philox draws keyed by the control-step count."""
-        d = self._dr
-        L.call("addhip_fill_uniform", L.ptr(self._dr_u), 2 * self.n, self._dr_seed, (8 << 40) + self._steps, L.current_stream())
-        g0, g1 = d.get("gain_scale", [1.0, 1.0])
-        f0, f1 = d.get("friction", [self._opts["friction"]] * 2)
-        lo = torch.tensor([float(g0), float(f0)], device=self._device)
-        hi = torch.tensor([float(g1), float(f1)], device=self._device)
-        torch.addcmul(lo, self._dr_u, hi - lo, out=self.env_scale)
-
-    def _randomize(self):
-        d = self._dr
-        every = int(d.get("resample_interval", 0))
-        if every > 0 and self._steps > 0 and self._steps % every == 0:
-            self._resample_scales()
-        push = int(d.get("push_interval", 0))
-        if push > 0 and self._steps > 0 and self._steps % push == 0:  # horizontal velocity kick of the root, |dv| <= push_velocity per axis
-            L.call("addhip_fill_uniform", L.ptr(self._dr_u), 2 * self.n, self._dr_seed, (9 << 40) + self._steps, L.current_stream())
-            self.vel[:, 0:2] += (2.0 * self._dr_u - 1.0) * float(d.get("push_velocity", 0.5))
-
     def step(self):
         if self._dirty:
             self._upload()
-        if self._dr is not None:
-            self._randomize()
+        if self._dr is not None:  # redraws / pushes due at this control step, then the device counter advances
+            L.call("addhip_rigid_randomize", self._dr_c, L.ptr(self.env_scale), L.ptr(self.vel), self.n, L.ptr(self._d_steps), 1, L.current_stream())
         self._steps += 1
         L.call("addhip_rigid_step", self.c_struct, L.ptr(self.pose), L.ptr(self.vel), L.ptr(self._target), int(self._target.shape[-1]), self.n,
                L.ptr(self.contact), L.ptr(self.contact_bits), L.current_stream())

@@ -180,7 +180,7 @@ class ADDAgent:
         # come from a device counter advanced once per iteration, so every replay draws fresh numbers -- the same numbers the
         # call-by-call path draws (the two are bit-identical; tests/test_hip_agent.py).
         self._rollout_graph = bool(cfg.get("rollout_graph", False))
-        self._graphs, self._graph_warm = {}, False
+        self._graphs, self._graph_warm, self._graph_model_version = {}, False, None
         self._sid_base = torch.zeros(1, dtype=torch.int64, device=dev)
         # optional externally supplied random draws (parity tests replay the reference's draws through these):
         #   {"noise": [T][N,29], "uniforms": {Philox stream id (stream_* below): [3,N]}, "perms": iterator of int64 permutations, "pre_step": fn(t)}
@@ -545,10 +545,9 @@ class ADDAgent:
 
     def _graph_ok(self):
         """A rollout can be replayed from a graph when nothing in it depends on host state that changes between iterations:
-        engine state shared in place, no injected draws, constant exploration probability, no host-driven randomisation."""
-        ent = self._env.robot.entity
-        return (self._fast_engine and self.inject is None and not math.isfinite(self._exp_anneal_samples) and self._exp_prob_beg >= 1.0
-                and getattr(ent, "_dr", None) is None)
+        engine state shared in place, no injected draws, constant exploration probability.  (The rigid engine's domain
+        randomisation is drawn on the device from a device-resident step counter, addhip_rigid_randomize: it is captured too.)"""
+        return self._fast_engine and self.inject is None and not math.isfinite(self._exp_anneal_samples) and self._exp_prob_beg >= 1.0
 
     def _rollout_body_relative(self):
         """The T steps with stream ids relative to the device counter (what the graph captures; also run eagerly once)."""
@@ -563,10 +562,16 @@ class ADDAgent:
         T = self.T
         self._sid_base.fill_(self._iter * T)  # outside the graph: the only per-iteration input of the rollout
         h0 = self._head
+        # the engine's model (gains, termination links) may have been changed since the last capture: refresh its device tables in
+        # place now -- never inside a capture -- and drop graphs whose launches carry the old by-value fields
+        ent = self._env.robot.entity
+        if getattr(ent, "_dirty", False):
+            ent._upload()
+        ver = getattr(ent, "model_version", 0)
+        if ver != self._graph_model_version:
+            self._graphs.clear()
+            self._graph_model_version = ver
         if not self._graph_warm:  # first use: run eagerly so that every kernel is loaded before a capture starts
-            ent = self._env.robot.entity
-            if getattr(ent, "_dirty", False):
-                ent._upload()
             self._rollout_body_relative()
             self._graph_warm = True
             return

@@ -1,8 +1,16 @@
-"""Console table + log.txt writer, byte-compatible with the reference's add_gym/util/logger.py:
-the key set is fixed by the first row (:67-83), the console table prints floats as %8.3g and ints as
-str (:86-114), log.txt rows are `{:<25}` columns of str(val) terminated by a carriage return (:116-143),
-and with torch.distributed initialised every logged scalar is replaced by its mean over ranks, ints cast
-back to int (:160-184).  Same class and method names, so code written against the reference's logger runs."""
+"""Console table + log.txt writer behind the reference's `Logger` surface (add_gym/util/logger.py: class and method names,
+argument meaning, and the bytes that reach the console and log.txt; pinned by tests/golden/logger.npz, which holds what the
+reference's own Logger wrote for the same rows).
+
+The format, as the fixture fixes it: the first row decides the columns and their order, a later row may not add one; the console
+table is a dashed rule, one `| key | value |` line per non-quiet column (keys right-aligned to the longest key, values %8.3g for
+floats and str() for ints, right-aligned to 15) and a closing rule; log.txt is 25-wide left-aligned columns of str(value), a
+header line before the first row, every line ended by a bare carriage return.  Under torch.distributed every value is replaced by
+its mean over ranks before it is shown, int-typed values staying ints, and only rank 0 prints or writes.
+
+Own design below that surface: the row is a list of column records plus a name index; the cross-rank mean is one float64
+all-reduce of the whole row.
+"""
 import atexit
 import os
 import time
@@ -10,16 +18,25 @@ import time
 import torch
 import torch.distributed as dist
 
+_COLUMN_WIDTH = 25  # log.txt
+_VALUE_WIDTH = 15   # console
+
+
+class _Column:
+    __slots__ = ("name", "val", "quiet")
+
+    def __init__(self, name):
+        self.name, self.val, self.quiet = name, None, False
+
+
+def _group_active():
+    return dist.is_available() and dist.is_initialized()
+
 
 class Logger:
-    class Entry:
-        def __init__(self, val, quiet=False):
-            self.val = val
-            self.quiet = quiet
-
     @staticmethod
     def is_root():
-        return (not dist.is_initialized()) or dist.get_rank() == 0
+        return not _group_active() or dist.get_rank() == 0
 
     @staticmethod
     def print(msg, end=None):
@@ -28,111 +45,104 @@ class Logger:
 
     def __init__(self):
         self.output_file = None
-        self.log_headers = []
-        self.log_current_row = {}
-        self._dump_str_template = ""
-        self._max_key_len = 0
-        self._row_count = 0
-        self._need_update = True
-        self._data_buffer = None
+        self._clear_rows()
 
+    def _clear_rows(self):
+        self._columns = []        # _Column records in first-row order
+        self._where = {}          # name -> position in _columns
+        self._rows_written = 0
+        self._pending_mean = False  # values logged since the last cross-rank mean
+        self._exchange = None
+
+    # ---- configuration
     def reset(self):
-        self._row_count = 0
-        self.log_headers = []
-        self.log_current_row = {}
-        self._need_update = True
-        self._data_buffer = None
+        self._clear_rows()
         if self.output_file is not None:
             self.output_file.truncate(0)
 
     def configure_output_file(self, filename=None):
-        self._row_count = 0
-        self.log_headers = []
-        self.log_current_row = {}
-        output_path = filename or "output/log_%i.txt" % int(time.time())
-        out_dir = os.path.dirname(output_path)
-        if Logger.is_root():
-            if out_dir and not os.path.exists(out_dir):
-                os.makedirs(out_dir, exist_ok=True)
-            # newline="": the row terminator is a bare "\r" on every platform, as the reference writes it
-            self.output_file = open(output_path, "w", newline="")
-            atexit.register(self.output_file.close)
-            Logger.print("Logging data to " + self.output_file.name)
+        self._clear_rows()
+        path = filename if filename else "output/log_%i.txt" % int(time.time())
+        if not Logger.is_root():
+            return
+        folder = os.path.dirname(path)
+        if folder:
+            os.makedirs(folder, exist_ok=True)
+        self.output_file = open(path, "w", newline="")  # newline="": the "\r" line ends reach the file untranslated
+        atexit.register(self.output_file.close)
+        Logger.print("Logging data to " + self.output_file.name)
 
+    # ---- one row
     def log(self, key, val, quiet=False, **kwargs):
-        if self._row_count == 0 and key not in self.log_headers:
-            self.log_headers.append(key)
-            self._max_key_len = max(self._max_key_len, len(key))
-        elif key not in self.log_headers:
-            raise AssertionError("Trying to introduce a new key %s that you didn't include in the first iteration" % key)
-        self.log_current_row[key] = Logger.Entry(val, quiet)
-        self._need_update = True
+        pos = self._where.get(key)
+        if pos is None:
+            assert self._rows_written == 0, "Trying to introduce a new key %s that you didn't include in the first iteration" % key
+            pos = self._where[key] = len(self._columns)
+            self._columns.append(_Column(key))
+        col = self._columns[pos]
+        col.val, col.quiet = val, quiet
+        self._pending_mean = True
 
     def get_num_keys(self):
-        return len(self.log_headers)
+        return len(self._columns)
 
     def has_key(self, key):
-        return key in self.log_headers
+        return key in self._where
 
     def get_current_val(self, key):
-        e = self.log_current_row.get(key)
-        return None if e is None else e.val
+        pos = self._where.get(key)
+        return None if pos is None else self._columns[pos].val
 
+    def keys(self):
+        return [c.name for c in self._columns]
+
+    log_headers = property(keys)  # the reference's attribute name, read-only here
+    rows_written = property(lambda self: self._rows_written)
+
+    # ---- output
     @staticmethod
     def format_console_value(val):
         if isinstance(val, float):
             return "%8.3g" % val
-        if isinstance(val, int):
-            return str(val)
-        return val
+        return str(val) if isinstance(val, int) else val
 
     def console_lines(self):
-        """The lines print_log prints (util/logger.py:93-114)."""
-        w = self._max_key_len
-        fmt = "| %" + str(w) + "s | %15s |"
-        lines = ["-" * (22 + w)]
-        for key in self.log_headers:
-            e = self.log_current_row[key]
-            if not e.quiet:
-                lines.append(fmt % (key, Logger.format_console_value(e.val)))
-        lines.append("-" * (22 + w))
-        return lines
-
-    def print_log(self):
-        if dist.is_initialized() and self._need_update:
-            self._mp_aggregate()
-        if Logger.is_root():
-            for line in self.console_lines():
-                print(line)
+        """The lines print_log prints for the current row."""
+        key_w = max((len(c.name) for c in self._columns), default=0)
+        rule = "-" * (key_w + _VALUE_WIDTH + 7)
+        body = ["| %*s | %*s |" % (key_w, c.name, _VALUE_WIDTH, Logger.format_console_value(c.val)) for c in self._columns if not c.quiet]
+        return [rule] + body + [rule]
 
     def row_strings(self):
-        """(header string or None, value string) of the current row, without the "\\r" terminators."""
-        template = "{:<25}" * self.get_num_keys()
-        vals = [self.log_current_row[k].val for k in self.log_headers]
-        head = template.format(*self.log_headers) if self._row_count == 0 else None
-        return head, template.format(*map(str, vals))
+        """(header line or None, value line) of the current row, without their "\\r" terminators."""
+        pad = lambda items: "".join(str(x).ljust(_COLUMN_WIDTH) for x in items)
+        head = pad(c.name for c in self._columns) if self._rows_written == 0 else None
+        return head, pad(c.val for c in self._columns)
+
+    def print_log(self):
+        self._mean_over_ranks()
+        if Logger.is_root():
+            print("\n".join(self.console_lines()))
 
     def write_log(self):
-        if dist.is_initialized() and self._need_update:
-            self._mp_aggregate()
+        self._mean_over_ranks()
         if Logger.is_root() and self.output_file is not None:
             head, row = self.row_strings()
-            if head is not None:
-                self.output_file.write(head + "\r")
-            self.output_file.write(row + "\r")
+            self.output_file.write((head + "\r" if head is not None else "") + row + "\r")
             self.output_file.flush()
-        self._row_count += 1
+        self._rows_written += 1
 
-    def _mp_aggregate(self):
-        """Mean over ranks of every logged scalar in one f64 all-reduce; int-typed entries stay ints (util/logger.py:160-184)."""
-        if self._data_buffer is None:
-            dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() and dist.get_backend() == "nccl" else torch.device("cpu")
-            self._data_buffer = torch.zeros(len(self.log_headers), dtype=torch.float64, device=dev)
-        host = torch.tensor([float(self.log_current_row[k].val) for k in self.log_headers], dtype=torch.float64)
-        self._data_buffer.copy_(host)
-        dist.all_reduce(self._data_buffer, op=dist.ReduceOp.SUM)
-        self._data_buffer /= dist.get_world_size()
-        for key, v in zip(self.log_headers, self._data_buffer.tolist()):
-            e = self.log_current_row[key]
-            e.val = int(v) if isinstance(e.val, int) else v
-        self._need_update = False
+    def _mean_over_ranks(self):
+        """Every logged scalar becomes its mean over ranks (one float64 all-reduce per row); int-typed entries stay ints."""
+        if not (_group_active() and self._pending_mean):
+            return
+        if self._exchange is None or self._exchange.numel() != len(self._columns):
+            on_gpu = torch.cuda.is_available() and dist.get_backend() == "nccl"
+            self._exchange = torch.empty(len(self._columns), dtype=torch.float64,
+                                         device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu"))
+        self._exchange.copy_(torch.tensor([float(c.val) for c in self._columns], dtype=torch.float64))
+        dist.all_reduce(self._exchange, op=dist.ReduceOp.SUM)
+        world = dist.get_world_size()
+        for c, total in zip(self._columns, self._exchange.tolist()):
+            c.val = int(total / world) if isinstance(c.val, int) else total / world
+        self._pending_mean = False

@@ -201,7 +201,7 @@ class TBLogger(logger.Logger):
 
     def key_tags(self):
         tags = []
-        for key in self.log_headers:
+        for key in self.keys():
             tag = TBLogger.MISC_TAG
             for col, keys in self._collections.items():
                 if key in keys:
@@ -210,15 +210,15 @@ class TBLogger(logger.Logger):
         return tags
 
     def write_log(self):
-        row_count = self._row_count
+        row_count = self.rows_written
         super().write_log()
         if logger.Logger.is_root() and self._writer is not None:
             if row_count == 0:
                 self._key_tags = self.key_tags()
-            step = row_count if self._step_key is None else self.log_current_row[self._step_key].val
-            for tag, key in zip(self._key_tags, self.log_headers):
+            step = row_count if self._step_key is None else self.get_current_val(self._step_key)
+            for tag, key in zip(self._key_tags, self.keys()):
                 if key != self._step_key:
-                    self._writer.add_scalar(tag, self.log_current_row[key].val, step)
+                    self._writer.add_scalar(tag, self.get_current_val(key), step)
             self._writer.flush()
 
     def add_image_png(self, tag, height, width, png_bytes, step):

@@ -36,8 +36,8 @@ enum { ADDHIP_DONE_NULL = 0, ADDHIP_DONE_FAIL = 1, ADDHIP_DONE_SUCC = 2, ADDHIP_
 
 const char* addhip_last_error(void);
 int addhip_version(void);
-/* sizeof() of addhip_motion_t, task_t, env_t, step_out_t, sampler_t, gemm_t, gather_t, rigid_model_t (in that order) -> out[0..7];
- * returns the number written (8) or -1.  For bindings to verify their struct layouts against the library they loaded. */
+/* sizeof() of addhip_motion_t, task_t, env_t, step_out_t, sampler_t, gemm_t, gather_t, rigid_model_t, rigid_dr_t (in that order) -> out[0..8];
+ * returns the number written (9) or -1.  For bindings to verify their struct layouts against the library they loaded. */
 int addhip_abi_sizes(int32_t* out, int32_t count);
 
 /* ---- reference-motion step tables: MotionLib._step_* (anim/motion_lib.py:285-320) ---- */
@@ -198,6 +198,22 @@ typedef struct {
  * the ground in the last substep; contact_bits [N] (or NULL): one bit per link. */
 int addhip_rigid_step(const addhip_rigid_model_t* m, float* sim_pose, float* sim_vel, const float* target, int32_t target_stride,
                       int32_t num_envs, uint8_t* contact_flag, uint32_t* contact_bits, void* stream);
+
+/* Domain randomisation of the rigid-body engine -- a BUILD-DEFINED EXTENSION (add-gym has no domain randomisation: SURVEY.md
+ * section 0; BASELINE configs[4] asks for it inside the hipGraph-captured rollout step).  One launch per control step, before
+ * addhip_rigid_step, driven by a DEVICE-resident counter, so a captured rollout replays it unchanged and draws what the
+ * call-by-call run draws.  step_counter = uint64[2] in device memory: [0] the control-step index s (0 at build), [1] scratch, 0
+ * between launches.  advance = 1: when s > 0 and s is a multiple of resample_interval (> 0), env_scale[N,2] = (PD gain scale, ground
+ * friction) is redrawn uniformly from the ranges (Philox stream (8<<40)+s under `seed`); when s > 0 and s is a multiple of
+ * push_interval (> 0), sim_vel[:,0:2] += U(-push_velocity, push_velocity) (stream (9<<40)+s); then step_counter[0] = s + 1.
+ * advance = 0 (initialisation): env_scale is drawn for step index s unconditionally, the counter stays. */
+typedef struct {
+  uint64_t seed;
+  int32_t resample_interval, push_interval;
+  float gain_lo, gain_hi, friction_lo, friction_hi, push_velocity;
+} addhip_rigid_dr_t;
+int addhip_rigid_randomize(const addhip_rigid_dr_t* dr, float* env_scale, float* sim_vel, int32_t num_envs, uint64_t* step_counter,
+                           int32_t advance, void* stream);
 
 /* ---- dense layers: torch.nn.Linear(+ReLU) stacks of PPOModel/ADDModel (ppo_model.py:13-21,
  *      add_model.py:12-15, nets/fc_*layers_1024units.py) on fp32 MFMA ---- */

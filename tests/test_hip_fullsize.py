@@ -227,33 +227,63 @@ def test_full_library_shard_43_clips_4096_envs():
     assert idx.min() >= 0 and idx.max() < lib.total_steps
 
 
-def test_randomised_rigid_shard_8192_envs_and_graph_rollout():
-    """BASELINE configs[4], one GPU's shard (65 536 envs over 8 GPUs = 8192 per GPU): the rigid-body engine with domain
-    randomisation (a build-defined extension: add-gym has none) through a whole iteration; and the hipGraph-captured rollout on the
-    same engine without host-driven randomisation (pushes are issued from the host, so that combination runs call by call)."""
+def test_randomised_rigid_shard_8192_envs_inside_the_graph_rollout():
+    """BASELINE configs[4] as written, one GPU's shard (65 536 envs over 8 GPUs = 8192 per GPU): the rigid-body engine WITH domain
+    randomisation (a build-defined extension: add-gym has none) inside the hipGraph-captured rollout.  The per-env gain / friction
+    redraws and the root pushes are drawn on the device from a device-resident step counter (addhip_rigid_randomize), so the rollout
+    replayed from the graph must be BIT-IDENTICAL to the same rollout issued call by call -- through the eager warm-up, the three
+    captures (one per ring phase) and pure replays, with redraws (every 5 control steps) and pushes (every 7) falling inside
+    replays; and a gain change after the captures must reach the replays (the graphs are re-captured, the tables refreshed in place)."""
     import torch
     import add_gym_amd.learning.add_agent as A
     from add_gym_amd.config import load_config
     from tests.util import kin_meta
 
-    for dr, graph in ((True, True), (False, True)):
-        cfg = load_config("train", ["engine=rigid", "engine.num_envs=8192", "agent.steps_per_iter=16", "task.motion_file=synthetic:3x120",
-                                    f"engine.domain_randomization.enabled={str(dr).lower()}", "engine.domain_randomization.push_interval=7",
+    keys = ("obs", "action", "a_logp", "done", "reward", "motion_time", "disc_obs")
+    runs = []
+    for graph in (False, True):
+        cfg = load_config("train", ["engine=rigid", "engine.num_envs=8192", "agent.steps_per_iter=16", "task.motion_file=synthetic:3x120", "seed=11",
+                                    "engine.domain_randomization.enabled=true", "engine.domain_randomization.push_interval=7",
+                                    "engine.domain_randomization.resample_interval=5", "engine.domain_randomization.seed=5",
                                     f"agent.rollout_graph={str(graph).lower()}"])
         cfg["task"]["motion_joint_order"] = kin_meta()["motion_joint_order"]
         ag = A.ADDAgent(cfg)
         ent = ag._env.robot.entity
-        assert (ent.env_scale is not None) == dr and ag._graph_ok() == (not dr)
+        assert ent.env_scale is not None and ag._graph_ok()
         ag.reset_all_envs()
         ag._init_train()
-        for _ in range(4):
-            info = ag._train_iter()
+        out = []
+        for it in range(8):
+            if it == 6:  # a model change after the captures: stiffer knees from here on
+                kp = ent._kp.clone()
+                kp[6:] *= 1.5
+                ent.set_dofs_kp(kp)
+                if graph:
+                    ptrs = (ent._d_body.data_ptr(), ent._d_chains.data_ptr())
+            if it:
+                ag._B["obs"][0].copy_(ag._B["obs"][ag.T])
+            ag._rollout_train()
             ag._iter += 1
-        torch.cuda.synchronize()
-        assert all(np.isfinite(v) for v in info.values())
-        assert torch.isfinite(ag._S["sim_pose"]).all() and torch.isfinite(ag._S["sim_vel"]).all()
-        assert (len(ag._graphs) > 0) == (not dr)
-        assert int((ag._B["done"] == 1).sum()) > 0
+            torch.cuda.synchronize()
+            out.append(dict({k: ag._B[k].clone() for k in keys}, pose=ag._S["sim_pose"].clone(), vel=ag._S["sim_vel"].clone(), scale=ent.env_scale.clone(),
+                            steps=int(ent._d_steps[0]), ticket=int(ent._d_steps[1])))
+            if graph and it == 5:
+                assert len(ag._graphs) == 3  # T = 16: the ring phase advances by 1 per iteration
+        runs.append(out)
+        if graph:
+            assert 1 <= len(ag._graphs) <= 2 and ptrs == (ent._d_body.data_ptr(), ent._d_chains.data_ptr())  # re-captured; tables refreshed in place
+            info = ag._train_iter()  # and a whole iteration (rollout from the graph + update) stays finite
+            torch.cuda.synchronize()
+            assert all(np.isfinite(v) for v in info.values())
+    for it, (a, b) in enumerate(zip(*runs)):
+        assert a["steps"] == b["steps"] == 16 * (it + 1) and a["ticket"] == b["ticket"] == 0
+        for k in a:
+            if k not in ("steps", "ticket"):
+                assert torch.equal(a[k], b[k]), (it, k)
+    eager = runs[0]
+    assert not torch.equal(eager[0]["scale"], eager[1]["scale"])          # redrawn (steps 20, 25, 30 fall in iteration 1)
+    assert 0.8 <= float(eager[-1]["scale"][:, 0].min()) and float(eager[-1]["scale"][:, 0].max()) <= 1.2
+    assert int((eager[-1]["done"] == 1).sum()) > 0 and torch.isfinite(eager[-1]["pose"]).all()
 
 
 def test_bf16_storage_mode_tracks_fp32_training():

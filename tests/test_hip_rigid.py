@@ -213,12 +213,66 @@ def test_domain_randomisation_per_env_gains_friction_and_pushes():
     scene2.step()
     torch.cuda.synchronize()
     assert np.abs(get(ent2).qd - got.qd).max() > 1e-2
-    # pushes: every 5th control step the root's horizontal velocity jumps by up to 0.6 m/s per axis
-    for _ in range(3):
+    # the draws themselves: addhip_rigid_randomize at control-step index s redraws env_scale from Philox stream (8<<40)+s and kicks the
+    # root from stream (9<<40)+s -- the numbers addhip_fill_uniform gives for those streams -- when s is due, and advances the
+    # device-resident counter either way (odd env count: the last Philox call serves one env only)
+    import add_gym_amd._lib as L
+
+    n2 = 77
+    drc = L.RigidDrT(3, 4, 5, 0.7, 1.3, 0.4, 1.2, 0.6)  # seed, resample every 4, push every 5
+    scale = torch.full((n2, 2), -1.0, device="cuda")
+    vel = torch.randn(n2, 36, device="cuda")
+    ctr = torch.zeros(2, dtype=torch.int64, device="cuda")
+    u = torch.zeros(n2, 2, device="cuda")
+    lo, width = torch.tensor([0.7, 0.4], device="cuda"), torch.tensor([0.6, 0.8], device="cuda")
+    st_ = L.current_stream()
+    L.call("addhip_rigid_randomize", drc, L.ptr(scale), L.ptr(vel), n2, L.ptr(ctr), 0, st_)  # initialisation: draws, does not advance
+    L.call("addhip_fill_uniform", L.ptr(u), 2 * n2, 3, (8 << 40) + 0, st_)
+    torch.testing.assert_close(scale, lo + u * width, rtol=0, atol=1e-6)
+    assert ctr.tolist() == [0, 0]
+    for s_ in range(0, 11):
+        scale0, vel0 = scale.clone(), vel.clone()
+        L.call("addhip_rigid_randomize", drc, L.ptr(scale), L.ptr(vel), n2, L.ptr(ctr), 1, st_)
+        assert ctr.tolist() == [s_ + 1, 0]
+        if s_ > 0 and s_ % 4 == 0:
+            L.call("addhip_fill_uniform", L.ptr(u), 2 * n2, 3, (8 << 40) + s_, st_)
+            torch.testing.assert_close(scale, lo + u * width, rtol=0, atol=1e-6)
+            assert not torch.equal(scale, scale0)
+        else:
+            assert torch.equal(scale, scale0)
+        if s_ > 0 and s_ % 5 == 0:
+            L.call("addhip_fill_uniform", L.ptr(u), 2 * n2, 3, (9 << 40) + s_, st_)
+            torch.testing.assert_close(vel[:, 0:2], vel0[:, 0:2] + (2.0 * u - 1.0) * 0.6, rtol=0, atol=1e-6)
+            assert float((vel[:, 0:2] - vel0[:, 0:2]).abs().max()) > 0.5
+        else:
+            assert torch.equal(vel[:, 0:2], vel0[:, 0:2])
+        assert torch.equal(vel[:, 2:], vel0[:, 2:])
+    # and through the engine: the entity's own counter follows its control steps; step index 5 kicks the root before the physics step
+    for _ in range(4):
         scene.step()
     torch.cuda.synchronize()
+    assert ent._d_steps.tolist() == [5, 0]
     v_before = ent.vel[:, 0:2].clone()
-    scene.step()  # step index 5: push, then the physics step
+    scene.step()
     torch.cuda.synchronize()
     dv = (ent.vel[:, 0:2] - v_before).abs().max(dim=1).values
-    assert float(dv.max()) > 0.3 and torch.isfinite(ent.vel).all()
+    assert float(dv.max()) > 0.3 and torch.isfinite(ent.vel).all() and ent._d_steps.tolist() == [6, 0]
+
+
+def test_gain_change_refreshes_the_device_tables_in_place():
+    """set_dofs_kp / set_termination_links after build: the next step uploads into the SAME device buffers (addresses baked into a
+    captured rollout stay valid) and bumps model_version (holders of captured launches re-capture: the scalar fields travel by value)."""
+    import torch
+
+    eng, scene, plane, ent, m, kp, kv = make_entity(8)
+    scene.step()
+    ptrs, ver = (ent._d_body.data_ptr(), ent._d_topo.data_ptr(), ent._d_points.data_ptr(), ent._d_chains.data_ptr()), ent.model_version
+    body0 = ent._d_body.clone()
+    ent.set_dofs_kp(torch.cat([torch.zeros(6), torch.tensor(kp * 2.0, dtype=torch.float32)]))
+    ent.set_termination_links(["left_ankle_roll_link", "right_ankle_roll_link"])
+    assert ent._dirty
+    scene.step()
+    torch.cuda.synchronize()
+    assert ptrs == (ent._d_body.data_ptr(), ent._d_topo.data_ptr(), ent._d_points.data_ptr(), ent._d_chains.data_ptr())
+    assert ent.model_version == ver + 1 and not ent._dirty
+    assert torch.equal(ent._d_body[:, 27], body0[:, 27] * 2.0) and torch.equal(ent._d_body[:, :27], body0[:, :27])
