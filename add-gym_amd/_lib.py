@@ -57,7 +57,7 @@ class GemmT(C.Structure):
                 ("bias", f32p), ("mask", f32p), ("ldmask", C.c_int32), ("a_mean", f32p), ("a_std", f32p), ("split_k", C.c_int32),
                 ("alpha", C.c_float), ("colsum", f32p), ("precision", C.c_int32),
                 ("relu_bits", f32p), ("mask_bits", f32p), ("ldbits", C.c_int32), ("accumulate", C.c_int32),
-                ("operands_bf16", C.c_int32), ("C16", f32p), ("ldc16", C.c_int32)]
+                ("operands_bf16", C.c_int32), ("C16", f32p), ("ldc16", C.c_int32), ("hint", C.c_int32)]
 
 
 class GatherT(C.Structure):
@@ -83,6 +83,7 @@ class RigidDrT(C.Structure):
 RIGID_BODY_W, RIGID_TOPO_W = 32, 8
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
 PREC_F32, PREC_BF16, PREC_BF16X2, PREC_BF16X3 = 0, 1, 2, 3
+GEMM_HINT_BIG_TILE, GEMM_HINT_NO_BIG_TILE, GEMM_HINT_ONE_STAGE, GEMM_HINT_TWO_STAGE = 1, 2, 4, 8
 
 i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
 P = C.POINTER

@@ -415,10 +415,8 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   if (narrow) return launch_cfg<128, 96, 4, 1, 32>(g, st);
   // launches with enough workgroups for 4 per CU run one LDS stage (37 KB) x 4 workgroups per CU instead of two stages x 2:
   // alone they time the same, beside the other streams' launches of an update step they overlap better (update phase -2 %)
-  {
-    static const char* sb = getenv("ADDHIP_F32_SB");
-    if (sb ? sb[0] == '1' : tiles128 >= 512) return launch_cfg<128, 128, 2, 2, 32, true>(g, st);
-  }
+  const bool one_stage = (g.hint & ADDHIP_GEMM_HINT_ONE_STAGE) ? true : (g.hint & ADDHIP_GEMM_HINT_TWO_STAGE) ? false : tiles128 >= 512;
+  if (one_stage) return launch_cfg<128, 128, 2, 2, 32, true>(g, st);
   return launch_cfg<128, 128, 2, 2, 32>(g, st);
 }
 

@@ -489,12 +489,12 @@ int gemm_bf16_dispatch(const addhip_gemm_t& g, hipStream_t st) {
   // whole-tile shapes that fill the chip AND are deep in K: at 4096^3 it runs 1040 TFLOP/s on random operands, but with the
   // 1024-deep K of the training step's launches its prologue and 256x256 write-out are not amortised (725 TFLOP/s isolated, the
   // same as the 128x128 kernel) and, holding a CU's LDS alone, it keeps the other streams' launches off the CU (update phase
-  // 47.8 vs 46.3 ms) -- so the step never selects it.  ADDHIP_BF16_BIG=1 / 0 forces it on (eligible shapes) / off.
+  // 47.8 vs 46.3 ms) -- so the step never selects it.  addhip_gemm_t.hint forces it on (eligible shapes) / off.
   const long long t256 = (long long)(g.M / 256) * (g.N / 256);
   const bool eligible = g.M % 256 == 0 && g.N % 256 == 0 && g.K % 64 == 0;
-  const char* force = getenv("ADDHIP_BF16_BIG");
   bool big = eligible && t256 * split >= 192 && g.K / split >= 2048;
-  if (force) big = eligible && force[0] == '1';
+  if (g.hint & ADDHIP_GEMM_HINT_BIG_TILE) big = eligible;
+  if (g.hint & ADDHIP_GEMM_HINT_NO_BIG_TILE) big = false;
   const int BM = big ? 256 : 128, BN = BM;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int cfg = big ? 2 : ((long long)tiles_m * tiles_n * split >= 768 ? 1 : 0);

@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=768, help="envs of the CPU-oracle sample (1 warm-up + 3 timed iterations, median; about 20 s of host time)")
+    ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU-oracle sample; 0 = the headline's own env count (BASELINE.md section 3: same N). "
+                    "One warm-up + one timed iteration (about 25 s each at 4096 envs on 16 cores)")
+    ap.add_argument("--no-configs2", action="store_true", help="skip the BASELINE configs[2] entry (16 384 envs, 5-clip set, bf16-storage MLP path)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement after the headline run")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="N=1 only: join a 1-rank RCCL group so that the multi-rank exchange path (async gradient buckets) runs; rehearsal, not a headline")
@@ -85,20 +87,20 @@ def time_gemms(agent, reps=3):
     return dict(launches=len(calls), flops=flops, ms=ms)
 
 
-def gemm_roofline(agent, precision):
+def gemm_roofline(agent, precision, with_traffic=True):
     """HIP-event time of all GEMM launches of one optimiser step against the MFMA peak of the instruction that forms the
     products: fp32 MFMA 157.3 TFLOP/s; bf16x3 = six bf16 MFMAs per fp32 product -> 2500 / 6 TFLOP/s of fp32 work."""
     g = time_gemms(agent)
     tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
     if precision == "fp32":
         peak, kern = MFMA_F32_PEAK_TFLOPS, "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all GEMM launches of one optimiser step)"
-        tr, tr_src = traffic("gemm_fp32_step")
+        tr, tr_src = traffic("gemm_fp32_step") if with_traffic else (None, None)
     else:
         products = {"bf16x3": 6, "bf16x2": 3, "bf16": 1}[precision]
         peak = MFMA_BF16_PEAK_TFLOPS / products
         kern = ("gemm_bf16_kernel (bf16 operands in HBM, " if precision == "bf16" else "gemm_split_kernel (") + \
                "v_mfma_f32_32x32x16_bf16 x %d per k-step; small shapes stay on gemm_kernel); all GEMM launches of one optimiser step" % products
-        tr, tr_src = traffic("gemm_bf16_step") if precision == "bf16" else (None, None)
+        tr, tr_src = traffic("gemm_bf16_step") if precision == "bf16" and with_traffic else (None, None)  # (counters were taken at 4096 envs)
     return {"bound": "mfma", "kernel": kern, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": tr, "traffic_source": tr_src,
             "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"],
             "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS}
@@ -200,7 +202,7 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(num_envs, steps_per_iter):
+def cpu_baseline(num_envs, steps_per_iter, timed_iters=1):
     """The CPU oracle's iteration (oracle/loop.py) on a bounded sample of the same workload, all host cores."""
     import numpy as np
     import torch
@@ -232,15 +234,30 @@ def cpu_baseline(num_envs, steps_per_iter):
     perms = [rng.permutation(total) for _ in range(32)]
     draws = LP.Draws(rng.standard_normal((Tn, n, 29)).astype(np.float32), lambda t, ids: draw(len(ids)), perms)
     times = []
-    for it in range(4):  # BASELINE.md section 3.2 protocol: 1 warm-up + 3 timed iterations, median
+    for it in range(1 + timed_iters):  # bounded sample: 1 warm-up + `timed_iters` timed iterations of the headline's own size, median
         t0 = time.perf_counter()
         ag.train_iter(draws)
         times.append(time.perf_counter() - t0)
-    dt = sorted(times[1:])[1]
+        print(f"[bench] cpu baseline iteration {it}: {times[-1]:.1f} s", file=sys.stderr, flush=True)
+    dt = sorted(times[1:])[(timed_iters - 1) // 2]
     num_mb = int(np.ceil(total / float(ag.cfg.batch_size * n)))
-    return dict(value=total / dt, unit="env-steps/s", cores=cores, kind="port",
+    return dict(value=total / dt, unit="env-steps/s", cores=cores, kind="port", envs=n,
                 sample=f"CPU oracle (numpy + torch-CPU fp32, {cores} threads): {n} envs x {Tn} steps rollout + {ag.cfg.update_epochs} epochs x "
-                       f"{num_mb} minibatches update per iteration; 1 warm-up + 3 timed iterations, median {dt:.1f} s")
+                       f"{num_mb} minibatches update per iteration; 1 warm-up + {timed_iters} timed iteration(s), median {dt:.1f} s")
+
+
+def cpu_baseline_reference():
+    """The imported reference's own _train_iter, timed in the BUILD container (tools/time_reference.py; the reference cannot travel to
+    the GPU box): a committed record, copied here with its source so that both CPU figures of BASELINE.md section 3 are on the line."""
+    src = os.path.join("profiles", "r02_time_reference_4096.log")
+    try:
+        rec = json.loads(open(os.path.join(ROOT, src)).read().strip().splitlines()[-1])
+        return {"value": rec["env_steps_per_s"], "unit": "env-steps/s", "cores": rec["threads"], "kind": "reference", "envs": rec["num_envs"],
+                "where": "build container (%s), not the GPU box" % rec["cpu"], "source": src,
+                "sample": "add_gym's own _train_iter on a kinematic fake engine, %d envs x %d steps, %d epochs; 1 warm-up + %d timed iterations, median %.1f s; %s"
+                          % (rec["num_envs"], rec["steps_per_iter"], rec["update_epochs"], rec["timed_iters"], rec["median_s"], rec["physics"])}
+    except Exception:
+        return None
 
 
 def main():
@@ -289,9 +306,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_agent(precision, engine="kinematic"):
-        cfg = load_config("train", [f"engine={engine}", f"engine.num_envs={a.envs}", "task.motion_file=synthetic:1x3600", f"seed={1 + rank}",
-                                    f"agent.matmul_precision={precision}"])
+    def make_agent(precision, engine="kinematic", envs=None, motion="synthetic:1x3600", extra=()):
+        cfg = load_config("train", [f"engine={engine}", f"engine.num_envs={envs or a.envs}", f"task.motion_file={motion}", f"seed={1 + rank}",
+                                    f"agent.matmul_precision={precision}"] + list(extra))
         ag = ADDAgent(cfg, distributed=distributed)
         ag.reset_all_envs()
         ag._init_train()
@@ -382,10 +399,22 @@ def main():
                                  "value": env_steps / dt3, "unit": "env-steps/s", "ms_per_step": 1000.0 * dt3 / a.steps,
                                  "matmul_precision": a.precision}
         del agent3
+    if not a.no_alt and not a.no_configs2:
+        # BASELINE configs[2]: "G1 mixed locomotion motion set, num_envs=16384, 1xMI355X, bf16 MLP MFMA path" -- five synthetic clips,
+        # 16 384 envs per GPU, agent.matmul_precision=bf16 (bf16 storage); parity of this composition: tests/test_hip_fullsize.py
+        agent4 = make_agent("bf16", envs=16384, motion="synthetic:5x1200")
+        dt4 = timed(agent4)
+        if rank == 0:
+            out["alt_config"] = {"config": "BASELINE configs[2]: 5-clip synthetic locomotion set, num_envs=16384/GPU, bf16-storage MLP MFMA path",
+                                 "envs": 16384, "precision": "bf16", "matmul_precision": "bf16", "motion_library": "synthetic:5x1200",
+                                 "value": agent4.T * agent4.N * world * a.steps / dt4, "unit": "env-steps/s", "ms_per_step": 1000.0 * dt4 / a.steps,
+                                 "minibatch_rows": agent4.Mb, "roofline": gemm_roofline(agent4, "bf16", with_traffic=False)}
+        del agent4
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # last: the oracle's 16 torch-CPU threads keep spinning after their parallel regions, and the launch-bound GPU runs above
         # (the bf16 modes enqueue ~90 kernels per 1.1 ms optimiser step) slow down when they share the host cores with them
-        out["cpu_baseline"] = cpu_baseline(a.cpu_envs, steps_per_iter)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_envs or a.envs, steps_per_iter)
+        out["cpu_baseline_reference"] = cpu_baseline_reference()
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -256,7 +256,17 @@ typedef struct {
   int32_t operands_bf16;
   uint16_t* C16;
   int32_t ldc16;
+  /* 0 (always, in product code): the dispatcher picks the kernel configuration from the shape.  ADDHIP_GEMM_HINT_* bits override one
+   * of its choices for measurements and tests (tools/gemm_*_one.py, tests/test_hip_gemm.py); the result is the same either way.
+   * No process environment variable influences kernel selection. */
+  int32_t hint;
 } addhip_gemm_t;
+enum {
+  ADDHIP_GEMM_HINT_BIG_TILE = 1,     /* bf16 operands: the 256x256 ring kernel on eligible shapes (M, N multiples of 256, K of 64) */
+  ADDHIP_GEMM_HINT_NO_BIG_TILE = 2,  /* bf16 operands: never the 256x256 kernel */
+  ADDHIP_GEMM_HINT_ONE_STAGE = 4,    /* fp32 128x128 tiles: one LDS stage x 4 workgroups per CU */
+  ADDHIP_GEMM_HINT_TWO_STAGE = 8     /* fp32 128x128 tiles: two LDS stages x 2 workgroups per CU */
+};
 int addhip_gemm_f32(const addhip_gemm_t* g, void* stream);
 
 /* dst[r*ld_dst + c] = bf16(src[r*ld_src + c]), round to nearest even (bf16-storage mode: minibatch inputs, head gradients, the weight

@@ -272,7 +272,7 @@ def test_relu_sign_bits_roundtrip_bf16_storage(N):
     torch.testing.assert_close(cs_b, cs_f, rtol=1e-4, atol=1e-3)
 
 
-def run_gemm_bf16(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, seed=0, both_outputs=True):
+def run_gemm_bf16(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, seed=0, both_outputs=True, hint=0):
     """Operands STORED as bf16 (addhip_gemm_t.operands_bf16): the products are exact, so against float64 on the same bf16 values the
     only error is the fp32 accumulation; the optional bf16 result copy must be the fp32 result rounded to nearest even."""
     import torch
@@ -294,7 +294,7 @@ def run_gemm_bf16(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, seed=0, both_outpu
     dcs = torch.full((N,), 0.5, device="cuda")
     use16 = both_outputs and split_k <= 1
     g = gemm(M, N, K, L.ptr(dA), lda, a_kc, L.ptr(dB), ldb, b_kc, L.ptr(dC), ldc, epilogue, L.ptr(dbias), L.ptr(dmask), N, None, None, split_k, 1.0,
-             L.ptr(dcs) if epilogue == 3 else None, 1, operands_bf16=1, C16=L.ptr(dC16) if use16 else None, ldc16=ldc)
+             L.ptr(dcs) if epilogue == 3 else None, 1, operands_bf16=1, C16=L.ptr(dC16) if use16 else None, ldc16=ldc, hint=hint)
     L.call("addhip_gemm_f32", g, L.current_stream())
     torch.cuda.synchronize()
     A64, B64 = A.double().numpy(), B.double().numpy()
@@ -339,16 +339,16 @@ def test_gemm_bf16_storage(a_kc, b_kc):
 
 
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])
-def test_gemm_bf16_storage_256_tiles(a_kc, b_kc, monkeypatch):
+def test_gemm_bf16_storage_256_tiles(a_kc, b_kc):
     """The 256x256-tile kernel (gemm_bf16_q_kernel: unit ring, counted vmcnt, quadrant phases), forced on for shapes the
     dispatcher would give to the 128x128 kernel: every operand layout, every epilogue, split-K, one and several K tiles."""
-    monkeypatch.setenv("ADDHIP_BF16_BIG", "1")
-    run_gemm_bf16(512, 768, 64, a_kc, b_kc)
-    run_gemm_bf16(256, 256, 1024 + 64, a_kc, b_kc)
+    big = 1  # ADDHIP_GEMM_HINT_BIG_TILE
+    run_gemm_bf16(512, 768, 64, a_kc, b_kc, hint=big)
+    run_gemm_bf16(256, 256, 1024 + 64, a_kc, b_kc, hint=big)
     if a_kc:
         for epi in (1, 2, 3):
-            run_gemm_bf16(512, 256, 448, 1, b_kc, epilogue=epi)
-    run_gemm_bf16(256, 512, 4096, a_kc, b_kc, split_k=6)
+            run_gemm_bf16(512, 256, 448, 1, b_kc, epilogue=epi, hint=big)
+    run_gemm_bf16(256, 512, 4096, a_kc, b_kc, split_k=6, hint=big)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x2"])
