@@ -16,6 +16,7 @@
 // (ppo_model.py:13-21), ADDModel.eval_disc (add_model.py:12-15) and their autograd.
 #include "common.h"
 #include "gemm_epilogue.h"
+#include "gemm_dma.h"
 
 namespace {
 
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(addhip_gemm_t g, 
 
   // epilogue (gemm_epilogue.h): every wave's block leaves through its private slice of the (now idle) stage buffers
   // (the loop's last barrier is behind every read of them)
-  addhip_epi::gemm_epilogue<FM, FN, EPI>(g, acc, reinterpret_cast<char*>(lds) + wave * addhip_epi::EpiBuf<FN>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0);
+  addhip_epi::gemm_epilogue<FM, FN, EPI>(g, acc, reinterpret_cast<char*>(lds) + wave * addhip_epi::EpiBuf<FN>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, bool SB = false>
@@ -361,13 +362,14 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* X, int M, int
 }  // namespace
 
 namespace addhip {
-int gemm_split_dispatch(const addhip_gemm_t& g, int planes, hipStream_t st);  // gemm_split.hip
-int gemm_bf16_dispatch(const addhip_gemm_t& g, hipStream_t st);               // gemm_bf16.hip
+int gemm_split_dispatch(const addhip_gemm_t& g, int planes, hipStream_t st);       // gemm_split.hip
+int gemm_bf16_dispatch(const addhip_dma::GemmGroup& grp, int count, hipStream_t st);  // gemm_bf16.hip
 }
 
-extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
-  ADDHIP_REQUIRE(gp, "null gemm descriptor");
-  addhip_gemm_t g = *gp;
+namespace {
+
+// argument checks shared by addhip_gemm_f32 and addhip_gemm_grouped; normalises alpha
+int validate(addhip_gemm_t& g) {
   ADDHIP_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem %d x %d x %d", g.M, g.N, g.K);
   ADDHIP_REQUIRE(g.A && g.B && (g.C || g.C16), "gemm: null operand");
   ADDHIP_REQUIRE(aligned16(g.A) && aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0), "gemm: operands must be 16-byte aligned with ld %% 4 == 0");
@@ -387,13 +389,36 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   if (g.colsum) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && g.split_k <= 1, "gemm: colsum needs the MASK epilogue");
   ADDHIP_REQUIRE(g.precision == ADDHIP_PREC_F32 || g.precision == ADDHIP_PREC_BF16 || g.precision == ADDHIP_PREC_BF16X2 ||
                      g.precision == ADDHIP_PREC_BF16X3, "gemm: bad precision");
-  if (g.alpha == 0.0f) g.alpha = 1.0f;
-  hipStream_t st = (hipStream_t)stream;
-  if (g.operands_bf16) {
-    ADDHIP_REQUIRE(!g.accumulate, "gemm: accumulate is not built for bf16-stored operands");
-    return addhip::gemm_bf16_dispatch(g, st);
-  }
   ADDHIP_REQUIRE(g.C || g.split_k <= 1, "gemm: split-K slabs are fp32 (C)");
+  if (g.operands_bf16) ADDHIP_REQUIRE(!g.accumulate, "gemm: accumulate is not built for bf16-stored operands");
+  if (g.alpha == 0.0f) g.alpha = 1.0f;
+  return 0;
+}
+
+// fp32 operands, 128x128 tiles, whole chip: the LDS-DMA kernel (gemm_dma.h).  Not for the fused input normalisation (the DMA
+// cannot transform in flight: those launches -- first layers of the rollout / evaluation passes -- stay on gemm_kernel).
+bool takes_dma_f32(const addhip_gemm_t& g, long long tiles128) {
+  return g.precision == ADDHIP_PREC_F32 && !g.a_mean && tiles128 > 256 && !(g.hint & ADDHIP_GEMM_HINT_REG_STAGED);
+}
+int launch_dma_f32(const addhip_dma::GemmGroup& grp, int count, hipStream_t st) {
+  const addhip_gemm_t& g = grp.g[0];
+  const int tiles_m = (g.M + 127) / 128, tiles_n = (g.N + 127) / 128, split = g.split_k > 1 ? g.split_k : 1;
+  const int wgs = addhip_dma::persistent_workgroups();
+  if (addhip_dma::takes_persistent(g, addhip_dma::ElemF32::BKS, count, wgs)) {
+    const long long total = (long long)tiles_m * tiles_n * split * count;
+    addhip_dma::launch_dma_persistent<addhip_dma::ElemF32>(grp, count, tiles_m, tiles_n, split, (int)(total < wgs ? total : wgs), st);
+    return addhip::check_launch("gemm_dma_persistent_kernel<f32>");
+  }
+  bool one_stage = false;
+  if (g.hint & ADDHIP_GEMM_HINT_ONE_STAGE) one_stage = true;
+  if (g.hint & ADDHIP_GEMM_HINT_TWO_STAGE) one_stage = false;
+  if (one_stage) addhip_dma::launch_dma<addhip_dma::ElemF32, 1>(grp, count, tiles_m, tiles_n, split, st);
+  else addhip_dma::launch_dma<addhip_dma::ElemF32, 0>(grp, count, tiles_m, tiles_n, split, st);
+  return addhip::check_launch("gemm_dma_kernel<f32>");
+}
+
+// one fp32-operand problem (validated)
+int dispatch_f32(const addhip_gemm_t& g, hipStream_t st) {
   if (g.M <= SMALL_M && g.a_kcontig && !g.a_mean && g.split_k <= 1 && !g.C16) {  // (the few-row kernel writes fp32 C only)
     if (g.b_kcontig) hipLaunchKernelGGL(gemm_small_m_kernel<true>, dim3((g.N + 3) / 4), dim3(256), 0, st, g);
     else hipLaunchKernelGGL(gemm_small_m_kernel<false>, dim3((g.N + 31) / 32), dim3(256), 0, st, g);
@@ -413,11 +438,62 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
                       (long long)((g.M + 127) / 128) * ((g.N + 95) / 96) * (g.split_k > 1 ? g.split_k : 1) >= 256;
   if (g.precision != ADDHIP_PREC_F32) return addhip::gemm_split_dispatch(g, g.precision, st);
   if (narrow) return launch_cfg<128, 96, 4, 1, 32>(g, st);
-  // launches with enough workgroups for 4 per CU run one LDS stage (37 KB) x 4 workgroups per CU instead of two stages x 2:
-  // alone they time the same, beside the other streams' launches of an update step they overlap better (update phase -2 %)
+  if (takes_dma_f32(g, tiles128)) {
+    addhip_dma::GemmGroup grp;
+    grp.g[0] = g;
+    return launch_dma_f32(grp, 1, st);
+  }
+  // register-staged 128x128 tiles (fused normalisation; ADDHIP_GEMM_HINT_REG_STAGED): launches with enough workgroups for 4 per CU
+  // run one LDS stage (37 KB) x 4 workgroups per CU instead of two stages x 2
   const bool one_stage = (g.hint & ADDHIP_GEMM_HINT_ONE_STAGE) ? true : (g.hint & ADDHIP_GEMM_HINT_TWO_STAGE) ? false : tiles128 >= 512;
   if (one_stage) return launch_cfg<128, 128, 2, 2, 32, true>(g, st);
   return launch_cfg<128, 128, 2, 2, 32>(g, st);
+}
+
+}  // namespace
+
+extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
+  ADDHIP_REQUIRE(gp, "null gemm descriptor");
+  addhip_gemm_t g = *gp;
+  if (int rc = validate(g)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (g.operands_bf16) {
+    addhip_dma::GemmGroup grp;
+    grp.g[0] = g;
+    return addhip::gemm_bf16_dispatch(grp, 1, st);
+  }
+  return dispatch_f32(g, st);
+}
+
+extern "C" int addhip_gemm_grouped(const addhip_gemm_t* problems, int32_t count, void* stream) {
+  ADDHIP_REQUIRE(problems && count >= 1 && count <= ADDHIP_GEMM_MAX_GROUP, "gemm_grouped: 1..%d problems", ADDHIP_GEMM_MAX_GROUP);
+  addhip_dma::GemmGroup grp;
+  for (int i = 0; i < count; ++i) {
+    grp.g[i] = problems[i];
+    if (int rc = validate(grp.g[i])) return rc;
+    const addhip_gemm_t &a = grp.g[0], &b = grp.g[i];
+    ADDHIP_REQUIRE(a.M == b.M && a.N == b.N && a.K == b.K && a.a_kcontig == b.a_kcontig && a.b_kcontig == b.b_kcontig && a.epilogue == b.epilogue &&
+                       a.split_k == b.split_k && a.precision == b.precision && a.operands_bf16 == b.operands_bf16 && a.accumulate == b.accumulate &&
+                       (a.a_mean != nullptr) == (b.a_mean != nullptr) && a.hint == b.hint,
+                   "gemm_grouped: problem %d differs from problem 0 in shape, layout, epilogue, split, precision or storage", i);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const addhip_gemm_t& g = grp.g[0];
+  if (count > 1) {
+    // one launch over all problems where the shape takes the 128x128 LDS-DMA kernel ...
+    const long long tiles128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
+    if (g.operands_bf16 && !(g.hint & ADDHIP_GEMM_HINT_BIG_TILE)) return addhip::gemm_bf16_dispatch(grp, count, st);
+    const int waste128 = (g.N + 127) / 128 * 128 - g.N, waste96 = (g.N + 95) / 96 * 96 - g.N;
+    const bool narrow = waste128 >= 64 && waste96 < 32;
+    if (!g.operands_bf16 && g.M > SMALL_M && g.N > 64 && !narrow && takes_dma_f32(g, tiles128 * count)) return launch_dma_f32(grp, count, st);
+    // ... and one by one otherwise (same results; the group is then only a convenience)
+    for (int i = 0; i < count; ++i) {
+      const int rc = addhip_gemm_f32(&problems[i], stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  return addhip_gemm_f32(problems, stream);
 }
 
 extern "C" int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count, float scale,

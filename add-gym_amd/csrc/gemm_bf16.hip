@@ -4,239 +4,24 @@
 // same epilogues, ReLU sign bits, fused bias-gradient column sums and split-K slabs as gemm.hip / gemm_split.hip.
 //
 // Unlike gemm_split.hip (fp32 operands split into bf16 planes on their way into LDS, 16-deep stages) nothing is converted
-// here: 128x128 tile, 4 wavefronts of 64x64 (2x2 accumulators of v_mfma_f32_32x32x16_bf16), 64-deep K stages = 16 MFMAs per
-// wave and barrier; either an LDS double buffer (2 x 32 KB -> 2 workgroups per CU, the next stage's DMA in flight under this
-// stage's MFMAs) or one 32 KB stage and 3-4 workgroups per CU covering for each other.  The tiles go global -> LDS by LDS-DMA
-// (global_load_lds_dwordx4; no staging registers, no ds_write pass), bank-swizzled through the source addresses; operands
-// that are m/n-contiguous in HBM are NOT transposed on the way in: their fragments are read with ds_read_b64_tr_b16.
+// here.  The 128x128-tile kernel is gemm_dma.h's gemm_dma_kernel<ElemBF16, ...> (shared with the fp32 path: tiles by LDS-DMA,
+// bank-swizzled through the source addresses; m/n-contiguous operands are NOT transposed on the way in: their fragments are read
+// with ds_read_b64_tr_b16); this file adds the 256x256 ring kernel for deep-K shapes, the dispatcher and the bf16 conversions.
 //
 // Replaces (in bf16 mode): the torch.nn.Linear forward/backward of PPOModel / ADDModel (ppo_model.py:13-21, add_model.py:12-15).
 #include "common.h"
 #include "gemm_epilogue.h"
+#include "gemm_dma.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
-
-using addhip_epi::EPI_RUNTIME;
-using addhip_epi::EpiBuf;
-using addhip_epi::gemm_epilogue;
-// 128x128 tile configurations (gemm_bf16_kernel): 0 = 4 waves of 64x64, two 64-deep LDS stages, 2 workgroups per CU;
-// 1 = the same tile, one stage, 3-4 workgroups per CU covering for each other.  (The 256x256 tile: gemm_bf16_q_kernel below.)
-template <int CFG> struct Cfg {
-  static constexpr int MT = 2;                           // 32-row accumulator blocks per wave (2 column blocks always)
-  static constexpr int WN = 2;                           // waves across N
-  static constexpr int NW = 4;                           // waves per workgroup
-  static constexpr int BM = (NW / WN) * MT * 32, BN = WN * 64;
-  static constexpr int BKS = 64;                         // k per stage
-  static constexpr int TILE_A = BM * BKS * 2, TILE_B = BN * BKS * 2, STAGE = TILE_A + TILE_B;
-  static constexpr int STAGES = CFG == 1 ? 1 : 2;
-  static constexpr int PPW = TILE_A / 1024 / NW;          // 1 KiB DMA pieces per wave, operand and stage (BM == BN)
-  static constexpr int EPI_BYTES = NW * 32 * (64 * 4 + 16);  // NW x 32 x ERS
-  static constexpr int LDS_BYTES = STAGES * STAGE > EPI_BYTES ? STAGES * STAGE : EPI_BYTES;
-};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4* ltr_t;
-
-__device__ uint4 g_zero_chunk;  // 16 zero bytes: the source of LDS chunks beyond the end of K
+using namespace addhip_dma;  // the 128x128 LDS-DMA kernel (gemm_dma_kernel<ElemBF16, ...>), its stagers and fragment readers
 
 // fp32 -> bf16, round to nearest even (no NaN special-casing: the callers' values are finite)
 __device__ __forceinline__ u16 to_bf16(float v) {
   const unsigned u = __float_as_uint(v);
   return (u16)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-
-// ---- operand tiles in LDS.  Both images are filled by LDS-DMA (global_load_lds_dwordx4: each wave-instruction lands
-// 64 x 16 B = 1 KiB at a wave-uniform LDS address, lane-linear), so the bank swizzle sits on the per-lane SOURCE address
-// and the same XOR is applied by the fragment reads.
-//
-// k-contiguous operand P[r*ld + k] (activations, weights, transposed weight shadows):
-//   image [rows][64 k], 128-B rows of 8 chunks, chunk c of row r at chunk position c ^ ((r >> 1) & 7), one piece = 8 rows; or
-//   image [rows][32 k],  64-B rows of 4 chunks, chunk c of row r at chunk position c ^ ((r >> 2) & 3), one piece = 16 rows
-//   (either way a ds_read_b128 lane group = 16 rows at one k chunk covers all 64 banks).
-// m/n-contiguous operand P[k*ld + r] (the weight-gradient GEMMs dW = dz^T x: both operands row-major over the minibatch):
-//   image [64 k][rows], 256-B or 512-B rows of 16-byte chunks; chunk ch of k-row kr sits at position ch ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
-//   one piece = 4 or 2 k-rows.  MFMA fragments (8 consecutive k of one row per lane) come out of it by two ds_read_b64_tr_b16
-//   (each delivers a 4 k x 16 rows block transposed), conflict-free with this XOR.
-template <int BKS> __device__ __forceinline__ int kc_swz(int row) { return BKS == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
-__device__ __forceinline__ int mc_swz(int kr) { return ((kr & 3) << 2) | ((kr >> 2) & 3); }
-
-template <bool KC, int ROWS, int BKS, int PPW>
-struct Stager {
-  unsigned off[PPW];  // byte offset of this lane's 16-byte chunk from the stage's (uniform) source base, pieces PPW*wave .. PPW*wave+PPW-1
-  int kq[PPW];        // the k (relative to the stage's first k) the chunk starts at (KC) / lies on (MC): tail guard
-  // rows_left = R - r0 (>= 1; a multiple of 8 for MC)
-  __device__ __forceinline__ void init(int wave, int lane, int ld, int rows_left) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int piece = PPW * wave + i;
-      if (KC) {
-        constexpr int LPR = BKS / 8;  // lanes (16-byte chunks) per row of the image
-        const int row = (64 / LPR) * piece + lane / LPR, c = (lane % LPR) ^ kc_swz<BKS>(row);
-        off[i] = 2u * ((unsigned)min(row, rows_left - 1) * (unsigned)ld + 8u * c);
-        kq[i] = 8 * c;
-      } else {
-        constexpr int LPR = ROWS / 8;  // lanes per k-row of the image
-        const int kr = (64 / LPR) * piece + lane / LPR, ch = (lane % LPR) ^ mc_swz(kr);
-        off[i] = 2u * ((unsigned)kr * (unsigned)ld + (unsigned)min(8 * ch, rows_left - 8));
-        kq[i] = kr;
-      }
-    }
-  }
-  // src: the operand at (tile's first row, stage's first k); dst: this operand's tile in the stage buffer; kleft = kend - k0
-  template <bool GUARD>
-  __device__ __forceinline__ void issue(const char* src, char* dst, int wave, int kleft) const {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const char* s = src + off[i];
-      if (GUARD && kq[i] >= kleft) s = reinterpret_cast<const char*>(&g_zero_chunk);  // K % 8 == 0: a chunk is in or out as a whole
-      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(dst + (PPW * wave + i) * 1024), 16, 0, 0);
-    }
-  }
-};
-
-// fragment (rows row0 .. row0+31 of the tile, k 16*ks .. 16*ks+15): lane (li, lh) gets row row0+li, k 16*ks + 8*lh .. +7
-template <int BKS>
-struct FragKC {
-  unsigned base, x;  // row byte offset, lh ^ swizzle
-  __device__ __forceinline__ void init(int w0, int li, int lh) { base = (unsigned)(w0 + li) * (2u * BKS); x = (unsigned)(lh ^ kc_swz<BKS>(li)); }  // w0 % 32 == 0
-  __device__ __forceinline__ bf16x8 get(const char* tile, int a, int ks) const {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + base + a * (32 * 2 * BKS) + (((2u * ks) ^ x) << 4)));
-  }
-};
-template <int ROWS, int MT>
-struct FragMC {
-  static constexpr unsigned RS = ROWS * 2;  // bytes per k-row of the image
-  unsigned addr[MT][2];  // [a][j]: this lane's address for the j-th 4-k block of fragment a at ks = 0
-  __device__ __forceinline__ void init(int w0, int lane) {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int kr = 8 * (g >> 1) + 4 * j + q;                  // + 16*ks: leaves mc_swz(kr) unchanged
-        const int ch = (w0 + a * 32 + 16 * (g & 1)) / 8 + (p >> 1);
-        addr[a][j] = RS * kr + 16u * (ch ^ mc_swz(kr)) + 8u * (p & 1);
-      }
-  }
-  __device__ __forceinline__ bf16x8 get(const char* tile, int a, int ks) const {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(tile + addr[a][0] + ks * (16 * RS)));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(tile + addr[a][1] + ks * (16 * RS)));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-  }
-};
-template <bool KC, int ROWS, int MT, int BKS> struct FragSel { typedef FragKC<BKS> type; };
-template <int ROWS, int MT, int BKS> struct FragSel<false, ROWS, MT, BKS> { typedef FragMC<ROWS, MT> type; };
-
-template <bool AKC, bool BKC, int EPI, int CFG>
-__global__ __launch_bounds__(256, CFG == 1 ? ((AKC && BKC) ? 4 : 3) : 2) void gemm_bf16_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
-  typedef Cfg<CFG> Q;
-  constexpr bool SB = Q::STAGES == 1;
-  constexpr int BM = Q::BM, BN = Q::BN, MT = Q::MT, STAGE = Q::STAGE, TILE = Q::TILE_A;  // TILE: offset of the B tile in a stage
-  constexpr int BK = Q::BKS;
-  __shared__ __attribute__((aligned(1024))) char lds[Q::LDS_BYTES];
-
-  // XCD-aware remap (blocks b and b+8 share an XCD): each XCD gets a contiguous run of tiles, N-tile fastest
-  const int total = tiles_m * tiles_n;
-  const int orig = blockIdx.x;
-  const int q = total >> 3, r = total & 7, xcd = orig & 7;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int split = g.split_k > 1 ? g.split_k : 1;
-  const int kchunk = ((g.K + split - 1) / split + BK - 1) / BK * BK;
-  const int kbeg = blockIdx.z * kchunk;
-  const int kend = min(g.K, kbeg + kchunk);
-  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-  const int nk_full = kend > kbeg ? (kend - kbeg) / BK : 0;
-
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm0 = (wave / Q::WN) * (MT * 32), wn0 = (wave % Q::WN) * 64;
-  const int li = lane & 31, lh = lane >> 5;
-
-  // stage sources: (tile's first row, first k of the split) and the step between stages
-  const char* srcA = reinterpret_cast<const char*>(g.A) + 2 * (AKC ? (size_t)m0 * g.lda + kbeg : (size_t)kbeg * g.lda + m0);
-  const char* srcB = reinterpret_cast<const char*>(g.B) + 2 * (BKC ? (size_t)n0 * g.ldb + kbeg : (size_t)kbeg * g.ldb + n0);
-  const size_t stepA = 2 * (AKC ? (size_t)BK : (size_t)BK * g.lda), stepB = 2 * (BKC ? (size_t)BK : (size_t)BK * g.ldb);
-  Stager<AKC, BM, BK, Q::PPW> sa;
-  Stager<BKC, BN, BK, Q::PPW> sb;
-  sa.init(wave, lane, g.lda, g.M - m0);
-  sb.init(wave, lane, g.ldb, g.N - n0);
-  typename FragSel<AKC, BM, MT, BK>::type fa_;
-  typename FragSel<BKC, BN, 2, BK>::type fb_;
-  if constexpr (AKC) fa_.init(wm0, li, lh); else fa_.init(wm0, lane);
-  if constexpr (BKC) fb_.init(wn0, li, lh); else fb_.init(wn0, lane);
-
-  f32x16 acc[MT][2];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
-
-  auto stage = [&](int kt, int buf) {
-    char* dst = lds + buf * STAGE;
-    const int kleft = kend - (kbeg + kt * BK);
-    if (kt < nk_full) {
-      sa.template issue<false>(srcA + kt * stepA, dst, wave, kleft);
-      sb.template issue<false>(srcB + kt * stepB, dst + TILE, wave, kleft);
-    } else {
-      sa.template issue<true>(srcA + kt * stepA, dst, wave, kleft);
-      sb.template issue<true>(srcB + kt * stepB, dst + TILE, wave, kleft);
-    }
-  };
-  auto compute = [&](int buf) {
-    const char* a_cur = lds + buf * STAGE;
-    const char* b_cur = a_cur + TILE;
-    // (the compiler sinks each k-step's fragment reads to just behind the issue of the MFMAs that consume the previous ones)
-    bf16x8 fa[2][MT], fb[2][2];
-#pragma unroll
-    for (int a = 0; a < MT; ++a) fa[0][a] = fa_.get(a_cur, a, 0);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) fb[0][b] = fb_.get(b_cur, b, 0);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      if (ks + 1 < BK / 16) {
-#pragma unroll
-        for (int a = 0; a < MT; ++a) fa[(ks + 1) & 1][a] = fa_.get(a_cur, a, ks + 1);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) fb[(ks + 1) & 1][b] = fb_.get(b_cur, b, ks + 1);
-      }
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
-    }
-  };
-  {
-    // Double-buffered (!SB): one barrier per 64-deep stage.  Its vmcnt(0) retires this wave's share of stage kt (issued one whole
-    // compute phase earlier), the barrier itself makes every wave's share visible and proves stage kt-1's buffer is no longer
-    // being read, so the DMA of stage kt+1 into that buffer is issued right behind it and stays in flight under the 16 MFMAs
-    // of stage kt.  Single-buffered (SB): issue, wait + barrier, compute, barrier; the CU's other workgroups fill the waits.
-    if (!SB && nk > 0) stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = SB ? 0 : (kt & 1);
-      if (SB) {
-        if (kt > 0) __syncthreads();
-        stage(kt, 0);
-      }
-      __syncthreads();
-      if (!SB && kt + 1 < nk) stage(kt + 1, cur ^ 1);
-      compute(cur);
-    }
-  }
-
-  __syncthreads();  // every wave is done with the last stage: LDS becomes the waves' private epilogue buffers
-  gemm_epilogue<MT, 2, EPI>(g, acc, lds + wave * EpiBuf<2>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -267,11 +52,11 @@ struct QStager {
     for (int i = 0; i < 2; ++i) {
       const int piece = 2 * wave + i;
       if (KC) {
-        const int lr = 8 * piece + (lane >> 3), c = (lane & 7) ^ kc_swz<64>(lr);
+        const int lr = 8 * piece + (lane >> 3), c = (lane & 7) ^ kc_swz(lr);
         const int tr = (lr / GS) * (2 * GS) + (lr % GS);
         off[i] = 2u * ((unsigned)tr * (unsigned)ld + 8u * c);
       } else {
-        const int kr = 4 * piece + (lane >> 4), ch = (lane & 15) ^ mc_swz(kr);
+        const int kr = 4 * piece + (lane >> 4), ch = (lane & 15) ^ ElemBF16::mc_swz(kr);
         const int lm = 8 * ch, tm = (lm / GS) * (2 * GS) + (lm % GS);
         off[i] = 2u * ((unsigned)kr * (unsigned)ld + (unsigned)tm);
       }
@@ -313,8 +98,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_q_kernel(addhip_gemm_t g, in
   QStager<BKC, 32> sb;
   sa.init(wave, lane, g.lda);
   sb.init(wave, lane, g.ldb);
-  typename FragSel<AKC, 128, 2, 64>::type fa_;
-  typename FragSel<BKC, 128, 1, 64>::type fb_;
+  typename FragSel<ElemBF16, AKC, 128, 2>::type fa_;
+  typename FragSel<ElemBF16, BKC, 128, 1>::type fb_;
   if constexpr (AKC) fa_.init(wm * 64, li, lh); else fa_.init(wm * 64, lane);
   if constexpr (BKC) fb_.init(wn * 32, li, lh); else fb_.init(wn * 32, lane);
 
@@ -394,7 +179,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_q_kernel(addhip_gemm_t g, in
     }
   }
   __syncthreads();
-  gemm_epilogue<4, 2, EPI>(g, acc, lds + wave * EpiBuf<2>::WAVE_BYTES, lane, m0 + wm * 128, n0 + wn * 64);
+  gemm_epilogue<4, 2, EPI>(g, acc, lds + wave * EpiBuf<2>::WAVE_BYTES, lane, m0 + wm * 128, n0 + wn * 64, blockIdx.z);
 }
 
 // fp32 -> bf16 (round to nearest even), row by row: dst[r*ld_dst + c] = bf16(src[r*ld_src + c]), cols % 4 == 0
@@ -473,15 +258,20 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __rest
 }  // namespace
 
 namespace addhip {
-// called by addhip_gemm_f32 (gemm.hip) after argument validation, for descriptors whose operands are stored as bf16
-int gemm_bf16_dispatch(const addhip_gemm_t& g, hipStream_t st) {
-  if (g.a_mean || g.a_std) return (set_error("gemm: fused normalisation is not built for bf16-stored operands"), -1);
-  if (g.a_kcontig ? (g.K % 8 != 0 || g.lda % 8 != 0) : (g.M % 8 != 0 || g.lda % 8 != 0))
-    return (set_error("gemm: bf16-stored A needs 16-byte chunks (K or M, and lda, multiples of 8)"), -1);
-  if (g.b_kcontig ? (g.K % 8 != 0 || g.ldb % 8 != 0) : (g.N % 8 != 0 || g.ldb % 8 != 0))
-    return (set_error("gemm: bf16-stored B needs 16-byte chunks (K or N, and ldb, multiples of 8)"), -1);
-  if (!g.C && !g.C16) return (set_error("gemm: no output"), -1);
-  if (g.split_k > 1 && (!g.C || g.C16)) return (set_error("gemm: split-K slabs are fp32"), -1);
+// called by the GEMM entry points (gemm.hip) after argument validation, for descriptors whose operands are stored as bf16;
+// count > 1: equal-shaped problems of one grouped launch
+int gemm_bf16_dispatch(const addhip_dma::GemmGroup& grp, int count, hipStream_t st) {
+  const addhip_gemm_t& g = grp.g[0];
+  for (int i = 0; i < count; ++i) {
+    const addhip_gemm_t& p = grp.g[i];
+    if (p.a_mean || p.a_std) return (set_error("gemm: fused normalisation is not built for bf16-stored operands"), -1);
+    if (p.a_kcontig ? (p.K % 8 != 0 || p.lda % 8 != 0) : (p.M % 8 != 0 || p.lda % 8 != 0))
+      return (set_error("gemm: bf16-stored A needs 16-byte chunks (K or M, and lda, multiples of 8)"), -1);
+    if (p.b_kcontig ? (p.K % 8 != 0 || p.ldb % 8 != 0) : (p.N % 8 != 0 || p.ldb % 8 != 0))
+      return (set_error("gemm: bf16-stored B needs 16-byte chunks (K or N, and ldb, multiples of 8)"), -1);
+    if (!p.C && !p.C16) return (set_error("gemm: no output"), -1);
+    if (p.split_k > 1 && (!p.C || p.C16)) return (set_error("gemm: split-K slabs are fp32"), -1);
+  }
   const int split = g.split_k > 1 ? g.split_k : 1;
   // 128x128 tiles: a single LDS stage x 4 (3 with a transposed operand) workgroups per CU when the launch has the workgroups to
   // fill that, double-buffered stages x 2 workgroups per CU if not (measured: 1024-tile launches 7-17 % faster single-buffered,
@@ -491,20 +281,28 @@ int gemm_bf16_dispatch(const addhip_gemm_t& g, hipStream_t st) {
   // same as the 128x128 kernel) and, holding a CU's LDS alone, it keeps the other streams' launches off the CU (update phase
   // 47.8 vs 46.3 ms) -- so the step never selects it.  addhip_gemm_t.hint forces it on (eligible shapes) / off.
   const long long t256 = (long long)(g.M / 256) * (g.N / 256);
-  const bool eligible = g.M % 256 == 0 && g.N % 256 == 0 && g.K % 64 == 0;
+  const bool eligible = count == 1 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 64 == 0;
   bool big = eligible && t256 * split >= 192 && g.K / split >= 2048;
   if (g.hint & ADDHIP_GEMM_HINT_BIG_TILE) big = eligible;
   if (g.hint & ADDHIP_GEMM_HINT_NO_BIG_TILE) big = false;
   const int BM = big ? 256 : 128, BN = BM;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-  const int cfg = big ? 2 : ((long long)tiles_m * tiles_n * split >= 768 ? 1 : 0);
-  dim3 grid(tiles_m * tiles_n, 1, split), block(big ? 512 : 256);
-#define ADDHIP_LAUNCH(AK, BKc, EPI)                                                                                      \
-  do {                                                                                                                   \
-    if (cfg == 2) hipLaunchKernelGGL((gemm_bf16_q_kernel<AK, BKc, EPI>), grid, block, 0, st, g, tiles_m, tiles_n);       \
-    else if (cfg == 1) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKc, EPI, 1>), grid, block, 0, st, g, tiles_m, tiles_n); \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKc, EPI, 0>), grid, block, 0, st, g, tiles_m, tiles_n);               \
-  } while (0)
+  if (!big) {
+    const int wgs = addhip_dma::persistent_workgroups();
+    if (addhip_dma::takes_persistent(g, addhip_dma::ElemBF16::BKS, count, wgs)) {
+      const long long total = (long long)tiles_m * tiles_n * split * count;
+      addhip_dma::launch_dma_persistent<addhip_dma::ElemBF16>(grp, count, tiles_m, tiles_n, split, (int)(total < wgs ? total : wgs), st);
+      return check_launch("gemm_dma_persistent_kernel<bf16>");
+    }
+    bool one_stage = (long long)tiles_m * tiles_n * split * count >= 768;
+    if (g.hint & ADDHIP_GEMM_HINT_ONE_STAGE) one_stage = true;
+    if (g.hint & ADDHIP_GEMM_HINT_TWO_STAGE) one_stage = false;
+    if (one_stage) addhip_dma::launch_dma<addhip_dma::ElemBF16, 1>(grp, count, tiles_m, tiles_n, split, st);
+    else addhip_dma::launch_dma<addhip_dma::ElemBF16, 0>(grp, count, tiles_m, tiles_n, split, st);
+    return check_launch("gemm_dma_kernel<bf16>");
+  }
+  dim3 grid(tiles_m * tiles_n, 1, split), block(512);
+#define ADDHIP_LAUNCH(AK, BKc, EPI) hipLaunchKernelGGL((gemm_bf16_q_kernel<AK, BKc, EPI>), grid, block, 0, st, g, tiles_m, tiles_n)
   if (g.a_kcontig && g.b_kcontig) {
     if (g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_BIAS_RELU);
     else if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_MASK);
@@ -519,7 +317,7 @@ int gemm_bf16_dispatch(const addhip_gemm_t& g, hipStream_t st) {
     else ADDHIP_LAUNCH(false, false, EPI_RUNTIME);
   }
 #undef ADDHIP_LAUNCH
-  return check_launch("gemm_bf16_kernel");
+  return check_launch("gemm_bf16_q_kernel");
 }
 }  // namespace addhip
 

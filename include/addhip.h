@@ -264,10 +264,20 @@ typedef struct {
 enum {
   ADDHIP_GEMM_HINT_BIG_TILE = 1,     /* bf16 operands: the 256x256 ring kernel on eligible shapes (M, N multiples of 256, K of 64) */
   ADDHIP_GEMM_HINT_NO_BIG_TILE = 2,  /* bf16 operands: never the 256x256 kernel */
-  ADDHIP_GEMM_HINT_ONE_STAGE = 4,    /* fp32 128x128 tiles: one LDS stage x 4 workgroups per CU */
-  ADDHIP_GEMM_HINT_TWO_STAGE = 8     /* fp32 128x128 tiles: two LDS stages x 2 workgroups per CU */
+  ADDHIP_GEMM_HINT_ONE_STAGE = 4,    /* 128x128 tiles: one LDS stage x 3-4 workgroups per CU */
+  ADDHIP_GEMM_HINT_TWO_STAGE = 8,    /* 128x128 tiles: two LDS stages x 2 workgroups per CU */
+  ADDHIP_GEMM_HINT_REG_STAGED = 16,  /* fp32 operands: the register-staged tile kernel instead of the LDS-DMA one */
+  ADDHIP_GEMM_HINT_PERSISTENT = 32,  /* 128x128 LDS-DMA tiles: the persistent kernel (epilogue of a tile under the next tile's main loop) */
+  ADDHIP_GEMM_HINT_NO_PERSISTENT = 64
 };
 int addhip_gemm_f32(const addhip_gemm_t* g, void* stream);
+/* Up to ADDHIP_GEMM_MAX_GROUP problems of the SAME shape, operand layouts, epilogue kind, split, precision and storage (different
+ * buffers) as ONE launch -- e.g. the actor's and the critic's equal-shaped layers of an update step (ppo_agent.py:194-275 runs them
+ * one after the other).  A launch then has several rounds of tiles, so one round's write-out overlaps the next round's first
+ * loads instead of the whole chip writing in lock-step.  Results are those of `count` addhip_gemm_f32 calls; shapes that do not
+ * take the 128x128 tile kernel are launched one by one. */
+#define ADDHIP_GEMM_MAX_GROUP 4
+int addhip_gemm_grouped(const addhip_gemm_t* problems, int32_t count, void* stream);
 
 /* dst[r*ld_dst + c] = bf16(src[r*ld_src + c]), round to nearest even (bf16-storage mode: minibatch inputs, head gradients, the weight
  * shadow after an optimiser step); cols and both leading dimensions multiples of 4 */

@@ -416,3 +416,95 @@ def test_shadow_refresh_flat_and_transposed_in_one_launch():
     with pytest.raises(RuntimeError):
         L.call("addhip_shadow_refresh", L.ptr(params), L.ptr(flat16), L.ptr(trans16), count, (C.c_int64 * 1)(count - 10), (C.c_int32 * 1)(8),
                (C.c_int32 * 1)(8), 1, L.current_stream())
+
+
+def _run_with_hint(hint, *a, **k):
+    """run_gemm with addhip_gemm_t.hint set on the descriptor it builds."""
+    import add_gym_amd.hotpath as H
+
+    orig = H.gemm
+    H.gemm = lambda *aa, **kk: orig(*aa, **dict(kk, hint=hint))
+    try:
+        return run_gemm(*a, **k)
+    finally:
+        H.gemm = orig
+
+
+@pytest.mark.parametrize("stages", [4 | 64, 8 | 64, 16, 32])  # ADDHIP_GEMM_HINT_ONE_STAGE / TWO_STAGE (LDS-DMA kernel, not persistent), REG_STAGED, PERSISTENT
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_fp32_lds_dma_kernel(a_kc, b_kc, stages):
+    """fp32 operands on the 128x128 LDS-DMA kernel (gemm_dma.h; what shapes of more than 256 tiles take): every layout, ragged M / N / K
+    edges (K tail inside a 32-deep stage, rows past the last tile, N not a multiple of 128), epilogues with sign-bit masks' fp32
+    fallback, split-K slabs with empty and ragged slices -- under both stage configurations and, for comparison, the register-staged
+    kernel on the same shapes; and the PERSISTENT kernel (a workgroup walks several tiles, the epilogue of one issued in pieces under
+    the next one's K stages: K of 1, 4, 9 and 32+ stages, so that pieces are drained with and without stages to hide under)."""
+    run = lambda *a, **k: _run_with_hint(stages, *a, **k)
+    if stages == 32:
+        run(8192 + 128 + 4, 1024, 32 - 4, a_kc, b_kc)   # one (ragged) stage per tile
+        run(16384, 512, 128, a_kc, b_kc, epilogue=2 if a_kc else 0)
+    run(16384 + (0 if not a_kc else 1), 1024, 264, a_kc, b_kc)
+    run(4100, 1024, 1024 + 4, a_kc, b_kc)
+    run(2048 + 4, 2048 - 4 * 9, 96 + 4, a_kc, b_kc)
+    if not a_kc and not b_kc:
+        run(1024, 512, 16385, 0, 0, split_k=22)
+        run(1024, 1024, 16384, 0, 0, split_k=8)
+        run(512, 1024, 300, 0, 0, split_k=16)  # slices shorter than a stage, some empty
+    if a_kc:
+        for epi in (1, 2, 3):
+            run(16385, 512, 1024, 1, b_kc, epilogue=epi)
+        run(8200, 1024, 512, 1, b_kc, alpha=0.5)
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+@pytest.mark.parametrize("count", [2, 3])
+def test_gemm_grouped_equals_single_launches(count, bf16):
+    """addhip_gemm_grouped: `count` equal-shaped problems on different buffers in one launch == the same problems launched one by one,
+    bit for bit (fp32 and bf16-stored operands; forward, dX and split-K weight-gradient shapes; a shape that is launched one by one)."""
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import gemm
+
+    rng = np.random.RandomState(11)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    esz = 2 if bf16 else 4
+    for (M, N, K, akc, bkc, epi, split) in ((4100, 1024, 264 if not bf16 else 272, 1, 1, 2, 1), (4096, 512, 1024, 1, 0, 3, 1), (1024, 1024, 4100 if not bf16 else 4104, 0, 0, 0, 8),
+                                            (256, 64, 128, 1, 1, 1, 1)):
+        probs, outs = [], []
+        for i in range(count):
+            A = torch.tensor(rng.uniform(-1, 1, (M, K) if akc else (K, M)).astype(F)).to(dt).cuda()
+            B = torch.tensor(rng.uniform(-1, 1, (N, K) if bkc else (K, N)).astype(F)).to(dt).cuda()
+            bias, mask = T(rng.uniform(-1, 1, N).astype(F)), T(rng.uniform(-1, 1, (M, N)).astype(F))
+            C1, C2 = (torch.full((max(split, 1), M, N), 7.0, device="cuda") for _ in range(2))
+            cs1, cs2 = (torch.zeros(N, device="cuda") for _ in range(2))
+            mk = lambda C, cs: gemm(M, N, K, P(A), K if akc else M, akc, P(B), K if bkc else N, bkc, P(C), N, epi, P(bias), P(mask), N, split_k=split,
+                                    colsum=P(cs) if epi == 3 else None, precision=L.PREC_BF16 if bf16 else L.PREC_F32, operands_bf16=bf16)
+            probs.append((mk(C1, cs1), mk(C2, cs2)))
+            outs.append((C1, C2, cs1, cs2))
+        arr = (L.GemmT * count)(*[p[0] for p in probs])
+        L.call("addhip_gemm_grouped", arr, count, L.current_stream())
+        for p in probs:
+            L.call("addhip_gemm_f32", p[1], L.current_stream())
+        torch.cuda.synchronize()
+        for C1, C2, cs1, cs2 in outs:
+            assert torch.equal(C1, C2) and not bool((C1 == 7.0).all()), (M, N, K)
+            torch.testing.assert_close(cs1, cs2, rtol=1e-4, atol=2e-3)  # column sums of 4096 values go by float atomics: order varies
+    # mismatched problems are refused
+    g1 = gemm(512, 512, 512, P(torch.zeros(512 * 512, device="cuda")), 512, 1, P(torch.zeros(512 * 512, device="cuda")), 512, 1, P(torch.zeros(512 * 512, device="cuda")), 512)
+    g2 = gemm(512, 512, 256, g1.A, 512, 1, g1.B, 512, 1, g1.C, 512)
+    with pytest.raises(L.AddhipError):
+        L.call("addhip_gemm_grouped", (L.GemmT * 2)(g1, g2), 2, L.current_stream())
+
+
+@pytest.mark.parametrize("hint", [32, 64])  # ADDHIP_GEMM_HINT_PERSISTENT / NO_PERSISTENT
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])
+def test_gemm_bf16_storage_persistent_kernel(a_kc, b_kc, hint):
+    """bf16-stored operands on the persistent LDS-DMA kernel and, same shapes, on the one-tile-per-workgroup kernel: ragged rows past
+    the last tile, K tails inside a 64-deep stage, 1 / 5 / 16 stages per tile, every epilogue, split-K slabs."""
+    run_gemm_bf16(16384 + (8 if not a_kc else 1), 1024, 272, a_kc, b_kc, hint=hint)
+    run_gemm_bf16(8192 + 128, 1024, 56, a_kc, b_kc, hint=hint)
+    if a_kc:
+        for epi in (1, 2, 3):
+            run_gemm_bf16(16385, 512, 1024, 1, b_kc, epilogue=epi, hint=hint)
+    if not a_kc and not b_kc:
+        run_gemm_bf16(1024, 272, 16385 + 7, 0, 0, split_k=22, hint=hint)
+        run_gemm_bf16(1024, 1024, 16384, 0, 0, split_k=8, hint=hint)

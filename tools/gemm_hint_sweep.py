@@ -1,0 +1,53 @@
+"""The update step's GEMM shapes under each kernel configuration of the 128x128 tile family (addhip_gemm_t.hint), one launch at a time
+(HIP events, median of 7) and as a grouped launch of two equal problems: what the dispatcher's choices in gemm.hip / gemm_bf16.hip rest on.
+usage: gemm_hint_sweep.py [fp32|bf16]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, add_gym_amd
+import add_gym_amd._lib as L
+from add_gym_amd.hotpath import gemm
+
+bf16 = (sys.argv[1] if len(sys.argv) > 1 else "fp32") == "bf16"
+dt = torch.bfloat16 if bf16 else torch.float32
+SHAPES = [(16384, 1024, 1024, 1, 1, 2, 1), (16384, 512, 1024, 1, 1, 2, 1), (16384, 1024, 272, 1, 1, 2, 1), (16384, 1024, 128, 1, 1, 2, 1),
+          (16384, 1024, 1024, 1, 0 if not bf16 else 1, 3, 1), (16384, 1024, 512, 1, 0 if not bf16 else 1, 3, 1),
+          (1024, 1024, 16384, 0, 0, 0, 8), (512, 1024, 16384, 0, 0, 0, 16), (1024, 272, 16384, 0, 0, 0, 22), (1024, 128, 16384, 0, 0, 0, 32)]
+HINTS = [("auto", 0), ("persistent", 32), ("two-stage", 8 | 64), ("one-stage", 4 | 64)] + ([] if bf16 else [("reg-staged", 16)])
+st = torch.cuda.current_stream()
+
+
+def make(M, N, K, akc, bkc, epi, split, hint):
+    A = torch.randn(M * K, device="cuda").to(dt)
+    B = torch.randn(N * K, device="cuda").to(dt)
+    C = torch.zeros(M * N * split, device="cuda")
+    bias = torch.randn(N, device="cuda")
+    bits = torch.randint(-2**31, 2**31 - 1, (M * ((N + 31) // 32),), device="cuda", dtype=torch.int32)
+    kw = dict(mask_bits=L.ptr(bits), ldbits=(N + 31) // 32) if epi == 3 else (dict(relu_bits=L.ptr(bits), ldbits=(N + 31) // 32) if epi == 2 else {})
+    C16 = torch.zeros(M * N, device="cuda", dtype=torch.bfloat16) if bf16 and split == 1 else None
+    g = gemm(M, N, K, L.ptr(A), K if akc else M, akc, L.ptr(B), K if bkc else N, bkc, None if C16 is not None else L.ptr(C), N, epi, L.ptr(bias), None, 0,
+             precision=L.PREC_BF16 if bf16 else L.PREC_F32, split_k=split, operands_bf16=int(bf16), C16=L.ptr(C16) if C16 is not None else None, ldc16=N, hint=hint, **kw)
+    return g, (A, B, C, bias, bits, C16)
+
+
+def timed(fn):
+    ts = []
+    for _ in range(8):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st); fn(); e1.record(st); e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts[1:])[3] * 1e3
+
+
+for shp in SHAPES:
+    M, N, K, akc, bkc, epi, split = shp
+    fl = 2.0 * M * N * K
+    row = []
+    for name, h in HINTS:
+        g, keep = make(*shp, h)
+        us = timed(lambda: L.call("addhip_gemm_f32", g, st.cuda_stream))
+        g2, keep2 = make(*shp, h)
+        arr = (L.GemmT * 2)(g, g2)
+        us2 = timed(lambda: L.call("addhip_gemm_grouped", arr, 2, st.cuda_stream))
+        row.append(f"{name} {us:6.1f} ({fl / us / 1e6:5.0f} TF) x2 {us2:6.1f} ({2 * fl / us2 / 1e6:5.0f})")
+        del keep, keep2
+    print(f"M={M:6d} N={N:5d} K={K:6d} akc={akc} bkc={bkc} epi={epi} split={split:2d} | " + " | ".join(row), flush=True)
