@@ -83,7 +83,7 @@ class RigidDrT(C.Structure):
 RIGID_BODY_W, RIGID_TOPO_W = 32, 8
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
 PREC_F32, PREC_BF16, PREC_BF16X2, PREC_BF16X3 = 0, 1, 2, 3
-(GEMM_HINT_BIG_TILE, GEMM_HINT_NO_BIG_TILE, GEMM_HINT_ONE_STAGE, GEMM_HINT_TWO_STAGE, GEMM_HINT_REG_STAGED, GEMM_HINT_PERSISTENT, GEMM_HINT_NO_PERSISTENT) = 1, 2, 4, 8, 16, 32, 64
+GEMM_HINT_BIG_TILE, GEMM_HINT_NO_BIG_TILE, GEMM_HINT_ONE_STAGE, GEMM_HINT_TWO_STAGE, GEMM_HINT_REG_STAGED = 1, 2, 4, 8, 16
 GEMM_MAX_GROUP = 4
 
 i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p

@@ -403,13 +403,10 @@ bool takes_dma_f32(const addhip_gemm_t& g, long long tiles128) {
 int launch_dma_f32(const addhip_dma::GemmGroup& grp, int count, hipStream_t st) {
   const addhip_gemm_t& g = grp.g[0];
   const int tiles_m = (g.M + 127) / 128, tiles_n = (g.N + 127) / 128, split = g.split_k > 1 ? g.split_k : 1;
-  const int wgs = addhip_dma::persistent_workgroups();
-  if (addhip_dma::takes_persistent(g, addhip_dma::ElemF32::BKS, count, wgs)) {
-    const long long total = (long long)tiles_m * tiles_n * split * count;
-    addhip_dma::launch_dma_persistent<addhip_dma::ElemF32>(grp, count, tiles_m, tiles_n, split, (int)(total < wgs ? total : wgs), st);
-    return addhip::check_launch("gemm_dma_persistent_kernel<f32>");
-  }
-  bool one_stage = false;
+  // one LDS stage x 4 workgroups per CU for the activation-streaming launches (forward, dX) that fill it -- the co-resident workgroups
+  // cover each other's first fetch and write-out (16384x1024x1024: 272 us against 298 two-stage and 287 register-staged) -- two stages
+  // x 2 per CU for the deep-K split-K weight gradients and for launches of fewer workgroups (profiles/r03_gemm_hint_sweep_fp32.log)
+  bool one_stage = g.a_kcontig && split == 1 && (long long)tiles_m * tiles_n * count >= 768;
   if (g.hint & ADDHIP_GEMM_HINT_ONE_STAGE) one_stage = true;
   if (g.hint & ADDHIP_GEMM_HINT_TWO_STAGE) one_stage = false;
   if (one_stage) addhip_dma::launch_dma<addhip_dma::ElemF32, 1>(grp, count, tiles_m, tiles_n, split, st);

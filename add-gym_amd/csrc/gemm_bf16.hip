@@ -274,8 +274,8 @@ int gemm_bf16_dispatch(const addhip_dma::GemmGroup& grp, int count, hipStream_t 
   }
   const int split = g.split_k > 1 ? g.split_k : 1;
   // 128x128 tiles: a single LDS stage x 4 (3 with a transposed operand) workgroups per CU when the launch has the workgroups to
-  // fill that, double-buffered stages x 2 workgroups per CU if not (measured: 1024-tile launches 7-17 % faster single-buffered,
-  // 512-workgroup launches 3-5 % faster double-buffered).  256x256 tiles (gemm_bf16_q_kernel, one workgroup per CU) only for
+  // half-fill that, double-buffered stages x 2 workgroups per CU if not (profiles/r03_gemm_hint_sweep_bf16.log: 1024-tile launches
+  // 8-20 % faster single-buffered, the 512-528-workgroup weight gradients 8-20 %, 512-workgroup forward launches the same).  256x256 tiles (gemm_bf16_q_kernel, one workgroup per CU) only for
   // whole-tile shapes that fill the chip AND are deep in K: at 4096^3 it runs 1040 TFLOP/s on random operands, but with the
   // 1024-deep K of the training step's launches its prologue and 256x256 write-out are not amortised (725 TFLOP/s isolated, the
   // same as the 128x128 kernel) and, holding a CU's LDS alone, it keeps the other streams' launches off the CU (update phase
@@ -288,13 +288,7 @@ int gemm_bf16_dispatch(const addhip_dma::GemmGroup& grp, int count, hipStream_t 
   const int BM = big ? 256 : 128, BN = BM;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   if (!big) {
-    const int wgs = addhip_dma::persistent_workgroups();
-    if (addhip_dma::takes_persistent(g, addhip_dma::ElemBF16::BKS, count, wgs)) {
-      const long long total = (long long)tiles_m * tiles_n * split * count;
-      addhip_dma::launch_dma_persistent<addhip_dma::ElemBF16>(grp, count, tiles_m, tiles_n, split, (int)(total < wgs ? total : wgs), st);
-      return check_launch("gemm_dma_persistent_kernel<bf16>");
-    }
-    bool one_stage = (long long)tiles_m * tiles_n * split * count >= 768;
+    bool one_stage = (long long)tiles_m * tiles_n * split * count >= 512;
     if (g.hint & ADDHIP_GEMM_HINT_ONE_STAGE) one_stage = true;
     if (g.hint & ADDHIP_GEMM_HINT_TWO_STAGE) one_stage = false;
     if (one_stage) addhip_dma::launch_dma<addhip_dma::ElemBF16, 1>(grp, count, tiles_m, tiles_n, split, st);

@@ -15,7 +15,6 @@
 // and the critic's layers of an update step run as one launch, so that a launch has several rounds of tiles and one round's
 // write-out overlaps the next round's first stage instead of the whole chip writing (and then fetching) in lock-step.
 #pragma once
-#include <type_traits>
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -168,7 +167,8 @@ template <int CFG> struct Cfg {
   static constexpr int LDS_BYTES = STAGES * STAGE > EPI_BYTES ? STAGES * STAGE : EPI_BYTES;
 };
 
-template <typename E, bool AKC, bool BKC, int CFG> constexpr int min_blocks() { return CFG == 1 ? ((AKC && BKC) ? 4 : 3) : 2; }
+// workgroups per CU: the one-stage configuration runs 4 (bf16 with a transposed operand: 3, its tr-read fragments need the registers)
+template <typename E, bool AKC, bool BKC, int CFG> constexpr int min_blocks() { return CFG == 1 ? ((E::ESZ == 4 || (AKC && BKC)) ? 4 : 3) : 2; }
 
 template <typename E, bool AKC, bool BKC, int EPI, int CFG>
 __global__ __launch_bounds__(256, (min_blocks<E, AKC, BKC, CFG>())) void gemm_dma_kernel(GemmGroup grp, int tiles_m, int tiles_n) {
@@ -275,163 +275,6 @@ __global__ __launch_bounds__(256, (min_blocks<E, AKC, BKC, CFG>())) void gemm_dm
   gemm_epilogue<MT, 2, EPI>(g, acc, lds + wave * EpiBuf<2>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// PERSISTENT variant with the epilogue of tile i issued UNDER the main loop of tile i+1.  Why: a K <= 1024 launch of the plain
-// kernel spends a large part of its time outside its main loop (bf16: 19 of 46 us) -- every workgroup of a round fetches its
-// first stage at the same moment and, one main loop later, all of them write C at the same moment with the matrix cores idle.
-// Here a workgroup walks a static list of tiles (tile = blockIdx.x + i * gridDim.x over all problems of the group and all
-// split-K slices) with two LDS stages that keep alternating ACROSS tiles: the last stage of tile i already fetches the first
-// stage of tile i+1, and tile i's finished accumulators stay in registers (2 workgroups per CU -> 256 VGPRs per wave) and leave
-// in eight pieces (gemm_epilogue_piece: half a 32x32 block each, straight from the accumulator layout, no LDS, no barrier) placed
-// behind the MFMAs of tile i+1's first eight K stages, where their store / VALU instructions issue in the matrix pipe's shadow.
-// Only the last tile of a workgroup pays an exposed epilogue (the LDS-transposed one).  Every split-K slice must be non-empty.
-template <typename E, bool AKC, bool BKC>
-struct TileCtx {
-  int prob, z, m0, n0, nk, nk_full, kleft0;
-  const char *srcA, *srcB;
-  size_t stepA, stepB;
-  Stager<E, AKC, 128, 4> sa;
-  Stager<E, BKC, 128, 4> sb;
-};
-
-template <typename E, bool AKC, bool BKC, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_dma_persistent_kernel(GemmGroup grp, int count, int tiles_m, int tiles_n, int split) {
-  typedef Cfg<0> Q;
-  constexpr int STAGE = Q::STAGE, TILE = Q::TILE_A, BK = E::BKS, ESZ = E::ESZ;
-  __shared__ __attribute__((aligned(1024))) char lds[Q::LDS_BYTES];
-  const int per = tiles_m * tiles_n, total = per * split * count;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm0 = (wave / 2) * 64, wn0 = (wave % 2) * 64;
-  const int li = lane & 31, lh = lane >> 5;
-  typedef TileCtx<E, AKC, BKC> Ctx;
-
-  // work item w -> (problem, split-K slice, tile); tiles of one slice are adjacent (they share operand panels), XCD-aware within it
-  auto setup = [&](Ctx& c, int w) {
-    c.prob = w / (per * split);
-    const int rem = w - c.prob * (per * split);
-    c.z = rem / per;
-    const int t = rem - c.z * per;
-    const int q = per >> 3, r = per & 7, xcd = t & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
-    const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
-    c.m0 = tm * 128;
-    c.n0 = tn * 128;
-    const addhip_gemm_t& g = grp.g[c.prob];
-    const int kchunk = ((g.K + split - 1) / split + BK - 1) / BK * BK;
-    const int kbeg = c.z * kchunk, kend = min(g.K, kbeg + kchunk);
-    c.kleft0 = kend - kbeg;
-    c.nk = (c.kleft0 + BK - 1) / BK;   // >= 1 (checked by the host)
-    c.nk_full = c.kleft0 / BK;
-    c.srcA = reinterpret_cast<const char*>(g.A) + (size_t)ESZ * (AKC ? (size_t)c.m0 * g.lda + kbeg : (size_t)kbeg * g.lda + c.m0);
-    c.srcB = reinterpret_cast<const char*>(g.B) + (size_t)ESZ * (BKC ? (size_t)c.n0 * g.ldb + kbeg : (size_t)kbeg * g.ldb + c.n0);
-    c.stepA = (size_t)ESZ * (AKC ? (size_t)BK : (size_t)BK * g.lda);
-    c.stepB = (size_t)ESZ * (BKC ? (size_t)BK : (size_t)BK * g.ldb);
-    c.sa.init(wave, lane, g.lda, g.M - c.m0);
-    c.sb.init(wave, lane, g.ldb, g.N - c.n0);
-  };
-  auto stage = [&](const Ctx& c, int kt, int buf) {
-    char* dst = lds + buf * STAGE;
-    const int kleft = c.kleft0 - kt * BK;
-    if (kt < c.nk_full) {
-      c.sa.template issue<false>(c.srcA + kt * c.stepA, dst, wave, kleft);
-      c.sb.template issue<false>(c.srcB + kt * c.stepB, dst + TILE, wave, kleft);
-    } else {
-      c.sa.template issue<true>(c.srcA + kt * c.stepA, dst, wave, kleft);
-      c.sb.template issue<true>(c.srcB + kt * c.stepB, dst + TILE, wave, kleft);
-    }
-  };
-  typename FragSel<E, AKC, 128, 2>::type fa_;
-  typename FragSel<E, BKC, 128, 2>::type fb_;
-  if constexpr (AKC) fa_.init(wm0, li, lh); else fa_.init(wm0, lane);
-  if constexpr (BKC) fb_.init(wn0, li, lh); else fb_.init(wn0, lane);
-
-  f32x16 acc[2][2], prev[2][2];
-  auto compute = [&](int buf) {
-    const char* a_cur = lds + buf * STAGE;
-    const char* b_cur = a_cur + TILE;
-    typename E::frag_t fa[2][2], fb[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) fa[0][a] = fa_.get(a_cur, a, 0);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) fb[0][b] = fb_.get(b_cur, b, 0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks + 1 < 4) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) fa[(ks + 1) & 1][a] = fa_.get(a_cur, a, ks + 1);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) fb[(ks + 1) & 1][b] = fb_.get(b_cur, b, ks + 1);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) E::mma(acc[a][b], fa[ks & 1][a], fb[ks & 1][b]);
-    }
-  };
-  // piece P of the previous tile's epilogue: block (P >> 2, (P >> 1) & 1), half P & 1
-  int pv_prob = 0, pv_z = 0, pv_row0 = 0, pv_col0 = 0;
-  auto piece = [&](auto pc) {
-    constexpr int P = decltype(pc)::value;
-    addhip_epi::gemm_epilogue_piece<EPI, (P & 1)>(grp.g[pv_prob], prev[P >> 2][(P >> 1) & 1], lane, pv_row0 + (P >> 2) * 32, pv_col0 + ((P >> 1) & 1) * 32, pv_z);
-  };
-
-  int w = blockIdx.x;
-  if (w >= total) return;
-  Ctx cur;
-  setup(cur, w);
-  stage(cur, 0, 0);
-  int buf = 0;
-  bool have_prev = false;
-  for (;;) {
-    const int wnext = w + (int)gridDim.x;
-    const bool has_next = wnext < total;
-    Ctx nxt = cur;
-    if (has_next) setup(nxt, wnext);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
-    int kt = 0;
-    // one K stage: its vmcnt(0) + barrier retire the stage's DMA for every wave and prove the other buffer is no longer read; the
-    // next stage's DMA (of this tile, or the first of the next tile) goes out, then this stage's MFMAs, then one epilogue piece
-    auto step = [&](auto pc) {
-      constexpr int P = decltype(pc)::value;
-      __syncthreads();
-      if (kt + 1 < cur.nk) stage(cur, kt + 1, buf ^ 1);
-      else if (has_next) stage(nxt, 0, buf ^ 1);
-      compute(buf);
-      if constexpr (P >= 0) {
-        if (have_prev) piece(pc);
-      }
-      buf ^= 1;
-      ++kt;
-    };
-#define ADDHIP_PEEL(P) if (kt < cur.nk) step(std::integral_constant<int, P>{});
-    ADDHIP_PEEL(0) ADDHIP_PEEL(1) ADDHIP_PEEL(2) ADDHIP_PEEL(3) ADDHIP_PEEL(4) ADDHIP_PEEL(5) ADDHIP_PEEL(6) ADDHIP_PEEL(7)
-#undef ADDHIP_PEEL
-    while (kt < cur.nk) step(std::integral_constant<int, -1>{});
-    if (have_prev && cur.nk < 8) {  // short K: the pieces that found no stage to hide under
-#define ADDHIP_DRAIN(P) if (cur.nk <= P) piece(std::integral_constant<int, P>{});
-      ADDHIP_DRAIN(0) ADDHIP_DRAIN(1) ADDHIP_DRAIN(2) ADDHIP_DRAIN(3) ADDHIP_DRAIN(4) ADDHIP_DRAIN(5) ADDHIP_DRAIN(6) ADDHIP_DRAIN(7)
-#undef ADDHIP_DRAIN
-    }
-    pv_prob = cur.prob; pv_z = cur.z; pv_row0 = cur.m0 + wm0; pv_col0 = cur.n0 + wn0;
-    if (!has_next) break;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) prev[a][b] = acc[a][b];
-    have_prev = true;
-    cur = nxt;
-    w = wnext;
-  }
-  // the workgroup's last tile: nothing left to hide under, LDS is free -> the transposed 16-byte-store epilogue
-  __syncthreads();
-  gemm_epilogue<2, 2, EPI>(grp.g[pv_prob], acc, lds + wave * EpiBuf<2>::WAVE_BYTES, lane, pv_row0, pv_col0, pv_z);
-}
-
 // hot layout / epilogue combinations get a compile-time epilogue; everything else shares the run-time one
 template <typename E, int CFG>
 inline void launch_dma(const GemmGroup& grp, int count, int tiles_m, int tiles_n, int split, hipStream_t st) {
@@ -452,52 +295,6 @@ inline void launch_dma(const GemmGroup& grp, int count, int tiles_m, int tiles_n
     else ADDHIP_DMA_LAUNCH(false, false, EPI_RUNTIME);
   }
 #undef ADDHIP_DMA_LAUNCH
-}
-
-template <typename E>
-inline void launch_dma_persistent(const GemmGroup& grp, int count, int tiles_m, int tiles_n, int split, int workgroups, hipStream_t st) {
-  const addhip_gemm_t& g = grp.g[0];
-  dim3 grid(workgroups), block(256);
-#define ADDHIP_DMA_LAUNCH(AK, BKc, EPI) \
-  hipLaunchKernelGGL((gemm_dma_persistent_kernel<E, AK, BKc, EPI>), grid, block, 0, st, grp, count, tiles_m, tiles_n, split)
-  if (g.a_kcontig && g.b_kcontig) {
-    if (g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_DMA_LAUNCH(true, true, ADDHIP_EPI_BIAS_RELU);
-    else if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_DMA_LAUNCH(true, true, ADDHIP_EPI_MASK);
-    else ADDHIP_DMA_LAUNCH(true, true, EPI_RUNTIME);
-  } else if (g.a_kcontig && !g.b_kcontig) {
-    if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_DMA_LAUNCH(true, false, ADDHIP_EPI_MASK);
-    else ADDHIP_DMA_LAUNCH(true, false, EPI_RUNTIME);
-  } else if (!g.a_kcontig && g.b_kcontig) {
-    ADDHIP_DMA_LAUNCH(false, true, EPI_RUNTIME);
-  } else {
-    if (g.epilogue == ADDHIP_EPI_NONE) ADDHIP_DMA_LAUNCH(false, false, ADDHIP_EPI_NONE);
-    else ADDHIP_DMA_LAUNCH(false, false, EPI_RUNTIME);
-  }
-#undef ADDHIP_DMA_LAUNCH
-}
-
-// Does a launch of `count` problems take the persistent kernel?  It needs every split-K slice non-empty and enough tiles for most
-// workgroups to walk at least two (otherwise nothing is hidden and its direct stores only cost); hint bits force either answer.
-inline bool takes_persistent(const addhip_gemm_t& g, int esz_k_per_stage, int count, int workgroups) {
-  const int split = g.split_k > 1 ? g.split_k : 1;
-  const int BK = esz_k_per_stage;
-  const int kchunk = ((g.K + split - 1) / split + BK - 1) / BK * BK;
-  if ((long long)(split - 1) * kchunk >= g.K) return false;  // an empty slice
-  if (g.hint & ADDHIP_GEMM_HINT_NO_PERSISTENT) return false;
-  if (g.hint & ADDHIP_GEMM_HINT_PERSISTENT) return true;
-  const long long total = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * split * count;
-  return total >= (3LL * workgroups) / 2;
-}
-
-// 2 persistent workgroups per CU
-inline int persistent_workgroups() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    n = 2 * cus;
-  }
-  return n;
 }
 
 }  // namespace addhip_dma

@@ -120,62 +120,4 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
   }
 }
 
-// The same epilogue for ONE HALF of one 32x32 accumulator block (registers 8*HALF .. 8*HALF+7 = tile rows 16*HALF .. 16*HALF+15),
-// written straight from the accumulator layout: a lane stores its own column, 4 (2) bytes per row -- 8 store instructions for
-// 16 rows x 32 columns instead of one 16-byte store per lane after an LDS transposition.  Slower when a wave does nothing else, but it
-// needs no LDS and no barrier, so the persistent GEMM kernel (gemm_dma.h) issues it in pieces UNDER the MFMAs of the next tile's
-// K stages, where its instruction count is free.  blk = the block's accumulators, (rtile, cgroup) = its first row / column in C.
-template <int EPI, int HALF>
-__device__ __forceinline__ void gemm_epilogue_piece(const addhip_gemm_t& g, const f32x16& blk, int lane, int rtile, int cgroup, int zslab) {
-  typedef unsigned short u16;
-  const int li = lane & 31, lh = lane >> 5;
-  const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
-  const bool accum = g.accumulate != 0;
-  float* C = g.C ? g.C + (accum ? (size_t)0 : (size_t)zslab * (size_t)g.M * g.ldc) : nullptr;
-  u16* C16 = reinterpret_cast<u16*>(g.C16);
-  const int col = cgroup + li;
-  const bool col_ok = col < g.N;
-  const float bias = (col_ok && (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU)) ? g.bias[col] : 0.f;
-  unsigned mword = 0u;  // lanes 0..31: the sign-bit word of tile row `lane`
-  if (epi == ADDHIP_EPI_MASK && g.mask_bits && lane < 32 && cgroup < g.N && rtile + lane < g.M)
-    mword = g.mask_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)];
-  unsigned rword = 0u;
-  float cs = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int x = 8 * HALF + i;
-    const int r0 = (x & 3) + 8 * (x >> 2), row = rtile + r0 + 4 * lh;
-    const bool ok = col_ok && row < g.M;
-    float v = g.alpha * blk[x] + bias;
-    if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-    if (epi == ADDHIP_EPI_MASK) {
-      if (g.mask_bits) {
-        const unsigned w0 = __builtin_amdgcn_readlane(mword, r0), w1 = __builtin_amdgcn_readlane(mword, r0 + 4);
-        v = (((lh ? w1 : w0) >> li) & 1u) ? v : 0.f;
-      } else {
-        v = (ok && g.mask[(size_t)row * g.ldmask + col] > 0.f) ? v : 0.f;
-      }
-      if (ok) cs += v;
-    }
-    if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {
-      const unsigned long long pos = __ballot(ok && v > 0.f);
-      rword = lane == r0 ? (unsigned)pos : lane == r0 + 4 ? (unsigned)(pos >> 32) : rword;
-    }
-    if (ok) {
-      if (C) {
-        float* dst = C + (size_t)row * g.ldc + col;
-        if (accum) unsafeAtomicAdd(dst, v);
-        else *dst = v;
-      }
-      if (C16) C16[(size_t)row * g.ldc16 + col] = epi_bf16(v);
-    }
-  }
-  if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits && lane >= 16 * HALF && lane < 16 * HALF + 16 && cgroup < g.N && rtile + lane < g.M)
-    g.relu_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)] = rword;
-  if (epi == ADDHIP_EPI_MASK && g.colsum) {
-    cs += __shfl_xor(cs, 32, 64);
-    if (lh == 0 && col_ok) atomicAdd(&g.colsum[col], cs);
-  }
-}
-
 }  // namespace addhip_epi

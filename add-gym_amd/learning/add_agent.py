@@ -24,7 +24,7 @@ from .. import hotpath as H
 from ..hotpath import gemm, make_task
 from ..util.logger import Logger
 from ..util.tb_logger import TBLogger
-from .model import Model, NetRunner, Plan
+from .model import Model, NetRunner, Plan, merge_sections
 
 
 _SIDE_STREAMS = {}
@@ -82,6 +82,9 @@ class ADDAgent:
         # value / discriminator evaluation passes keep fp32 operands (formed by the bf16x2 products)
         self._storage16 = prec == "bf16"
         self._prec_small = H.PRECISIONS["bf16x2"] if self._storage16 else self._prec
+        # agent.group_actor_critic (default off): the actor's and the critic's equal-shaped forward / dX GEMMs of an update step run as
+        # grouped launches (addhip_gemm_grouped) on one stream; off = one launch per net and layer on two streams, same results
+        self._group_actor_critic = bool(cfg.get("group_actor_critic", False))
 
         # ---- motion library + sampler (add_motion.py:14-33)
         kin = env.robot._kin_char_model
@@ -282,7 +285,14 @@ class ADDAgent:
                                              L.ptr(B["ep_stats"][t])))
 
         # ---- update step on one gathered minibatch (ppo_agent.py:194-275, add_agent.py:141-202)
+        # The actor's and the critic's sections are recorded into plans of their own.  Default: they follow each other in the step's
+        # plan and run on two streams (beside the discriminator's two).  agent.group_actor_critic: they are MERGED onto one stream --
+        # the two nets have the same hidden shapes, so their forward and dX GEMMs pair up into grouped launches (addhip_gemm_grouped:
+        # one launch of two rounds of tiles); everything else keeps its order within its net.  Grouped launches are 2-20 % faster
+        # than their two halves launched alone (profiles/r03_gemm_hint_sweep_*.log), but inside the step the two-stream form wins:
+        # there a net's loss-head / reduction kernels run beside the other net's GEMMs.
         p = self._update_plan = Plan()
+        p_actor, p_critic = Plan(), Plan()
         # every loss coefficient carries 1/world: the all-reduce SUM of the gradients is then their mean over ranks
         gs = 1.0 / self._world
         ls_d = self._disc_loss_weight * gs
@@ -291,6 +301,7 @@ class ADDAgent:
         # actor
         s16 = self._storage16
         x16 = L.ptr(W["norm_obs16"]) if s16 else None
+        p = p_actor
         ra.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True, x16_ptr=x16)
         self._gemm(p, Mb, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
         p.add("addhip_count_mask", L.ptr(W["mb_mask"]), Mb, L.ptr(W["nv"]))
@@ -305,15 +316,19 @@ class ADDAgent:
         self._gemm(p, Mb, hA, 32, L.ptr(W["d_mean"]), 32, 1, m.p("actor", "Wh"), hA, 0, None if s16 else L.ptr(ra.dz[-1]), hA, L.EPI_MASK,
                    colsum=m.g("actor", f"b{len(m.actor.hidden) - 1}"), **top16(ra), **ra.mask_args(len(m.actor.hidden) - 1, 0, Mb))
         ra.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True, x16_ptr=x16, top_cast_done=True)
-        self._update_marks = [("actor", len(p.calls))]  # the net's gradient is complete after this many calls
         # critic
+        p = p_critic
         rc.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True, x16_ptr=x16)
         p.add("addhip_critic_head", L.ptr(rc.h[-1]), hC, hC, Mb, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(W["mb_tar"]), self._critic_loss_weight * gs,
               None, L.ptr(W["dv"]), L.ptr(W["stats"]) + 4 * 8)
         p.add("addhip_head_backward", L.ptr(W["dv"]), m.p("critic", "Wh"), L.ptr(rc.h[-1]), hC, hC, Mb, None if s16 else L.ptr(rc.dz[-1]),
               L.ptr(rc.dz16[-1]) if s16 else None, m.g("critic", "Wh"), m.g("critic", "bh"), m.g("critic", f"b{len(m.critic.hidden) - 1}"))
         rc.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True, x16_ptr=x16, top_cast_done=True)
-        self._update_marks.append(("critic", len(p.calls)))
+        p = self._update_plan
+        pos_a, pos_c = merge_sections(p, p_actor, p_critic, group=self._group_actor_critic)
+        end_a, end_ac = pos_a[-1] + 1, len(p.calls)
+        ea, ec = pos_a[ra.early_mark - 1] + 1, pos_c[rc.early_mark - 1] + 1  # the net's gradient, first layer excepted, is final after this many calls
+        self._update_marks = [("actor", end_a), ("critic", end_ac)] if not self._group_actor_critic else [("actor+critic", end_ac)]
         # discriminator: Mb agent/demo differences + one zero-difference row (row Mb of norm_diff stays 0)
         Md = Mb + 1
         # L2 terms (add_agent.py:161-164, 181-186): logit reg on the head weights, weight decay on all disc weights.  They go into the
@@ -367,23 +382,29 @@ class ADDAgent:
         self._update_marks.append(("disc", len(p.calls)))
         # Launch / exchange schedule of one optimiser step: entries (stream, first call, last call, gradient range to all-reduce after
         # it, entry whose completion the stream waits for before it starts, entry it waits for before the all-reduce), issued in
-        # list order.  Actor and critic hand over everything but their first layer as soon as it is final; the collectives are
+        # list order.  Actor and critic (one merged section on the main stream) hand over everything but their first layers as soon as it is final; the collectives are
         # issued in the order they become ready, because one communicator runs them in issue order.
         # The discriminator's section is the longest chain of the step, so its independent pieces run side by side on two
         # streams: the logit loss and its backward step through the head (stream 3) beside the gradient-penalty chain (stream 2),
         # then the top layer's weight gradient (stream 3, own split-K scratch) beside the dX GEMM and the first layer's.
-        (_, end_a), (_, end_c), (_, end_d) = self._update_marks
-        ea, ec = ra.early_mark, rc.early_mark
+        end_d = self._update_marks[-1][1]
         br = m.bucket_ranges
         dw_first, dw_last = rd.dw_marks[len(m.disc.hidden) - 1]
-        sched = [(0, 0, ea, br["actor_tail"], None, None), (1, end_a, ec, br["critic_tail"], None, None),
-                 (2, end_c, d_head, None, None, None),          # 2: L2 terms, forward
+        if self._group_actor_critic:
+            ac_early = max(ea, ec)
+            head = [(0, 0, ac_early, br["actor_tail"], None, None), (0, ac_early, ac_early, br["critic_tail"], None, None)]  # (no calls: the second bucket)
+            tail = [(0, ac_early, end_ac, None, None, None)]
+        else:
+            head = [(0, 0, ea, br["actor_tail"], None, None), (1, end_a, ec, br["critic_tail"], None, None)]
+            tail = [(0, ea, end_a, None, None, None), (1, ec, end_ac, None, None, None)]
+        sched = head + [
+                 (2, end_ac, d_head, None, None, None),         # 2: L2 terms, forward
                  (3, d_head, d_gp, None, 2, None),              # 3: logit loss, head backward -> top dz
                  (2, d_gp, d_bwd, None, None, None),            # 4: gradient-penalty chain
                  (3, d_bwd, dw_first, None, None, None),        # 5: (bf16 storage: the top dz rounded to bf16)
                  (3, dw_first, dw_last, None, 4, None),         # 6: top-layer weight gradient (needs the chain's a2 / e1)
-                 (2, dw_last, end_d, br["disc"], 5, 6),         # 7: dX, first-layer weight gradient
-                 (0, ea, end_a, None, None, None), (1, ec, end_c, None, None, None)]  # the two first layers: one bucket after the join
+                 (2, dw_last, end_d, br["disc"], 5, 6)          # 7: dX, first-layer weight gradient
+                 ] + tail                                        # the two first layers: one bucket after the join
         self._update_schedule = sched
         self._sched_events = sorted({e[4] for e in sched if e[4] is not None} | {e[5] for e in sched if e[5] is not None})
 

@@ -236,6 +236,51 @@ class Plan:
                 raise L.AddhipError(f"{name} failed ({rc}): {self._lib.addhip_last_error().decode()}")
 
 
+def _group_key(call):
+    """Signature under which two recorded GEMM calls may share a grouped launch (None: never)."""
+    name, _, args = call
+    if name != "addhip_gemm_f32":
+        return None
+    g = args[0]
+    if g.split_k > 1 or g.M <= 8 or g.a_mean:  # split-K weight gradients gain nothing from grouping (measured), few-row launches take another kernel
+        return None
+    return (g.M, g.N, g.K, g.a_kcontig, g.b_kcontig, g.epilogue, g.precision, g.operands_bf16, g.accumulate, bool(g.mask_bits), bool(g.relu_bits),
+            bool(g.C16), bool(g.C), bool(g.colsum))
+
+
+def merge_sections(plan, sec_a, sec_b, group=True):
+    """Append the calls of two independent recorded sections to `plan`, pairing GEMMs of equal signature -- in the order they occur in
+    either section -- into addhip_gemm_grouped launches; every other call keeps its order within its own section.  Returns
+    (pos_a, pos_b): the index in `plan.calls` at which each call of either section ended up."""
+    lib = plan._lib
+    base = len(plan.calls)
+    out, pos_a, pos_b, ib = [], [], [None] * len(sec_b.calls), 0
+    for ca in sec_a.calls:
+        key = _group_key(ca) if group else None
+        j = None
+        if key is not None:
+            j = next((j for j in range(ib, len(sec_b.calls)) if _group_key(sec_b.calls[j]) == key), None)
+        if j is not None:
+            for i in range(ib, j):
+                pos_b[i] = base + len(out)
+                out.append(sec_b.calls[i])
+            arr = (L.GemmT * 2)(ca[2][0], sec_b.calls[j][2][0])
+            plan.hold(arr)
+            pos_a.append(base + len(out))
+            pos_b[j] = base + len(out)
+            out.append(("addhip_gemm_grouped", lib.addhip_gemm_grouped, (arr, 2)))
+            ib = j + 1
+        else:
+            pos_a.append(base + len(out))
+            out.append(ca)
+    for i in range(ib, len(sec_b.calls)):
+        pos_b[i] = base + len(out)
+        out.append(sec_b.calls[i])
+    plan.calls.extend(out)
+    plan.keep.extend(sec_a.keep + sec_b.keep)
+    return pos_a, pos_b
+
+
 class NetRunner:
     """Forward / backward call recording for one Mlp over `rows` rows with its own activation buffers."""
 

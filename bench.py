@@ -68,11 +68,11 @@ def time_gemms(agent, reps=3):
     import add_gym_amd._lib as L
 
     st = torch.cuda.current_stream()
-    calls = [(fn, args) for name, fn, args in agent._update_plan.calls if name == "addhip_gemm_f32"]
+    calls = [(fn, args) for name, fn, args in agent._update_plan.calls if name in ("addhip_gemm_f32", "addhip_gemm_grouped")]
     flops = 0.0
     for _, args in calls:
-        g = args[0]
-        flops += 2.0 * g.M * g.N * g.K
+        g = args[0][0] if len(args) == 2 else args[0]          # grouped: (array of equal-shaped problems, count)
+        flops += 2.0 * g.M * g.N * g.K * (args[1] if len(args) == 2 else 1)
     ms = 0.0
     for _ in range(reps):
         for fn, args in calls:

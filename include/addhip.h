@@ -266,9 +266,7 @@ enum {
   ADDHIP_GEMM_HINT_NO_BIG_TILE = 2,  /* bf16 operands: never the 256x256 kernel */
   ADDHIP_GEMM_HINT_ONE_STAGE = 4,    /* 128x128 tiles: one LDS stage x 3-4 workgroups per CU */
   ADDHIP_GEMM_HINT_TWO_STAGE = 8,    /* 128x128 tiles: two LDS stages x 2 workgroups per CU */
-  ADDHIP_GEMM_HINT_REG_STAGED = 16,  /* fp32 operands: the register-staged tile kernel instead of the LDS-DMA one */
-  ADDHIP_GEMM_HINT_PERSISTENT = 32,  /* 128x128 LDS-DMA tiles: the persistent kernel (epilogue of a tile under the next tile's main loop) */
-  ADDHIP_GEMM_HINT_NO_PERSISTENT = 64
+  ADDHIP_GEMM_HINT_REG_STAGED = 16   /* fp32 operands: the register-staged tile kernel instead of the LDS-DMA one */
 };
 int addhip_gemm_f32(const addhip_gemm_t* g, void* stream);
 /* Up to ADDHIP_GEMM_MAX_GROUP problems of the SAME shape, operand layouts, epilogue kind, split, precision and storage (different

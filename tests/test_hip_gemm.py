@@ -430,18 +430,15 @@ def _run_with_hint(hint, *a, **k):
         H.gemm = orig
 
 
-@pytest.mark.parametrize("stages", [4 | 64, 8 | 64, 16, 32])  # ADDHIP_GEMM_HINT_ONE_STAGE / TWO_STAGE (LDS-DMA kernel, not persistent), REG_STAGED, PERSISTENT
+@pytest.mark.parametrize("stages", [4, 8, 16])  # ADDHIP_GEMM_HINT_ONE_STAGE / TWO_STAGE (LDS-DMA kernel), REG_STAGED (the register-staged kernel)
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_gemm_fp32_lds_dma_kernel(a_kc, b_kc, stages):
     """fp32 operands on the 128x128 LDS-DMA kernel (gemm_dma.h; what shapes of more than 256 tiles take): every layout, ragged M / N / K
     edges (K tail inside a 32-deep stage, rows past the last tile, N not a multiple of 128), epilogues with sign-bit masks' fp32
     fallback, split-K slabs with empty and ragged slices -- under both stage configurations and, for comparison, the register-staged
-    kernel on the same shapes; and the PERSISTENT kernel (a workgroup walks several tiles, the epilogue of one issued in pieces under
-    the next one's K stages: K of 1, 4, 9 and 32+ stages, so that pieces are drained with and without stages to hide under)."""
+    kernel on the same shapes."""
     run = lambda *a, **k: _run_with_hint(stages, *a, **k)
-    if stages == 32:
-        run(8192 + 128 + 4, 1024, 32 - 4, a_kc, b_kc)   # one (ragged) stage per tile
-        run(16384, 512, 128, a_kc, b_kc, epilogue=2 if a_kc else 0)
+    run(8192 + 128 + 4, 1024, 32 - 4, a_kc, b_kc)   # one (ragged) stage per tile
     run(16384 + (0 if not a_kc else 1), 1024, 264, a_kc, b_kc)
     run(4100, 1024, 1024 + 4, a_kc, b_kc)
     run(2048 + 4, 2048 - 4 * 9, 96 + 4, a_kc, b_kc)
@@ -495,11 +492,11 @@ def test_gemm_grouped_equals_single_launches(count, bf16):
         L.call("addhip_gemm_grouped", (L.GemmT * 2)(g1, g2), 2, L.current_stream())
 
 
-@pytest.mark.parametrize("hint", [32, 64])  # ADDHIP_GEMM_HINT_PERSISTENT / NO_PERSISTENT
+@pytest.mark.parametrize("hint", [4, 8])  # ADDHIP_GEMM_HINT_ONE_STAGE / TWO_STAGE
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])
-def test_gemm_bf16_storage_persistent_kernel(a_kc, b_kc, hint):
-    """bf16-stored operands on the persistent LDS-DMA kernel and, same shapes, on the one-tile-per-workgroup kernel: ragged rows past
-    the last tile, K tails inside a 64-deep stage, 1 / 5 / 16 stages per tile, every epilogue, split-K slabs."""
+def test_gemm_bf16_storage_stage_configurations(a_kc, b_kc, hint):
+    """bf16-stored operands under both stage configurations of the 128x128 LDS-DMA kernel, whatever the dispatcher would pick: ragged rows
+    past the last tile, K tails inside a 64-deep stage, 1 / 5 / 16 stages per tile, every epilogue, split-K slabs."""
     run_gemm_bf16(16384 + (8 if not a_kc else 1), 1024, 272, a_kc, b_kc, hint=hint)
     run_gemm_bf16(8192 + 128, 1024, 56, a_kc, b_kc, hint=hint)
     if a_kc:

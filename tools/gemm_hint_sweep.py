@@ -12,7 +12,7 @@ dt = torch.bfloat16 if bf16 else torch.float32
 SHAPES = [(16384, 1024, 1024, 1, 1, 2, 1), (16384, 512, 1024, 1, 1, 2, 1), (16384, 1024, 272, 1, 1, 2, 1), (16384, 1024, 128, 1, 1, 2, 1),
           (16384, 1024, 1024, 1, 0 if not bf16 else 1, 3, 1), (16384, 1024, 512, 1, 0 if not bf16 else 1, 3, 1),
           (1024, 1024, 16384, 0, 0, 0, 8), (512, 1024, 16384, 0, 0, 0, 16), (1024, 272, 16384, 0, 0, 0, 22), (1024, 128, 16384, 0, 0, 0, 32)]
-HINTS = [("auto", 0), ("persistent", 32), ("two-stage", 8 | 64), ("one-stage", 4 | 64)] + ([] if bf16 else [("reg-staged", 16)])
+HINTS = [("auto", 0), ("two-stage", 8), ("one-stage", 4)] + ([] if bf16 else [("reg-staged", 16)])
 st = torch.cuda.current_stream()
 
 

@@ -16,7 +16,7 @@ for r in (ag._run_actor, ag._run_critic, ag._run_disc):
 for k, w in ag._W.items():
     if w.dtype == torch.bfloat16: w.copy_(torch.randn(w.shape, device=w.device))
 st = torch.cuda.current_stream().cuda_stream
-calls = [(fn, args) for name, fn, args in ag._update_plan.calls if name == "addhip_gemm_f32"]
+calls = [(fn, args) for name, fn, args in ag._update_plan.calls if name in ("addhip_gemm_f32", "addhip_gemm_grouped")]
 print("gemm launches per step:", len(calls))
 for _ in range(3):
     for fn, args in calls:

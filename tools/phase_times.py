@@ -8,8 +8,9 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 engine = sys.argv[3] if len(sys.argv) > 3 else "kinematic"
 graph = sys.argv[4] if len(sys.argv) > 4 else "false"
+extra = sys.argv[5:]   # further config overrides, e.g. agent.group_actor_critic=false
 ag = ADDAgent(load_config("train", [f"engine={engine}", f"engine.num_envs={N}", f"agent.matmul_precision={prec}", "task.motion_file=synthetic:1x3600",
-                                    f"agent.rollout_graph={graph}"]))
+                                    f"agent.rollout_graph={graph}"] + extra))
 ag.reset_all_envs(); ag._init_train()
 import gc; gc.collect(); gc.freeze()
 acc = {}
@@ -23,4 +24,4 @@ for it in range(8):
     timed("update_model", ag._update_model)
     timed("normalizers+info", lambda: (ag._update_normalizers(), ag._collect_info(40)))
     ag._iter += 1
-print(prec, N, engine, "rollout_graph=" + graph, {k: round(sorted(v[4:])[len(v[4:]) // 2], 2) for k, v in acc.items()}, "ms", flush=True)
+print(prec, N, engine, "rollout_graph=" + graph, *extra, {k: round(sorted(v[4:])[len(v[4:]) // 2], 2) for k, v in acc.items()}, "ms", flush=True)

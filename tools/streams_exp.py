@@ -1,4 +1,4 @@
-"""Experiment: the three nets' sections of the update plan on one stream vs three concurrent streams (timing only; the
+"""Experiment: the sections of the update plan (actor + critic merged, discriminator) on one stream vs concurrent streams (timing only; the
 shared split-K scratch makes the concurrent results meaningless)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,11 +21,11 @@ def par():
     ev = torch.cuda.Event(); ev.record(main)
     streams = [main] + side
     for s in side: s.wait_event(ev)
-    for i, s in enumerate(streams):
-        plan.run(s.cuda_stream, marks[i], marks[i + 1])
+    for i in range(len(marks) - 1):
+        plan.run(streams[i].cuda_stream, marks[i], marks[i + 1])
     for s in side:
         e = torch.cuda.Event(); e.record(s); main.wait_event(e)
-for name, fn in (("one stream", seq), ("three streams", par), ("one stream", seq), ("three streams", par)):
+for name, fn in (("one stream", seq), ("one stream per section", par), ("one stream", seq), ("one stream per section", par)):
     for _ in range(2): fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
