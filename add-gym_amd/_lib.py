@@ -80,6 +80,13 @@ class RigidDrT(C.Structure):
                 ("friction_lo", C.c_float), ("friction_hi", C.c_float), ("push_velocity", C.c_float)]
 
 
+class OptimizerT(C.Structure):
+    _fields_ = [("type", C.c_int32), ("param", f32p), ("grad", f32p), ("state1", f32p), ("state2", f32p), ("count", C.c_int64), ("lr", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("step", C.c_int32), ("param16", f32p),
+                ("zero_grad", C.c_int32)]
+
+
+OPT_ADAMW, OPT_SGD = 0, 1
 RIGID_BODY_W, RIGID_TOPO_W = 32, 8
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
 PREC_F32, PREC_BF16, PREC_BF16X2, PREC_BF16X3 = 0, 1, 2, 3
@@ -132,6 +139,7 @@ SIGNATURES = {
     "addhip_grad_clip": [vp, i64, f32, vp, vp, vp],
     "addhip_adamw": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
     "addhip_sgd": [vp, vp, vp, i64, f32, f32, f32, i32, vp],
+    "addhip_optimizer_step": [P(OptimizerT), vp],
     "addhip_return_tracker_fold": [vp, i32, vp, vp],
 }
 
@@ -154,7 +162,7 @@ def load():
     lib.addhip_last_error.restype = C.c_char_p
     lib.addhip_version.restype = C.c_int
     lib.addhip_abi_sizes.argtypes, lib.addhip_abi_sizes.restype = [C.POINTER(C.c_int32), C.c_int32], C.c_int
-    structs = (MotionT, TaskT, EnvT, StepOutT, SamplerT, GemmT, GatherT, RigidModelT, RigidDrT)
+    structs = (MotionT, TaskT, EnvT, StepOutT, SamplerT, GemmT, GatherT, RigidModelT, RigidDrT, OptimizerT)
     sizes = (C.c_int32 * len(structs))()
     mine = [C.sizeof(t) for t in structs]
     if lib.addhip_abi_sizes(sizes, len(structs)) != len(structs) or list(sizes) != mine:

@@ -20,7 +20,7 @@ extern "C" int addhip_version(void) { return 3; }
 extern "C" int addhip_abi_sizes(int32_t* out, int32_t count) {
   const int32_t sizes[] = {(int32_t)sizeof(addhip_motion_t), (int32_t)sizeof(addhip_task_t), (int32_t)sizeof(addhip_env_t), (int32_t)sizeof(addhip_step_out_t),
                            (int32_t)sizeof(addhip_sampler_t), (int32_t)sizeof(addhip_gemm_t), (int32_t)sizeof(addhip_gather_t), (int32_t)sizeof(addhip_rigid_model_t),
-                           (int32_t)sizeof(addhip_rigid_dr_t)};
+                           (int32_t)sizeof(addhip_rigid_dr_t), (int32_t)sizeof(addhip_optimizer_t)};
   const int32_t n = (int32_t)(sizeof(sizes) / sizeof(sizes[0]));
   if (!out || count < n) return -1;
   for (int32_t i = 0; i < n; ++i) out[i] = sizes[i];

@@ -334,7 +334,7 @@ extern "C" int addhip_to_bf16_t(const float* src, uint16_t* dst, int32_t rows, i
 
 extern "C" int addhip_shadow_refresh(const float* params, uint16_t* flat16, uint16_t* trans16, int64_t count, const int64_t* offset, const int32_t* rows,
                                      const int32_t* cols, int32_t n_mats, void* stream) {
-  ADDHIP_REQUIRE(params && flat16 && count > 0 && n_mats >= 0 && n_mats <= ADDHIP_SHADOW_MAX_MATS, "shadow_refresh: bad arguments");
+  ADDHIP_REQUIRE(params && (flat16 || n_mats > 0) && count > 0 && n_mats >= 0 && n_mats <= ADDHIP_SHADOW_MAX_MATS, "shadow_refresh: bad arguments");
   ADDHIP_REQUIRE(n_mats == 0 || (trans16 && offset && rows && cols), "shadow_refresh: matrix table missing");
   ADDHIP_REQUIRE(aligned16(params) && (reinterpret_cast<uintptr_t>(flat16) & 7u) == 0, "shadow_refresh: misaligned buffers");
   ShadowMats mats;
@@ -351,7 +351,7 @@ extern "C" int addhip_shadow_refresh(const float* params, uint16_t* flat16, uint
     mats.tile_end[i] = tiles;
   }
   long long fb = (count / 4 + 255) / 256;
-  const int flat_blocks = (int)(fb < 1 ? 1 : fb > 2048 ? 2048 : fb);
+  const int flat_blocks = flat16 ? (int)(fb < 1 ? 1 : fb > 2048 ? 2048 : fb) : 0;  // flat16 == NULL: the transposed copies only
   hipLaunchKernelGGL(shadow_refresh_kernel, dim3((unsigned)(flat_blocks + tiles)), dim3(256), 0, (hipStream_t)stream, params, flat16, trans16,
                      (long long)count, flat_blocks, mats);
   return addhip::check_launch("shadow_refresh_kernel");

@@ -559,16 +559,24 @@ __global__ __launch_bounds__(256) void l2_grad_kernel(const float* w, float* gra
   if (threadIdx.x == 0 && sumsq) atomicAdd(sumsq, t);
 }
 
-// torch.optim.AdamW single-tensor update order (weight decay, lerp, addcmul, sqrt/bias2 + eps, addcdiv)
+// torch.optim.AdamW single-tensor update order (weight decay, lerp, addcmul, sqrt/bias2 + eps, addcdiv); one definition for
+// addhip_adamw and addhip_optimizer_step, so that the two agree bit for bit
+__device__ __forceinline__ void adamw_one(float& p, float gi, float& m, float& v, float lr, float b1, float b2, float eps, float wd, float step_size,
+                                          float bc2_sqrt) {
+  float pi = p * (1.f - lr * wd);
+  float mi = m + (1.f - b1) * (gi - m);
+  float vi = v * b2 + (1.f - b2) * gi * gi;
+  float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p = pi - step_size * (mi / denom);
+  m = mi;
+  v = vi;
+}
 __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,
                              float step_size, float bc2_sqrt) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float gi = g[i];
-    float pi = p[i] * (1.f - lr * wd);
-    float mi = m[i] + (1.f - b1) * (gi - m[i]);
-    float vi = v[i] * b2 + (1.f - b2) * gi * gi;
-    float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - step_size * (mi / denom);
+    float pi = p[i], mi = m[i], vi = v[i];
+    adamw_one(pi, g[i], mi, vi, lr, b1, b2, eps, wd, step_size, bc2_sqrt);
+    p[i] = pi;
     m[i] = mi;
     v[i] = vi;
   }
@@ -576,13 +584,57 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long 
 
 // torch.optim.SGD single-tensor update with momentum (mp_optimizer.py:33-36: momentum 0.9, dampening 0, no nesterov):
 // g += wd p;  buf = first ? g : mu buf + g;  p -= lr buf
+__device__ __forceinline__ void sgd_one(float& p, float gi, float& buf, float lr, float mu, float wd, int first) {
+  if (wd != 0.f) gi = gi + wd * p;
+  const float b = first ? gi : buf * mu + gi;
+  buf = b;
+  p = p - lr * b;
+}
 __global__ void sgd_kernel(float* p, const float* g, float* buf, long long n, float lr, float mu, float wd, int first) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float gi = g[i];
-    if (wd != 0.f) gi = gi + wd * p[i];
-    const float b = first ? gi : buf[i] * mu + gi;
-    buf[i] = b;
-    p[i] = p[i] - lr * b;
+    float pi = p[i], bi = buf[i];
+    sgd_one(pi, g[i], bi, lr, mu, wd, first);
+    buf[i] = bi;
+    p[i] = pi;
+  }
+}
+
+// MPOptimizer.step as ONE pass over the flat buffers (addhip_optimizer_step): the AdamW / SGD update above element for element, plus --
+// in the same read of the gradient and write of the parameter -- the bf16 weight shadow (round to nearest even) and the zero_grad of the
+// NEXT step (mp_optimizer.py:14-16), so that an optimiser step ends with one launch instead of optimiser + shadow conversion + memset
+__device__ __forceinline__ unsigned short opt_bf16(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+template <bool SGD>
+__global__ __launch_bounds__(256) void optimizer_step_kernel(addhip_optimizer_t o, float step_size, float bc2_sqrt) {
+  const long long n4 = o.count >> 2;
+  float4* p4 = reinterpret_cast<float4*>(o.param);
+  float4* g4 = reinterpret_cast<float4*>(o.grad);
+  float4* m4 = reinterpret_cast<float4*>(o.state1);
+  float4* v4 = reinterpret_cast<float4*>(o.state2);
+  auto one = [&](float& p, float g, float& m, float& v) {
+    if (SGD) sgd_one(p, g, m, o.lr, o.beta1, o.weight_decay, o.step == 1 ? 1 : 0);
+    else adamw_one(p, g, m, v, o.lr, o.beta1, o.beta2, o.eps, o.weight_decay, step_size, bc2_sqrt);
+  };
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 p = p4[i], m = m4[i], v = SGD ? make_float4(0.f, 0.f, 0.f, 0.f) : v4[i];
+    const float4 g = g4[i];
+    one(p.x, g.x, m.x, v.x); one(p.y, g.y, m.y, v.y); one(p.z, g.z, m.z, v.z); one(p.w, g.w, m.w, v.w);
+    p4[i] = p;
+    m4[i] = m;
+    if (!SGD) v4[i] = v;
+    if (o.param16)
+      reinterpret_cast<uint2*>(o.param16)[i] = make_uint2((unsigned)opt_bf16(p.x) | ((unsigned)opt_bf16(p.y) << 16), (unsigned)opt_bf16(p.z) | ((unsigned)opt_bf16(p.w) << 16));
+    if (o.zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (o.count & 3)) {  // (count % 4 elements past the last float4)
+    const long long i = (n4 << 2) + threadIdx.x;
+    float v = SGD ? 0.f : o.state2[i];
+    one(o.param[i], o.grad[i], o.state1[i], v);
+    if (!SGD) o.state2[i] = v;
+    if (o.param16) o.param16[i] = opt_bf16(o.param[i]);
+    if (o.zero_grad) o.grad[i] = 0.f;
   }
 }
 
@@ -847,6 +899,24 @@ extern "C" int addhip_sgd(float* param, const float* grad, float* momentum_buf, 
   hipLaunchKernelGGL(sgd_kernel, dim3(elem_grid(count)), dim3(256), 0, ST, param, grad, momentum_buf, (long long)count, lr, momentum, weight_decay,
                      step == 1 ? 1 : 0);
   return addhip::check_launch("sgd_kernel");
+}
+
+extern "C" int addhip_optimizer_step(const addhip_optimizer_t* op, void* stream) {
+  ADDHIP_REQUIRE(op, "optimizer_step: null descriptor");
+  const addhip_optimizer_t o = *op;
+  ADDHIP_REQUIRE(o.type == ADDHIP_OPT_ADAMW || o.type == ADDHIP_OPT_SGD, "optimizer_step: type must be ADDHIP_OPT_ADAMW or ADDHIP_OPT_SGD");
+  ADDHIP_REQUIRE(o.param && o.grad && o.state1 && (o.state2 || o.type == ADDHIP_OPT_SGD) && o.count > 0 && o.step >= 1, "optimizer_step: bad arguments");
+  ADDHIP_REQUIRE(aligned16(o.param) && aligned16(o.grad) && aligned16(o.state1) && (o.type == ADDHIP_OPT_SGD || aligned16(o.state2)) &&
+                     (reinterpret_cast<uintptr_t>(o.param16) & 7u) == 0, "optimizer_step: buffers must be 16-byte aligned (the bf16 shadow: 8)");
+  long long blocks = ((o.count >> 2) + 255) / 256;
+  blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+  if (o.type == ADDHIP_OPT_SGD) {
+    hipLaunchKernelGGL(optimizer_step_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ST, o, 0.f, 1.f);
+  } else {
+    const double bc1 = 1.0 - pow((double)o.beta1, (double)o.step), bc2 = 1.0 - pow((double)o.beta2, (double)o.step);
+    hipLaunchKernelGGL(optimizer_step_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ST, o, (float)((double)o.lr / bc1), (float)sqrt(bc2));
+  }
+  return addhip::check_launch("optimizer_step_kernel");
 }
 
 extern "C" int addhip_grad_clip(float* grad, int64_t count, float max_norm, float* scratch, float* norm_out, void* stream) {

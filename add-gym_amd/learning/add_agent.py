@@ -168,6 +168,10 @@ class ADDAgent:
             D.broadcast_(self._model.params, 0)
         if self._storage16:
             self._model.enable_shadow()
+        mm = self._model
+        sgd = self._opt_type == "SGD"
+        self._opt_c = L.OptimizerT(L.OPT_SGD if sgd else L.OPT_ADAMW, L.ptr(mm.params), L.ptr(mm.grads), L.ptr(mm.exp_avg), None if sgd else L.ptr(mm.exp_avg_sq),
+                                   mm.count, self._lr, 0.9, 0.999, 1e-8, self._wd, 1, L.ptr(mm.params16) if self._storage16 else None, 1)
 
         self._build_workspace()
         self._build_plans()
@@ -303,6 +307,8 @@ class ADDAgent:
         x16 = L.ptr(W["norm_obs16"]) if s16 else None
         p = p_actor
         ra.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True, x16_ptr=x16)
+        if s16:  # the transposed weight copies the backward pass reads: refreshed here, beside the other nets' GEMMs (the optimiser step wrote the flat shadow)
+            p.add("addhip_shadow_refresh", *m.transposed_refresh_args("actor"))
         self._gemm(p, Mb, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
         p.add("addhip_count_mask", L.ptr(W["mb_mask"]), Mb, L.ptr(W["nv"]))
         p.add("addhip_actor_loss", L.ptr(W["mean"]), L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_mask"]), Mb, m.std32,
@@ -319,6 +325,8 @@ class ADDAgent:
         # critic
         p = p_critic
         rc.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True, x16_ptr=x16)
+        if s16:
+            p.add("addhip_shadow_refresh", *m.transposed_refresh_args("critic"))
         p.add("addhip_critic_head", L.ptr(rc.h[-1]), hC, hC, Mb, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(W["mb_tar"]), self._critic_loss_weight * gs,
               None, L.ptr(W["dv"]), L.ptr(W["stats"]) + 4 * 8)
         p.add("addhip_head_backward", L.ptr(W["dv"]), m.p("critic", "Wh"), L.ptr(rc.h[-1]), hC, hC, Mb, None if s16 else L.ptr(rc.dz[-1]),
@@ -341,6 +349,8 @@ class ADDAgent:
         nd = L.ptr(W["norm_diff"])
         nd16 = L.ptr(W["norm_diff16"]) if s16 else None
         rd.forward(p, nd, Md, sign_bits=True, x16_ptr=nd16)
+        if s16:
+            p.add("addhip_shadow_refresh", *m.transposed_refresh_args("disc"))
         d_head = len(p.calls)
         p.add("addhip_disc_head", L.ptr(rd.h[-1]), hD, hD, Mb, L.ptr(rd.h[-1]) + 4 * Mb * hD, m.p("disc", "Wh"), m.p("disc", "bh"), ls_d,
               L.ptr(W["dlogit"]), L.ptr(W["dlogit"]) + 4 * Mb, L.ptr(W["stats"]) + 4 * 12)
@@ -685,7 +695,7 @@ class ADDAgent:
         self._next_minibatch_indices()
         L.call("addhip_gather_minibatch", self._gather_c, st)
         while steps < n_steps:
-            self._run_update_sections()
+            self._run_update_sections(zero_grad=steps == 0)  # later steps find the gradient zeroed by the optimiser launch before them
             steps += 1
             gathered = None
             if steps < n_steps:
@@ -701,18 +711,16 @@ class ADDAgent:
             if self._grad_clip > 0.0:
                 L.call("addhip_grad_clip", L.ptr(m.grads), m.count, self._grad_clip, L.ptr(W["scratch"]), None, st)
             m.opt_step += 1
-            if self._opt_type == "SGD":
-                L.call("addhip_sgd", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), m.count, self._lr, 0.9, self._wd, m.opt_step, st)
-            else:
-                L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, self._lr, 0.9, 0.999, 1e-8,
-                       self._wd, m.opt_step, st)
-            if self._storage16:
-                m.refresh_shadow(st)
+            # MPOptimizer.step: the update, the bf16 shadow of the new parameters (bf16-storage mode; the transposed copies follow inside
+            # the next step's sections) and the zero_grad of the next step in ONE launch
+            o = self._opt_c
+            o.step = m.opt_step
+            L.call("addhip_optimizer_step", o, st)
             if gathered is not None:
                 main.wait_event(gathered)
         return steps
 
-    def _run_update_sections(self):
+    def _run_update_sections(self, zero_grad=True):
         """The actor, critic and discriminator sections of the update plan are independent until the optimiser: they run on
         three streams, so that one net's tile write-out bursts and partial last waves of workgroups overlap another
         net's MFMA phases (all tiles of one GEMM launch are in phase with each other).  With more than one rank each
@@ -721,7 +729,8 @@ class ADDAgent:
         m, plan = self._model, self._update_plan
         main = torch.cuda.current_stream()
         streams = [main] + self._side_streams
-        L.call("addhip_fill_zero", L.ptr(m.grads), m.count, main.cuda_stream)  # MPOptimizer.step's zero_grad (mp_optimizer.py:14-16)
+        if zero_grad:  # MPOptimizer.step's zero_grad (mp_optimizer.py:14-16); inside an update phase addhip_optimizer_step has done it
+            L.call("addhip_fill_zero", L.ptr(m.grads), m.count, main.cuda_stream)
         # (bf16-storage mode: the gather wrote the bf16 copies of the minibatch rows too; row Mb of norm_diff16 stays 0 from its allocation)
         fork = torch.cuda.Event()
         fork.record(main)

@@ -113,6 +113,11 @@ class Model:
         n = len(self._transposed)
         offs, dims = zip(*(self.offsets[k] for k in self._transposed))
         self._shadow_table = ((C.c_int64 * n)(*offs), (C.c_int32 * n)(*(d[0] for d in dims)), (C.c_int32 * n)(*(d[1] for d in dims)), n)
+        self._net_tables = {}
+        for net in self.nets:  # the same table net by net: each net's transposed copies are refreshed on its own stream (transposed_refresh_args)
+            keys = [k for k in self._transposed if k[0] == net.name]
+            o, dm = zip(*(self.offsets[k] for k in keys))
+            self._net_tables[net.name] = ((C.c_int64 * len(keys))(*o), (C.c_int32 * len(keys))(*(d[0] for d in dm)), (C.c_int32 * len(keys))(*(d[1] for d in dm)), len(keys))
         self.refresh_shadow()
 
     def refresh_shadow(self, stream=None):
@@ -121,6 +126,12 @@ class Model:
             st = L.current_stream() if stream is None else stream
             offs, rows, cols, n = self._shadow_table
             L.call("addhip_shadow_refresh", L.ptr(self.params), L.ptr(self.params16), L.ptr(self.params16t), self.count, offs, rows, cols, n, st)
+
+    def transposed_refresh_args(self, net):
+        """Arguments (without the stream) of the addhip_shadow_refresh call that rewrites only `net`'s transposed weight copies from the
+        fp32 parameters (the flat shadow is written by the optimiser step itself)."""
+        offs, rows, cols, n = self._net_tables[net]
+        return (L.ptr(self.params), None, L.ptr(self.params16t), self.count, offs, rows, cols, n)
 
     def p16(self, net, key):
         off, _ = self.offsets[(net, key)]

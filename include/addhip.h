@@ -36,8 +36,8 @@ enum { ADDHIP_DONE_NULL = 0, ADDHIP_DONE_FAIL = 1, ADDHIP_DONE_SUCC = 2, ADDHIP_
 
 const char* addhip_last_error(void);
 int addhip_version(void);
-/* sizeof() of addhip_motion_t, task_t, env_t, step_out_t, sampler_t, gemm_t, gather_t, rigid_model_t, rigid_dr_t (in that order) -> out[0..8];
- * returns the number written (9) or -1.  For bindings to verify their struct layouts against the library they loaded. */
+/* sizeof() of addhip_motion_t, task_t, env_t, step_out_t, sampler_t, gemm_t, gather_t, rigid_model_t, rigid_dr_t, optimizer_t (in that order) -> out[0..9];
+ * returns the number written (10) or -1.  For bindings to verify their struct layouts against the library they loaded. */
 int addhip_abi_sizes(int32_t* out, int32_t count);
 
 /* ---- reference-motion step tables: MotionLib._step_* (anim/motion_lib.py:285-320) ---- */
@@ -285,7 +285,8 @@ int addhip_to_bf16(const float* src, uint16_t* dst, int64_t rows, int32_t cols, 
 int addhip_to_bf16_t(const float* src, uint16_t* dst, int32_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream);
 /* The whole bf16 weight shadow after an optimiser step in ONE launch: flat16[i] = bf16(params[i]) for i < count, and for each of the
  * n_mats (<= ADDHIP_SHADOW_MAX_MATS) row-major matrices [rows, cols] at params + offset the transposed copy [cols, rows] at
- * trans16 + offset (offset, rows, cols: host arrays) */
+ * trans16 + offset (offset, rows, cols: host arrays).  flat16 may be NULL (the flat shadow is then written by addhip_optimizer_step and only
+ * the transposed copies of the listed matrices are refreshed -- e.g. one net's, on that net's stream, between its forward and backward pass) */
 #define ADDHIP_SHADOW_MAX_MATS 8
 int addhip_shadow_refresh(const float* params, uint16_t* flat16, uint16_t* trans16, int64_t count, const int64_t* offset, const int32_t* rows,
                           const int32_t* cols, int32_t n_mats, void* stream);
@@ -428,6 +429,23 @@ int addhip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg
  * p -= lr*buf */
 int addhip_sgd(float* param, const float* grad, float* momentum_buf, int64_t count, float lr, float momentum, float weight_decay,
                int32_t step, void* stream);
+
+/* MPOptimizer.step (mp_optimizer.py:14-46: zero_grad ... step) as one launch over the flat buffers: the AdamW or SGD(momentum) update of
+ * addhip_adamw / addhip_sgd element for element, and in the same pass (both optional)
+ *   param16   the bf16 shadow of the updated parameters, round to nearest even (bf16-storage mode: what the next forward GEMMs read);
+ *   zero_grad grad[i] = 0 after it was read: the zero_grad with which the NEXT step begins.
+ * state1 = exp_avg (AdamW) / momentum buffer (SGD), state2 = exp_avg_sq (AdamW; unused for SGD); beta1 doubles as the SGD momentum. */
+enum { ADDHIP_OPT_ADAMW = 0, ADDHIP_OPT_SGD = 1 };
+typedef struct {
+  int32_t type;
+  float* param; float* grad; float* state1; float* state2;
+  int64_t count;
+  float lr, beta1, beta2, eps, weight_decay;
+  int32_t step;            /* 1-based */
+  uint16_t* param16;       /* or NULL */
+  int32_t zero_grad;
+} addhip_optimizer_t;
+int addhip_optimizer_step(const addhip_optimizer_t* o, void* stream);
 
 /* ReturnTracker running means over the T steps of an iteration (base_agent.py:596-621):
  * ep_stats [T,3] -> state {episodes, mean_return, mean_ep_len} updated step by step */

@@ -497,3 +497,38 @@ def test_full_size_td_lambda_and_flat_optimiser():
         L.call("addhip_adamw", L.ptr(dp), P(T(g)), L.ptr(m), L.ptr(v), count, 1e-4, 0.9, 0.999, 1e-8, 0.0, step, L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(dp.cpu().numpy(), p.detach().numpy(), rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("kind", ["adamw", "sgd"])
+def test_optimizer_step_is_the_separate_kernels_in_one_launch(kind):
+    """addhip_optimizer_step (MPOptimizer.step, mp_optimizer.py:14-46, as one launch) == addhip_adamw / addhip_sgd element for element, plus the
+    bf16 shadow of the new parameters (== addhip_to_bf16 of them) and the zeroed gradient; a count that is not a multiple of 4."""
+    import torch
+    import add_gym_amd._lib as L
+
+    n = 4 * 50001 + 3
+    rng = np.random.RandomState(2)
+    p0 = torch.tensor(rng.standard_normal(n + 1).astype(F), device="cuda")[:n]
+    bufs = [[p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")] for _ in range(2)]
+    p16 = torch.zeros(n + 1, dtype=torch.bfloat16, device="cuda")
+    for step in range(1, 4):
+        g = torch.tensor((rng.standard_normal(n) * 0.1).astype(F), device="cuda")
+        (pa, ma, va), (pb, mb, vb) = bufs
+        if kind == "adamw":
+            L.call("addhip_adamw", L.ptr(pa), L.ptr(g), L.ptr(ma), L.ptr(va), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, L.current_stream())
+        else:
+            L.call("addhip_sgd", L.ptr(pa), L.ptr(g), L.ptr(ma), n, 1e-2, 0.9, 1e-3, step, L.current_stream())
+        g2 = g.clone()
+        o = L.OptimizerT(L.OPT_ADAMW if kind == "adamw" else L.OPT_SGD, L.ptr(pb), L.ptr(g2), L.ptr(mb), L.ptr(vb) if kind == "adamw" else None, n,
+                         1e-3 if kind == "adamw" else 1e-2, 0.9, 0.999, 1e-8, 1e-2 if kind == "adamw" else 1e-3, step, L.ptr(p16), 1)
+        L.call("addhip_optimizer_step", o, L.current_stream())
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), step
+        assert float(g2.abs().max()) == 0.0
+        assert torch.equal(p16[:n], pb.to(torch.bfloat16)) and float(p16[n]) == 0.0
+    # without the options the gradient is left alone
+    g3 = g.clone()
+    o.grad, o.param16, o.zero_grad, o.step = L.ptr(g3), None, 0, 4
+    L.call("addhip_optimizer_step", o, L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(g3, g)

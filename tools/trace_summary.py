@@ -9,7 +9,7 @@ rows = []
 for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-opt = [i for i, r in enumerate(rows) if "adamw" in r[2] or "sgd_kernel" in r[2]]
+opt = [i for i, r in enumerate(rows) if "adamw" in r[2] or "sgd_kernel" in r[2] or "optimizer_step" in r[2]]
 first, last = opt[-steps - 1], opt[-1]           # from the end of the optimiser launch before the phase's second step ... keep whole steps
 t0, t1 = rows[first][1], rows[last][1]
 sel = [r for r in rows if r[0] >= t0 and r[1] <= t1]
