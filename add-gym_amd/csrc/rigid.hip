@@ -511,10 +511,10 @@ constexpr int L4_S = 10;                 // steps per pass = max(start + len) ov
 constexpr int L4_ENVS = 16;              // environments per 64-lane workgroup
 constexpr int L4_BW = BW + 1;
 constexpr int L4_STATE = L4_ENVS * (36 + 36 + 32);
-constexpr int L4_MODEL = MAXB * L4_BW + MAXB * TW + 64 + MAXP * 4;
-constexpr int P_SIN = 0, P_COS = L4_S, P_U = 2 * L4_S, P_DINV = 8 * L4_S, P_UU = 9 * L4_S, P_BV = 10 * L4_S, P_BNZ = 16 * L4_S, P_BH = 19 * L4_S;
-constexpr int P_TOTAL = 20 * L4_S;
-constexpr int L4_LDS_FLOATS = L4_STATE + L4_MODEL + P_TOTAL * 64;
+constexpr int L4_MODEL = MAXB * L4_BW + MAXB * TW + 64;     // + 4 floats per collision point (sized at launch)
+// per-lane LDS fields, one slot per step ([field][lane]); the fields from P_W on exist only in the all-LDS form of the kernel
+constexpr int P_U = 0, P_DINV = 6 * L4_S, P_UU = 7 * L4_S, P_W = 8 * L4_S, P_N = 14 * L4_S, P_BH = 17 * L4_S, P_SIN = 18 * L4_S, P_COS = 19 * L4_S;
+constexpr int l4_lds_floats(int num_points, bool regs) { return L4_STATE + L4_MODEL + num_points * 4 + (regs ? 8 : 20) * L4_S * 64; }
 
 __device__ __forceinline__ float quad_from(float v, int src_lane_in_quad) { return __shfl(v, (threadIdx.x & ~3) | src_lane_in_quad, 64); }
 __device__ __forceinline__ float quad_sum(float v) {
@@ -580,6 +580,7 @@ __device__ __forceinline__ void body_contacts(const float* pts, int npt, int lin
   }
 }
 
+template <bool REGS>
 __global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M, float* __restrict__ sim_pose, float* __restrict__ sim_vel,
                                                          const float* __restrict__ target, int tstride, int n, unsigned char* __restrict__ contact_flag,
                                                          unsigned* __restrict__ contact_bits) {
@@ -595,11 +596,20 @@ __global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M,
   int* mtopo = reinterpret_cast<int*>(mbody + MAXB * L4_BW);
   int* mchain = mtopo + MAXB * TW;
   float* mpts = reinterpret_cast<float*>(mchain + 64);
-  float* pl = lds + L4_STATE + L4_MODEL;
+  float* pl = mpts + M.num_points * 4;  // (the launch sizes the dynamic LDS for the model's own point count)
 #define SP(c) st_pose[e * 36 + (c)]
 #define SV(c) st_vel[e * 36 + (c)]
 #define TG(c) st_tgt[e * 32 + (c)]
-#define PL(f, i) pl[((f) + (i)) * 64 + lane]
+  // Per-body state handed from pass to pass, one slot per STEP of the pass: body velocity (w, vl), up-vector and height (pass 1 ->
+  // passes 2 / 3), sin / cos of the joint angles (substep to substep), U, 1/D, u (pass 2 -> pass 3).  All of it can live in LDS
+  // ([field][lane], 200 floats per lane: 69 KB per workgroup, two workgroups = two waves per CU).  REGS: the first 120 floats per lane are
+  // VGPR arrays instead -- the step counter is wave-uniform, so they are registers addressed through M0 (s_set_gpr_idx), not memory --
+  // which leaves 38 KB of LDS per workgroup: FOUR waves per CU, one per SIMD (65 536 envs: 1207 -> 648 us per control step).  The
+  // indexed moves cost a lone wave 8 % (4096 envs: 150 -> 162 us), so launches that cannot fill two waves per CU keep the LDS form;
+  // U, 1/D, u stay in LDS either way (with them the arrays pass the 256 directly addressable VGPRs and spill).
+  float r_w0[L4_S], r_w1[L4_S], r_w2[L4_S], r_v0[L4_S], r_v1[L4_S], r_v2[L4_S], r_n0[L4_S], r_n1[L4_S], r_n2[L4_S], r_bh[L4_S], r_sin[L4_S], r_cos[L4_S];
+#define PL(f, s_) pl[((f) + (s_)) * 64 + lane]
+#define SLOT(reg, f, s_) (REGS ? reg[s_] : PL(f, s_))
   const int nb = M.num_bodies;
   for (int idx = lane; idx < live * 36; idx += 64) {
     st_pose[idx] = sim_pose[(size_t)env0 * 36 + idx];
@@ -668,9 +678,9 @@ __global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M,
         float sn, cs;
         if (sub == 0) {
           sincosf(qj, &sn, &cs);
-          PL(P_SIN, i) = sn; PL(P_COS, i) = cs;
+          SLOT(r_sin, P_SIN, s) = sn; SLOT(r_cos, P_COS, s) = cs;
         } else {
-          sn = PL(P_SIN, i); cs = PL(P_COS, i);
+          sn = SLOT(r_sin, P_SIN, s); cs = SLOT(r_cos, P_COS, s);
         }
         const M3 R = joint_rot(bc + 3, ax, sn, cs);
         const V3 r{bc[0], bc[1], bc[2]};
@@ -679,10 +689,8 @@ __global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M,
         if (ax == 0) w.x += qd; else if (ax == 1) w.y += qd; else w.z += qd;
         const V3 nz = mulT(R, cnz);
         chh = chh + dot(cnz, r);
-        PL(P_BV, 6 * i) = w.x; PL(P_BV, 6 * i + 1) = w.y; PL(P_BV, 6 * i + 2) = w.z;
-        PL(P_BV, 6 * i + 3) = vl.x; PL(P_BV, 6 * i + 4) = vl.y; PL(P_BV, 6 * i + 5) = vl.z;
-        PL(P_BNZ, 3 * i) = nz.x; PL(P_BNZ, 3 * i + 1) = nz.y; PL(P_BNZ, 3 * i + 2) = nz.z;
-        PL(P_BH, i) = chh;
+        SLOT(r_w0, P_W + 0 * L4_S, s) = w.x; SLOT(r_w1, P_W + 1 * L4_S, s) = w.y; SLOT(r_w2, P_W + 2 * L4_S, s) = w.z; SLOT(r_v0, P_W + 3 * L4_S, s) = vl.x; SLOT(r_v1, P_W + 4 * L4_S, s) = vl.y; SLOT(r_v2, P_W + 5 * L4_S, s) = vl.z;
+        SLOT(r_n0, P_N + 0 * L4_S, s) = nz.x; SLOT(r_n1, P_N + 1 * L4_S, s) = nz.y; SLOT(r_n2, P_N + 2 * L4_S, s) = nz.z; SLOT(r_bh, P_BH, s) = chh;
         cw = w; cv = vl; cnz = nz;
       }
     }
@@ -713,9 +721,9 @@ __global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M,
         const float* bc = mbody + k * L4_BW;
         const int* tp = mtopo + k * TW;
         const int ax = tp[1], dof = tp[2], pt0 = tp[5], npt = tp[6], link = tp[7];
-        const V3 w{PL(P_BV, 6 * i), PL(P_BV, 6 * i + 1), PL(P_BV, 6 * i + 2)}, vl{PL(P_BV, 6 * i + 3), PL(P_BV, 6 * i + 4), PL(P_BV, 6 * i + 5)};
-        const V3 nz{PL(P_BNZ, 3 * i), PL(P_BNZ, 3 * i + 1), PL(P_BNZ, 3 * i + 2)};
-        const float hk = PL(P_BH, i);
+        const V3 w{SLOT(r_w0, P_W + 0 * L4_S, s), SLOT(r_w1, P_W + 1 * L4_S, s), SLOT(r_w2, P_W + 2 * L4_S, s)}, vl{SLOT(r_v0, P_W + 3 * L4_S, s), SLOT(r_v1, P_W + 4 * L4_S, s), SLOT(r_v2, P_W + 5 * L4_S, s)};
+        const V3 nz{SLOT(r_n0, P_N + 0 * L4_S, s), SLOT(r_n1, P_N + 1 * L4_S, s), SLOT(r_n2, P_N + 2 * L4_S, s)};
+        const float hk = SLOT(r_bh, P_BH, s);
         ArtI I;
         Sp6 p;
         body_inertia(bc, w, vl, nz, M.gravity, I, p);
@@ -738,8 +746,8 @@ __global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M,
         else { Ua = {I.A.xz, I.A.yz, I.A.zz}; Ul = {I.B.m[6], I.B.m[7], I.B.m[8]}; }
         const float Dinv = 1.f / (comp(Ua, ax) + dadd);
         const float u = tau - comp(p.a, ax);
-        PL(P_U, 6 * i) = Ua.x; PL(P_U, 6 * i + 1) = Ua.y; PL(P_U, 6 * i + 2) = Ua.z; PL(P_U, 6 * i + 3) = Ul.x; PL(P_U, 6 * i + 4) = Ul.y; PL(P_U, 6 * i + 5) = Ul.z;
-        PL(P_DINV, i) = Dinv; PL(P_UU, i) = u;
+        PL(P_U, 6 * s) = Ua.x; PL(P_U, 6 * s + 1) = Ua.y; PL(P_U, 6 * s + 2) = Ua.z; PL(P_U, 6 * s + 3) = Ul.x; PL(P_U, 6 * s + 4) = Ul.y; PL(P_U, 6 * s + 5) = Ul.z;
+        PL(P_DINV, s) = Dinv; PL(P_UU, s) = u;
         I.A.xx -= Dinv * Ua.x * Ua.x; I.A.xy -= Dinv * Ua.x * Ua.y; I.A.xz -= Dinv * Ua.x * Ua.z; I.A.yy -= Dinv * Ua.y * Ua.y; I.A.yz -= Dinv * Ua.y * Ua.z; I.A.zz -= Dinv * Ua.z * Ua.z;
         I.C.xx -= Dinv * Ul.x * Ul.x; I.C.xy -= Dinv * Ul.x * Ul.y; I.C.xz -= Dinv * Ul.x * Ul.z; I.C.yy -= Dinv * Ul.y * Ul.y; I.C.yz -= Dinv * Ul.y * Ul.z; I.C.zz -= Dinv * Ul.z * Ul.z;
         {
@@ -755,7 +763,7 @@ __global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M,
         p.a = p.a + mul(I.A, ca) + mul(I.B, cl) + ud * Ua;
         p.l = p.l + mulT(I.B, ca) + mul(I.C, cl) + ud * Ul;
         // to the parent's coordinates:  X^T Ia X,  X^T pa   (X = rot(R^T) xlt(r))
-        const M3 R = joint_rot(bc + 3, ax, PL(P_SIN, i), PL(P_COS, i));
+        const M3 R = joint_rot(bc + 3, ax, SLOT(r_sin, P_SIN, s), SLOT(r_cos, P_COS, s));
         const V3 r{bc[0], bc[1], bc[2]};
         ArtI P;
         P.A = rot_sym(R, I.A);
@@ -836,16 +844,16 @@ __global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M,
         const float* bc = mbody + k * L4_BW;
         const int* tp = mtopo + k * TW;
         const int ax = tp[1], dof = tp[2];
-        const float s0 = PL(P_SIN, i), c0 = PL(P_COS, i);
+        const float s0 = SLOT(r_sin, P_SIN, s), c0 = SLOT(r_cos, P_COS, s);
         const M3 R = joint_rot(bc + 3, ax, s0, c0);
         const V3 r{bc[0], bc[1], bc[2]};
-        const V3 w{PL(P_BV, 6 * i), PL(P_BV, 6 * i + 1), PL(P_BV, 6 * i + 2)}, vl{PL(P_BV, 6 * i + 3), PL(P_BV, 6 * i + 4), PL(P_BV, 6 * i + 5)};
+        const V3 w{SLOT(r_w0, P_W + 0 * L4_S, s), SLOT(r_w1, P_W + 1 * L4_S, s), SLOT(r_w2, P_W + 2 * L4_S, s)}, vl{SLOT(r_v0, P_W + 3 * L4_S, s), SLOT(r_v1, P_W + 4 * L4_S, s), SLOT(r_v2, P_W + 5 * L4_S, s)};
         const float qd = SV(6 + dof);
         const V3 ev = unit(ax);
         V3 aa = mulT(R, caa) + qd * cross(w, ev);
         const V3 al = mulT(R, cal - cross(r, caa)) + qd * cross(vl, ev);
-        const V3 Ua{PL(P_U, 6 * i), PL(P_U, 6 * i + 1), PL(P_U, 6 * i + 2)}, Ul{PL(P_U, 6 * i + 3), PL(P_U, 6 * i + 4), PL(P_U, 6 * i + 5)};
-        const float qdd = (PL(P_UU, i) - dot(Ua, aa) - dot(Ul, al)) * PL(P_DINV, i);
+        const V3 Ua{PL(P_U, 6 * s), PL(P_U, 6 * s + 1), PL(P_U, 6 * s + 2)}, Ul{PL(P_U, 6 * s + 3), PL(P_U, 6 * s + 4), PL(P_U, 6 * s + 5)};
+        const float qdd = (PL(P_UU, s) - dot(Ua, aa) - dot(Ul, al)) * PL(P_DINV, s);
         if (ax == 0) aa.x += qdd; else if (ax == 1) aa.y += qdd; else aa.z += qdd;
         caa = aa; cal = al;
         const float qdn = qd + h * qdd;
@@ -855,8 +863,8 @@ __global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M,
         const float d2 = dq * dq;
         const float sd = dq * (1.f + d2 * (-1.f / 6.f + d2 * (1.f / 120.f - d2 * (1.f / 5040.f))));
         const float cd = 1.f + d2 * (-0.5f + d2 * (1.f / 24.f - d2 * (1.f / 720.f)));
-        PL(P_SIN, i) = s0 * cd + c0 * sd;
-        PL(P_COS, i) = c0 * cd - s0 * sd;
+        SLOT(r_sin, P_SIN, s) = s0 * cd + c0 * sd;
+        SLOT(r_cos, P_COS, s) = c0 * cd - s0 * sd;
       }
     }
     // ---------------- root: semi-implicit Euler (all four lanes, identically)
@@ -899,6 +907,7 @@ __global__ __launch_bounds__(64) void rigid_step4_kernel(addhip_rigid_model_t M,
 #undef SV
 #undef TG
 #undef PL
+#undef SLOT
 }
 
 
@@ -974,14 +983,22 @@ extern "C" int addhip_rigid_step(const addhip_rigid_model_t* m, float* sim_pose,
   ADDHIP_REQUIRE(m->num_points >= 0 && m->num_points <= MAXP, "rigid_step: at most %d collision points", MAXP);
   ADDHIP_REQUIRE(m->substeps >= 1 && m->substeps <= 64 && m->dt > 0.f, "rigid_step: bad dt / substeps");
   if (m->chains) {  // four lanes per environment
+    // two waves per CU (the all-LDS form) serve up to 2 x 16 envs per CU; beyond that the register form runs four
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const bool regs = num_envs > 2 * L4_ENVS * cus;
     static bool attr4_set = false;
-    const size_t shmem4 = sizeof(float) * L4_LDS_FLOATS;
     if (!attr4_set) {
-      ADDHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem4));
+      ADDHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(sizeof(float) * l4_lds_floats(MAXP, false))));
+      ADDHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(sizeof(float) * l4_lds_floats(MAXP, true))));
       attr4_set = true;
     }
-    hipLaunchKernelGGL(rigid_step4_kernel, dim3((num_envs + L4_ENVS - 1) / L4_ENVS), dim3(64), shmem4, (hipStream_t)stream, *m, sim_pose, sim_vel, target,
-                       target_stride, num_envs, contact_flag, contact_bits);
+    const size_t shmem4 = sizeof(float) * l4_lds_floats(m->num_points, regs);  // G1 (301 points): 69 KB / 38.7 KB
+    const dim3 grid4((num_envs + L4_ENVS - 1) / L4_ENVS);
+    if (regs) hipLaunchKernelGGL(rigid_step4_kernel<true>, grid4, dim3(64), shmem4, (hipStream_t)stream, *m, sim_pose, sim_vel, target, target_stride, num_envs, contact_flag, contact_bits);
+    else hipLaunchKernelGGL(rigid_step4_kernel<false>, grid4, dim3(64), shmem4, (hipStream_t)stream, *m, sim_pose, sim_vel, target, target_stride, num_envs, contact_flag, contact_bits);
     return addhip::check_launch("rigid_step4_kernel");
   }
   static bool attr_set = false;

@@ -89,6 +89,41 @@ def test_one_control_step_matches_the_float64_oracle(case, lanes):
     assert np.array_equal(c["valid_mask"].cpu().numpy(), ((bits[:, None] >> np.arange(m.nb)) & 1).astype(bool))
 
 
+@pytest.mark.parametrize("case", ["contact", "flight"])
+def test_register_form_of_the_four_lane_kernel_matches_the_float64_oracle(case):
+    """Launches of more than two waves per CU take the form of the four-lane kernel that keeps the per-body pass state in step-indexed
+    VGPR arrays (38 KB of LDS per workgroup: four waves per CU).  The 70 oracle states, tiled over enough envs to select it: the first 70
+    against the float64 oracle at the usual tolerance, every replica bit-identical to its original (a ragged last workgroup included)."""
+    import torch
+
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    reps = (2 * 16 * cus) // 70 + 2
+    n = 70 * reps - 3
+    eng, scene, plane, ent, m, kp, kv = make_entity(n, lanes_per_env=4)
+    assert n > 2 * 16 * cus
+    rng = np.random.RandomState(3 if case == "contact" else 4)
+    st = rand_states(rng, 70, 0.25, 0.85) if case == "contact" else rand_states(rng, 70, 2.0, 3.0)
+    pose, vel = (a.astype(F) for a in st.packed())
+    tgt = rng.uniform(-0.5, 0.5, (70, 29)).astype(F)
+    tile = lambda a: torch.tensor(np.tile(a, (reps, 1))[:n], device="cuda")
+    ent.pose.copy_(tile(pose))
+    ent.vel.copy_(tile(vel))
+    ent.control_dofs_position(tile(tgt))
+    scene.step()
+    torch.cuda.synchronize()
+    got = get(ent)
+    st64 = RB.State.from_packed(pose.astype(np.float64), vel.astype(np.float64))
+    want, touch = RB.step(m, RB.RigidParams(), kp, kv, st64, tgt.astype(np.float64))
+    for name in ("root_pos", "root_quat", "q", "root_vel", "root_ang", "qd"):
+        a, b = getattr(got, name)[:70], getattr(want, name)
+        scale = max(1.0, np.abs(b).max())
+        assert np.abs(a - b).max() <= 1e-5 * scale * (10 if case == "contact" else 1), (name, float(np.abs(a - b).max()), float(scale))
+    P, V, Bt = ent.pose.cpu().numpy(), ent.vel.cpu().numpy(), ent.contact_bits.cpu().numpy()
+    for r in range(1, reps):
+        k = min(70, n - 70 * r)
+        assert np.array_equal(P[70 * r:70 * r + k], P[:k]) and np.array_equal(V[70 * r:70 * r + k], V[:k]) and np.array_equal(Bt[70 * r:70 * r + k], Bt[:k]), r
+
+
 def test_free_flight_follows_the_centre_of_mass_and_keeps_momentum():
     import torch
 
