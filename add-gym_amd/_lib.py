@@ -86,6 +86,54 @@ class OptimizerT(C.Structure):
                 ("zero_grad", C.c_int32)]
 
 
+class SectionT(C.Structure):
+    _fields_ = [("stream", C.c_int32), ("first", C.c_int32), ("last", C.c_int32), ("wait_before", C.c_int32), ("wait_after", C.c_int32), ("bucket", C.c_int32)]
+
+
+MLP_MAX_HIDDEN = 4
+_H = MLP_MAX_HIDDEN
+
+
+class MlpT(C.Structure):
+    _fields_ = [("num_hidden", C.c_int32), ("in_dim", C.c_int32), ("in_ld", C.c_int32), ("hidden", C.c_int32 * _H), ("head_rows", C.c_int32), ("precision", C.c_int32),
+                ("W", f32p * _H), ("b", f32p * _H), ("Wh", f32p), ("bh", f32p), ("gW", f32p * _H), ("gb", f32p * _H), ("gWh", f32p), ("gbh", f32p),
+                ("W16", f32p * _H), ("W16t", f32p * _H), ("rows_cap", C.c_int32), ("h", f32p * _H), ("dz", f32p * _H), ("hbits", f32p * _H), ("h16", f32p * _H),
+                ("dz16", f32p * _H), ("slabs", f32p), ("slab_floats", C.c_int64), ("slabs_top", f32p), ("flat_params", f32p), ("flat_trans16", f32p),
+                ("flat_count", C.c_int64), ("t_offset", C.POINTER(C.c_int64)), ("t_rows", C.POINTER(C.c_int32)), ("t_cols", C.POINTER(C.c_int32)), ("t_count", C.c_int32)]
+
+
+class ExtraDwT(C.Structure):
+    _fields_ = [("A", f32p), ("lda", C.c_int32), ("B", f32p), ("ldb", C.c_int32), ("rows", C.c_int64)]
+
+
+class MlpMarksT(C.Structure):
+    _fields_ = [("launches", C.c_int32), ("early", C.c_int32), ("dw_first", C.c_int32 * _H), ("dw_last", C.c_int32 * _H)]
+
+
+class PpoLossT(C.Structure):
+    _fields_ = [("actor", C.POINTER(MlpT)), ("critic", C.POINTER(MlpT)), ("rows", C.c_int32), ("norm_obs", f32p), ("norm_obs16", f32p), ("norm_action", f32p),
+                ("old_logp", f32p), ("adv", f32p), ("tar_val", f32p), ("rand_mask", f32p), ("action_std", C.c_float), ("logp_const", C.c_float),
+                ("ppo_clip_ratio", C.c_float), ("action_bound_weight", C.c_float), ("action_reg_weight", C.c_float), ("critic_loss_weight", C.c_float),
+                ("grad_scale", C.c_float), ("head_precision", C.c_int32), ("mean", f32p), ("d_mean", f32p), ("dv", f32p), ("num_valid", f32p), ("stats", f32p)]
+
+
+class PpoMarksT(C.Structure):
+    _fields_ = [("launches", C.c_int32), ("actor_end", C.c_int32), ("actor_early", C.c_int32), ("critic_early", C.c_int32)]
+
+
+class DiscLossT(C.Structure):
+    _fields_ = [("disc", C.POINTER(MlpT)), ("rows", C.c_int32), ("disc_dim", C.c_int32), ("norm_diff", f32p), ("norm_diff16", f32p), ("loss_scale", C.c_float),
+                ("logit_reg", C.c_float), ("grad_penalty", C.c_float), ("weight_decay", C.c_float), ("dlogit", f32p), ("a2", f32p), ("a1", f32p), ("g", f32p),
+                ("G", f32p), ("e1", f32p), ("da2", f32p), ("a2_16", f32p), ("a1_16", f32p), ("G16", f32p), ("e1_16", f32p), ("stats", f32p)]
+
+
+class DiscMarksT(C.Structure):
+    _fields_ = [("launches", C.c_int32), ("head", C.c_int32), ("chain", C.c_int32), ("backward", C.c_int32), ("top_dw_first", C.c_int32), ("top_dw_last", C.c_int32)]
+
+
+BWD_GRADS_ZEROED, BWD_TOP_BIAS_DONE, BWD_ACCUMULATE_DW, BWD_TOP_CAST_DONE, BWD_SIGN_BITS = 1, 2, 4, 8, 16
+BUCKET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_void_p)  # addhip_bucket_fn(user, bucket, stream)
+MAX_STREAMS = 8
 OPT_ADAMW, OPT_SGD = 0, 1
 RIGID_BODY_W, RIGID_TOPO_W = 32, 8
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
@@ -141,6 +189,24 @@ SIGNATURES = {
     "addhip_sgd": [vp, vp, vp, i64, f32, f32, f32, i32, vp],
     "addhip_optimizer_step": [P(OptimizerT), vp],
     "addhip_return_tracker_fold": [vp, i32, vp, vp],
+    # recorded plans / schedules (host-side runtime; handles are opaque pointers)
+    "addhip_plan_create": [P(vp)],
+    "addhip_plan_destroy": [vp],
+    "addhip_plan_record_begin": [vp],
+    "addhip_plan_record_end": [vp],
+    "addhip_plan_size": [vp],                      # returns the number of calls
+    "addhip_plan_call_name": [vp, i32],            # returns const char*
+    "addhip_plan_call_gemms": [vp, i32, P(GemmT), i32],  # returns the number of descriptors
+    "addhip_plan_run": [vp, i32, i32, vp],
+    "addhip_schedule_create": [vp, P(SectionT), i32, i32, P(vp)],
+    "addhip_schedule_destroy": [vp],
+    "addhip_schedule_run": [vp, P(vp), BUCKET_FN, vp],
+    # composite entry points (the library assembles the launches)
+    "addhip_mlp_forward": [P(MlpT), vp, vp, i64, vp, vp, i32, vp],
+    "addhip_mlp_backward": [P(MlpT), vp, vp, i64, P(ExtraDwT), i32, P(MlpMarksT), vp],
+    "addhip_ppo_loss_fwd_bwd": [P(PpoLossT), P(PpoMarksT), vp],
+    "addhip_disc_loss_fwd_bwd": [P(DiscLossT), P(DiscMarksT), vp],
+    "addhip_update_schedule": [i32, P(PpoMarksT), P(DiscMarksT), P(SectionT), i32],   # returns the number of sections
 }
 
 _lib = None
@@ -162,7 +228,8 @@ def load():
     lib.addhip_last_error.restype = C.c_char_p
     lib.addhip_version.restype = C.c_int
     lib.addhip_abi_sizes.argtypes, lib.addhip_abi_sizes.restype = [C.POINTER(C.c_int32), C.c_int32], C.c_int
-    structs = (MotionT, TaskT, EnvT, StepOutT, SamplerT, GemmT, GatherT, RigidModelT, RigidDrT, OptimizerT)
+    structs = (MotionT, TaskT, EnvT, StepOutT, SamplerT, GemmT, GatherT, RigidModelT, RigidDrT, OptimizerT, SectionT, MlpT, ExtraDwT, MlpMarksT, PpoLossT,
+               PpoMarksT, DiscLossT, DiscMarksT)
     sizes = (C.c_int32 * len(structs))()
     mine = [C.sizeof(t) for t in structs]
     if lib.addhip_abi_sizes(sizes, len(structs)) != len(structs) or list(sizes) != mine:
@@ -171,6 +238,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.addhip_plan_call_name.restype = C.c_char_p
     _lib = lib
     return lib
 

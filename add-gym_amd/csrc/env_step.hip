@@ -13,6 +13,7 @@
 //
 // Reference functions restated here: see include/addhip.h at each entry point.
 #include "common.h"
+#include "record.h"
 #include "quat.h"
 
 using namespace addhip;
@@ -695,6 +696,7 @@ inline int env_grid(int num_envs) {
 
 extern "C" int addhip_env_step(const addhip_motion_t* m, const addhip_task_t* t, const addhip_env_t* e,
                                const addhip_step_out_t* o, int32_t head, void* stream) {
+  ADDHIP_RECORDABLE(addhip_env_step, m, t, e, o, head);
   if (int rc = check_common(m, t, e)) return rc;
   ADDHIP_REQUIRE(o, "null outputs");
   ADDHIP_REQUIRE(!o->obs_timeout || o->obs, "obs_timeout needs obs");
@@ -729,6 +731,7 @@ extern "C" int addhip_env_reset(const addhip_motion_t* m, const addhip_task_t* t
                                 const addhip_sampler_t* s, const float* u_clip, const float* u_seg, const float* u_jit,
                                 float* obs_out, float* disc_obs_out, float* disc_demo_out, int32_t reset_all, int32_t head,
                                 void* stream) {
+  ADDHIP_RECORDABLE(addhip_env_reset, m, t, e, s, u_clip, u_seg, u_jit, obs_out, disc_obs_out, disc_demo_out, reset_all, head);
   if (int rc = check_common(m, t, e)) return rc;
   ADDHIP_REQUIRE(s && s->errors && s->seg_size && s->clip_cdf && s->temp_bits, "sampler pointers missing");
   ADDHIP_REQUIRE(s->num_segments > 0 && s->num_segments <= 64, "num_segments must be in 1..64");
@@ -761,6 +764,7 @@ extern "C" int addhip_env_reset(const addhip_motion_t* m, const addhip_task_t* t
 extern "C" int addhip_motion_lookup(const addhip_motion_t* m, const int32_t* ids, const float* times, int32_t count,
                                     int32_t* idx_out, float* pose_out, float* vel_out, void* stream) {
   ADDHIP_REQUIRE(m && ids && times && count > 0, "bad lookup arguments");
+  ADDHIP_RECORDABLE(addhip_motion_lookup, m, ids, times, count, idx_out, pose_out, vel_out);
   hipLaunchKernelGGL(lookup_kernel, dim3((count + 3) / 4), dim3(256), 0, (hipStream_t)stream, *m, ids, times, count, idx_out, pose_out, vel_out);
   return check_launch("lookup_kernel");
 }
@@ -768,6 +772,7 @@ extern "C" int addhip_motion_lookup(const addhip_motion_t* m, const int32_t* ids
 extern "C" int addhip_kin_engine_step(float* sim_pose, float* sim_vel, const float* target, int32_t target_stride, int32_t num_envs,
                                       float lag, float dt, void* stream) {
   ADDHIP_REQUIRE(sim_pose && sim_vel && target && num_envs > 0 && target_stride >= ADDHIP_NUM_DOF, "bad engine-step arguments");
+  ADDHIP_RECORDABLE(addhip_kin_engine_step, sim_pose, sim_vel, target, target_stride, num_envs, lag, dt);
   const int n = num_envs * ADDHIP_NUM_DOF;
   hipLaunchKernelGGL(kin_engine_step_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sim_pose, sim_vel, target,
                      target_stride, num_envs, lag, dt);

@@ -15,6 +15,7 @@
 // Replaces: torch.nn.Linear forward/backward inside PPOModel.eval_actor/eval_critic
 // (ppo_model.py:13-21), ADDModel.eval_disc (add_model.py:12-15) and their autograd.
 #include "common.h"
+#include "record.h"
 #include "gemm_epilogue.h"
 #include "gemm_dma.h"
 
@@ -453,6 +454,8 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   ADDHIP_REQUIRE(gp, "null gemm descriptor");
   addhip_gemm_t g = *gp;
   if (int rc = validate(g)) return rc;
+  if (addhip::recording())  // (record.h: the descriptor is kept by value, and kept visible to addhip_plan_call_gemms)
+    return addhip::record_push("addhip_gemm_f32", [g](void* s) -> int { return addhip_gemm_f32(&g, s); }, &g, 1);
   hipStream_t st = (hipStream_t)stream;
   if (g.operands_bf16) {
     addhip_dma::GemmGroup grp;
@@ -474,6 +477,8 @@ extern "C" int addhip_gemm_grouped(const addhip_gemm_t* problems, int32_t count,
                        (a.a_mean != nullptr) == (b.a_mean != nullptr) && a.hint == b.hint,
                    "gemm_grouped: problem %d differs from problem 0 in shape, layout, epilogue, split, precision or storage", i);
   }
+  if (addhip::recording())
+    return addhip::record_push("addhip_gemm_grouped", [grp, count](void* s) -> int { return addhip_gemm_grouped(grp.g, count, s); }, grp.g, count);
   hipStream_t st = (hipStream_t)stream;
   const addhip_gemm_t& g = grp.g[0];
   if (count > 1) {
@@ -496,6 +501,7 @@ extern "C" int addhip_gemm_grouped(const addhip_gemm_t* problems, int32_t count,
 extern "C" int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count, float scale,
                                   int32_t accumulate, void* stream) {
   ADDHIP_REQUIRE(in && out && slabs > 0 && count > 0, "slab_reduce: bad arguments");
+  ADDHIP_RECORDABLE(addhip_slab_reduce, in, slabs, slab_stride, out, count, scale, accumulate);
   if (count % 4 == 0 && slab_stride % 4 == 0 && aligned16(in) && aligned16(out)) {
     long long b4 = (count / 4 + 255) / 256;
     if (b4 > 2048) b4 = 2048;
@@ -512,12 +518,14 @@ extern "C" int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_s
 
 extern "C" int addhip_fill_zero(float* p, int64_t count, void* stream) {
   ADDHIP_REQUIRE(p && count > 0, "fill_zero: bad arguments");
+  ADDHIP_RECORDABLE(addhip_fill_zero, p, count);
   ADDHIP_HIP(hipMemsetAsync(p, 0, sizeof(float) * (size_t)count, (hipStream_t)stream));
   return 0;
 }
 
 extern "C" int addhip_col_sum(const float* X, int32_t M, int32_t N, int32_t ld, float* out, float scale, int32_t accumulate, void* stream) {
   ADDHIP_REQUIRE(X && out && M > 0 && N > 0 && ld >= N, "col_sum: bad arguments");
+  ADDHIP_RECORDABLE(addhip_col_sum, X, M, N, ld, out, scale, accumulate);
   hipStream_t st = (hipStream_t)stream;
   if (!accumulate) ADDHIP_HIP(hipMemsetAsync(out, 0, sizeof(float) * N, st));
   int strips = (N + 63) / 64;

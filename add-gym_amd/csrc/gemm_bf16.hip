@@ -10,6 +10,7 @@
 //
 // Replaces (in bf16 mode): the torch.nn.Linear forward/backward of PPOModel / ADDModel (ppo_model.py:13-21, add_model.py:12-15).
 #include "common.h"
+#include "record.h"
 #include "gemm_epilogue.h"
 #include "gemm_dma.h"
 
@@ -319,6 +320,7 @@ extern "C" int addhip_to_bf16(const float* src, uint16_t* dst, int64_t rows, int
   ADDHIP_REQUIRE(src && dst && rows > 0 && cols > 0 && cols % 4 == 0 && ld_src >= cols && ld_dst >= cols && ld_src % 4 == 0 && ld_dst % 4 == 0,
                  "to_bf16: bad arguments (cols and row strides must be multiples of 4)");
   ADDHIP_REQUIRE(aligned16(src) && (reinterpret_cast<uintptr_t>(dst) & 7u) == 0, "to_bf16: misaligned buffers");
+  ADDHIP_RECORDABLE(addhip_to_bf16, src, dst, rows, cols, ld_src, ld_dst);
   const long long n = (long long)rows * (cols / 4);
   long long blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -328,6 +330,7 @@ extern "C" int addhip_to_bf16(const float* src, uint16_t* dst, int64_t rows, int
 
 extern "C" int addhip_to_bf16_t(const float* src, uint16_t* dst, int32_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream) {
   ADDHIP_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "to_bf16_t: bad arguments");
+  ADDHIP_RECORDABLE(addhip_to_bf16_t, src, dst, rows, cols, ld_src, ld_dst);
   hipLaunchKernelGGL(to_bf16_t_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, ld_src, ld_dst);
   return addhip::check_launch("to_bf16_t_kernel");
 }
@@ -349,6 +352,13 @@ extern "C" int addhip_shadow_refresh(const float* params, uint16_t* flat16, uint
     mats.cols[i] = on ? cols[i] : 0;
     if (on) tiles += ((rows[i] + 31) / 32) * ((cols[i] + 31) / 32);
     mats.tile_end[i] = tiles;
+  }
+  if (addhip::recording()) {  // (record.h: the host-side matrix table is copied)
+    const std::vector<int64_t> o(offset, offset + n_mats);
+    const std::vector<int32_t> r(rows, rows + n_mats), c(cols, cols + n_mats);
+    return addhip::record_push(
+        "addhip_shadow_refresh",
+        [=](void* s) -> int { return addhip_shadow_refresh(params, flat16, trans16, count, o.data(), r.data(), c.data(), n_mats, s); }, nullptr, 0);
   }
   long long fb = (count / 4 + 255) / 256;
   const int flat_blocks = flat16 ? (int)(fb < 1 ? 1 : fb > 2048 ? 2048 : fb) : 0;  // flat16 == NULL: the transposed copies only

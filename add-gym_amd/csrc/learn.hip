@@ -4,6 +4,7 @@
 // one wavefront per row with 64-lane shuffle reductions, or one thread per element, coalesced.
 // Reference functions restated: see include/addhip.h at each entry point.
 #include "common.h"
+#include "record.h"
 #include "philox.h"
 
 namespace {
@@ -683,23 +684,27 @@ __global__ void return_tracker_fold_kernel(const float* ep, int T, float* state)
 
 extern "C" int addhip_fill_normal(float* out, int64_t count, uint64_t seed, uint64_t stream_id, void* stream) {
   ADDHIP_REQUIRE(out && count > 0, "fill_normal: bad arguments");
+  ADDHIP_RECORDABLE(addhip_fill_normal, out, count, seed, stream_id);
   hipLaunchKernelGGL(fill_normal_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id,
                      (const uint64_t*)nullptr);
   return addhip::check_launch("fill_normal_kernel");
 }
 extern "C" int addhip_fill_normal_at(float* out, int64_t count, uint64_t seed, uint64_t stream_id, const uint64_t* stream_base, void* stream) {
   ADDHIP_REQUIRE(out && count > 0 && stream_base, "fill_normal_at: bad arguments");
+  ADDHIP_RECORDABLE(addhip_fill_normal_at, out, count, seed, stream_id, stream_base);
   hipLaunchKernelGGL(fill_normal_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id, stream_base);
   return addhip::check_launch("fill_normal_kernel");
 }
 extern "C" int addhip_fill_uniform(float* out, int64_t count, uint64_t seed, uint64_t stream_id, void* stream) {
   ADDHIP_REQUIRE(out && count > 0, "fill_uniform: bad arguments");
+  ADDHIP_RECORDABLE(addhip_fill_uniform, out, count, seed, stream_id);
   hipLaunchKernelGGL(fill_uniform_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id,
                      (const uint64_t*)nullptr);
   return addhip::check_launch("fill_uniform_kernel");
 }
 extern "C" int addhip_fill_uniform_at(float* out, int64_t count, uint64_t seed, uint64_t stream_id, const uint64_t* stream_base, void* stream) {
   ADDHIP_REQUIRE(out && count > 0 && stream_base, "fill_uniform_at: bad arguments");
+  ADDHIP_RECORDABLE(addhip_fill_uniform_at, out, count, seed, stream_id, stream_base);
   hipLaunchKernelGGL(fill_uniform_kernel, dim3(elem_grid((count + 3) / 4)), dim3(256), 0, ST, out, (long long)count, seed, stream_id, stream_base);
   return addhip::check_launch("fill_uniform_kernel");
 }
@@ -709,6 +714,7 @@ extern "C" int addhip_actor_sample(const float* mean, int32_t ld_mean, const flo
                                    float* a_logp, float* rand_mask, void* stream) {
   ADDHIP_REQUIRE(mean && a_mean && a_std && action && a_logp && rand_mask && num_envs > 0, "actor_sample: bad arguments");
   ADDHIP_REQUIRE(deterministic || noise, "actor_sample: noise missing");
+  ADDHIP_RECORDABLE(addhip_actor_sample, mean, ld_mean, noise, stdv, logp_const, a_mean, a_std, num_envs, deterministic, explore_u, exp_prob, action, a_logp, rand_mask);
   hipLaunchKernelGGL(actor_sample_kernel, dim3(row_grid(num_envs)), dim3(256), 0, ST, mean, ld_mean, noise, stdv, logp_const, a_mean, a_std,
                      num_envs, deterministic, explore_u, exp_prob, action, a_logp, rand_mask);
   return addhip::check_launch("actor_sample_kernel");
@@ -718,6 +724,7 @@ extern "C" int addhip_disc_prep(const float* disc_obs, const float* disc_demo, i
                                  float min_diff, float* norm_diff, const int32_t* motion_id, const float* motion_time, const addhip_sampler_t* s,
                                  int32_t num_clips, float* abs_sum, void* stream) {
   ADDHIP_REQUIRE(disc_obs && disc_demo && mean_abs && rows > 0 && dim <= stride && stride <= 256, "disc_prep: bad arguments (stride <= 256)");
+  ADDHIP_RECORDABLE(addhip_disc_prep, disc_obs, disc_demo, stride, dim, rows, mean_abs, min_diff, norm_diff, motion_id, motion_time, s, num_clips, abs_sum);
   addhip_sampler_t ss;
   memset(&ss, 0, sizeof(ss));
   int cells = 0;
@@ -735,6 +742,7 @@ extern "C" int addhip_disc_prep(const float* disc_obs, const float* disc_demo, i
 
 extern "C" int addhip_sampler_update(const addhip_sampler_t* s, int32_t num_clips, void* stream) {
   ADDHIP_REQUIRE(s && s->errors && s->err_sum && s->err_cnt && num_clips > 0, "sampler_update: bad arguments");
+  ADDHIP_RECORDABLE(addhip_sampler_update, s, num_clips);
   int cells = num_clips * s->num_segments;
   hipLaunchKernelGGL(sampler_update_kernel, dim3((cells + 255) / 256), dim3(256), 0, ST, *s, cells);
   return addhip::check_launch("sampler_update_kernel");
@@ -743,6 +751,7 @@ extern "C" int addhip_sampler_update(const addhip_sampler_t* s, int32_t num_clip
 extern "C" int addhip_disc_reward(const float* logits, float* reward_inout, int64_t count, float scale, float task_w, float disc_w, float* stats,
                                   void* stream) {
   ADDHIP_REQUIRE(logits && reward_inout && count > 0, "disc_reward: bad arguments");
+  ADDHIP_RECORDABLE(addhip_disc_reward, logits, reward_inout, count, scale, task_w, disc_w, stats);
   hipLaunchKernelGGL(disc_reward_kernel, dim3(elem_grid(count) < 1024 ? elem_grid(count) : 1024), dim3(256), 0, ST, logits, reward_inout,
                      (long long)count, scale, task_w, disc_w, stats);
   return addhip::check_launch("disc_reward_kernel");
@@ -750,6 +759,7 @@ extern "C" int addhip_disc_reward(const float* logits, float* reward_inout, int6
 
 extern "C" int addhip_head_gemv(const float* H, int32_t ld, int32_t K, int64_t rows, const float* w, const float* b, float* out, void* stream) {
   ADDHIP_REQUIRE(H && w && b && out && rows > 0 && K % 4 == 0 && ld % 4 == 0, "head_gemv: bad arguments");
+  ADDHIP_RECORDABLE(addhip_head_gemv, H, ld, K, rows, w, b, out);
   hipLaunchKernelGGL(head_gemv_kernel, dim3(row_grid(rows)), dim3(256), 0, ST, H, ld, K, (long long)rows, w, b, out);
   return addhip::check_launch("head_gemv_kernel");
 }
@@ -760,6 +770,7 @@ extern "C" int addhip_td_lambda_adv(const float* reward, const float* next_vals,
   ADDHIP_REQUIRE(reward && next_vals && vals && done && rand_mask && tar_val && adv && scratch && stats_out && T > 0 && N > 0,
                  "td_lambda_adv: bad arguments");
   ADDHIP_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7u) == 0, "td_lambda_adv: scratch must be 8-byte aligned");
+  ADDHIP_RECORDABLE(addhip_td_lambda_adv, reward, next_vals, timeout_vals, vals, done, rand_mask, T, N, discount, td_lambda, succ_val, fail_val, adv_clip, tar_val, adv, scratch, stats_out);
   int blocks = (N + 255) / 256;
   ADDHIP_REQUIRE(blocks <= 1024, "td_lambda_adv: at most 262144 envs per rank");
   double* partial = reinterpret_cast<double*>(scratch);
@@ -774,6 +785,7 @@ extern "C" int addhip_td_lambda_adv(const float* reward, const float* next_vals,
 
 extern "C" int addhip_norm_accum(const float* X, int64_t rows, int32_t dim, int32_t ld, float* sum, float* sumsq, void* stream) {
   ADDHIP_REQUIRE(X && sum && rows > 0 && dim > 0 && ld >= dim, "norm_accum: bad arguments");
+  ADDHIP_RECORDABLE(addhip_norm_accum, X, rows, dim, ld, sum, sumsq);
   int strips = (dim + 63) / 64;
   int ysplit = 1;
   while (strips * ysplit < 512 && rows / (ysplit * 2) >= 64) ysplit *= 2;
@@ -785,6 +797,7 @@ extern "C" int addhip_norm_accum(const float* X, int64_t rows, int32_t dim, int3
 extern "C" int addhip_norm_merge(float* mean, float* stdv, float* mean_sq, int64_t* count, float* sum, float* sumsq, int64_t new_count, int32_t dim,
                                  float min_var, int32_t first, void* stream) {
   ADDHIP_REQUIRE(mean && stdv && mean_sq && count && sum && sumsq && dim > 0 && dim <= 1024, "norm_merge: bad arguments (dim <= 1024)");
+  ADDHIP_RECORDABLE(addhip_norm_merge, mean, stdv, mean_sq, count, sum, sumsq, new_count, dim, min_var, first);
   hipLaunchKernelGGL(norm_merge_kernel, dim3(1), dim3(1024), 0, ST, mean, stdv, mean_sq, (long long*)count, sum, sumsq, (long long)new_count, dim,
                      min_var, first);
   return addhip::check_launch("norm_merge_kernel");
@@ -792,6 +805,7 @@ extern "C" int addhip_norm_merge(float* mean, float* stdv, float* mean_sq, int64
 
 extern "C" int addhip_diffnorm_merge(float* mean_abs, int64_t* count, float* abs_sum, int64_t new_count, int32_t dim, void* stream) {
   ADDHIP_REQUIRE(mean_abs && count && abs_sum && new_count > 0 && dim > 0 && dim <= 1024, "diffnorm_merge: bad arguments");
+  ADDHIP_RECORDABLE(addhip_diffnorm_merge, mean_abs, count, abs_sum, new_count, dim);
   hipLaunchKernelGGL(diffnorm_merge_kernel, dim3(1), dim3(1024), 0, ST, mean_abs, (long long*)count, abs_sum, (long long)new_count, dim);
   return addhip::check_launch("diffnorm_merge_kernel");
 }
@@ -801,12 +815,14 @@ extern "C" int addhip_gather_minibatch(const addhip_gather_t* g, void* stream) {
   ADDHIP_REQUIRE(g->obs && g->obs_mean && g->obs_std && g->action && g->a_mean && g->a_std && g->a_logp && g->adv && g->tar_val && g->rand_mask &&
                      g->disc_obs && g->disc_demo && g->mean_abs, "gather: source pointers missing");
   ADDHIP_REQUIRE(g->norm_obs && g->norm_action && g->o_logp && g->o_adv && g->o_tar_val && g->o_mask && g->norm_diff, "gather: output pointers missing");
+  ADDHIP_RECORDABLE(addhip_gather_minibatch, g);
   hipLaunchKernelGGL(gather_kernel, dim3(row_grid(g->count)), dim3(256), 0, ST, *g);
   return addhip::check_launch("gather_kernel");
 }
 
 extern "C" int addhip_count_mask(const float* rand_mask, int32_t M, float* out, void* stream) {
   ADDHIP_REQUIRE(rand_mask && out && M > 0, "count_mask: bad arguments");
+  ADDHIP_RECORDABLE(addhip_count_mask, rand_mask, M, out);
   ADDHIP_HIP(hipMemsetAsync(out, 0, sizeof(float), ST));
   hipLaunchKernelGGL(count_mask_kernel, dim3(elem_grid(M) < 64 ? elem_grid(M) : 64), dim3(256), 0, ST, rand_mask, M, out);
   return addhip::check_launch("count_mask_kernel");
@@ -816,6 +832,7 @@ extern "C" int addhip_actor_loss(const float* mean, const float* norm_action, co
                                  float stdv, float logp_const, float clip_ratio, float bound_weight, float reg_weight, float loss_scale,
                                  const float* n_valid, float* d_mean, float* stats, void* stream) {
   ADDHIP_REQUIRE(mean && norm_action && old_logp && adv && rand_mask && n_valid && d_mean && stats && M > 0, "actor_loss: bad arguments");
+  ADDHIP_RECORDABLE(addhip_actor_loss, mean, norm_action, old_logp, adv, rand_mask, M, stdv, logp_const, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, stats);
   hipLaunchKernelGGL(actor_loss_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, mean, norm_action, old_logp, adv, rand_mask, M,
                      stdv, logp_const, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, stats);
   return addhip::check_launch("actor_loss_kernel");
@@ -824,6 +841,7 @@ extern "C" int addhip_actor_loss(const float* mean, const float* norm_action, co
 extern "C" int addhip_critic_head(const float* H, int32_t ld, int32_t K, int32_t M, const float* w, const float* b, const float* tar, float loss_scale,
                                   float* dZ, float* dv_out, float* stats, void* stream) {
   ADDHIP_REQUIRE(H && w && b && tar && dv_out && stats && M > 0 && K % 4 == 0 && ld % 4 == 0, "critic_head: bad arguments");
+  ADDHIP_RECORDABLE(addhip_critic_head, H, ld, K, M, w, b, tar, loss_scale, dZ, dv_out, stats);
   hipLaunchKernelGGL(critic_head_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, H, ld, K, M, w, b, tar, loss_scale, dZ,
                      dv_out, stats);
   return addhip::check_launch("critic_head_kernel");
@@ -832,6 +850,7 @@ extern "C" int addhip_critic_head(const float* H, int32_t ld, int32_t K, int32_t
 extern "C" int addhip_disc_head(const float* H, int32_t ld, int32_t K, int32_t M, const float* h_pos, const float* w, const float* b, float loss_scale,
                                 float* dlogit, float* dlogit_pos, float* stats, void* stream) {
   ADDHIP_REQUIRE(H && h_pos && w && b && dlogit && dlogit_pos && stats && M > 0 && K % 4 == 0 && ld % 4 == 0, "disc_head: bad arguments");
+  ADDHIP_RECORDABLE(addhip_disc_head, H, ld, K, M, h_pos, w, b, loss_scale, dlogit, dlogit_pos, stats);
   hipLaunchKernelGGL(disc_head_kernel, dim3(row_grid(M + 1) < 256 ? row_grid(M + 1) : 256), dim3(256), 0, ST, H, ld, K, M, h_pos, w, b, loss_scale,
                      dlogit, dlogit_pos, stats);
   return addhip::check_launch("disc_head_kernel");
@@ -839,11 +858,13 @@ extern "C" int addhip_disc_head(const float* H, int32_t ld, int32_t K, int32_t M
 
 extern "C" int addhip_outer_mask(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, void* stream) {
   ADDHIP_REQUIRE(v && w && H && out && rows > 0 && K % 4 == 0 && ld % 4 == 0, "outer_mask: bad arguments");
+  ADDHIP_RECORDABLE(addhip_outer_mask, v, w, H, ld, K, rows, out);
   hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, out, (unsigned short*)nullptr);
   return addhip::check_launch("outer_mask_kernel");
 }
 extern "C" int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, uint16_t* out16, void* stream) {
   ADDHIP_REQUIRE(w && H && (out || out16) && rows > 0 && K % 4 == 0 && ld % 4 == 0, "bcast_mask: bad arguments");
+  ADDHIP_RECORDABLE(addhip_bcast_mask, w, H, ld, K, rows, out, out16);
   hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, (const float*)nullptr, w, H, ld, K, (long long)rows, out, out16);
   return addhip::check_launch("outer_mask_kernel(bcast)");
 }
@@ -851,6 +872,7 @@ extern "C" int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int
 extern "C" int addhip_head_backward(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* dZ, uint16_t* dZ16,
                                     float* dW_head, float* db_head, float* db_top, void* stream) {
   ADDHIP_REQUIRE(v && w && H && rows > 0 && K > 0 && K <= 1024 && K % 4 == 0 && ld % 4 == 0 && ld >= K, "head_backward: bad arguments (K <= 1024)");
+  ADDHIP_RECORDABLE(addhip_head_backward, v, w, H, ld, K, rows, dZ, dZ16, dW_head, db_head, db_top);
   const int grid = row_grid(rows) < 256 ? row_grid(rows) : 256;
   hipLaunchKernelGGL(head_backward_kernel, dim3(grid), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, dZ, dZ16, dW_head, db_head, db_top);
   return addhip::check_launch("head_backward_kernel");
@@ -858,6 +880,7 @@ extern "C" int addhip_head_backward(const float* v, const float* w, const float*
 
 extern "C" int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, uint16_t* G16, float* stats, void* stream) {
   ADDHIP_REQUIRE(g && (G || G16) && stats && M > 0 && dim <= ld, "grad_penalty: bad arguments");
+  ADDHIP_RECORDABLE(addhip_grad_penalty, g, ld, dim, M, coef, G, G16, stats);
   hipLaunchKernelGGL(grad_penalty_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, g, ld, dim, M, coef, G, G16, stats);
   return addhip::check_launch("grad_penalty_kernel");
 }
@@ -865,6 +888,7 @@ extern "C" int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int3
 extern "C" int addhip_weighted_col_sum(const float* v, const float* X, int32_t ld, int32_t K, int64_t rows, float* out, float scale, int32_t accumulate,
                                        void* stream) {
   ADDHIP_REQUIRE(v && X && out && rows > 0 && K > 0 && ld >= K, "weighted_col_sum: bad arguments");
+  ADDHIP_RECORDABLE(addhip_weighted_col_sum, v, X, ld, K, rows, out, scale, accumulate);
   if (!accumulate) ADDHIP_HIP(hipMemsetAsync(out, 0, sizeof(float) * K, ST));
   int strips = (K + 63) / 64;
   int ysplit = 1;
@@ -876,6 +900,7 @@ extern "C" int addhip_weighted_col_sum(const float* v, const float* X, int32_t l
 
 extern "C" int addhip_l2_grad(const float* w, float* grad, int64_t count, float coef, float* sumsq_out, void* stream) {
   ADDHIP_REQUIRE(w && grad && count > 0, "l2_grad: bad arguments");
+  ADDHIP_RECORDABLE(addhip_l2_grad, w, grad, count, coef, sumsq_out);
   hipLaunchKernelGGL(l2_grad_kernel, dim3(elem_grid(count) < 512 ? elem_grid(count) : 512), dim3(256), 0, ST, w, grad, (long long)count, coef, sumsq_out);
   return addhip::check_launch("l2_grad_kernel");
 }
@@ -883,6 +908,7 @@ extern "C" int addhip_l2_grad(const float* w, float* grad, int64_t count, float 
 extern "C" int addhip_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr, float beta1, float beta2,
                             float eps, float weight_decay, int32_t step, void* stream) {
   ADDHIP_REQUIRE(param && grad && exp_avg && exp_avg_sq && count > 0 && step >= 1, "adamw: bad arguments");
+  ADDHIP_RECORDABLE(addhip_adamw, param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, weight_decay, step);
   // bias corrections in double like torch's python-scalar path (torch/optim/adamw.py single-tensor)
   double bc1 = 1.0 - pow((double)beta1, (double)step);
   double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -896,6 +922,7 @@ extern "C" int addhip_adamw(float* param, const float* grad, float* exp_avg, flo
 extern "C" int addhip_sgd(float* param, const float* grad, float* momentum_buf, int64_t count, float lr, float momentum, float weight_decay,
                           int32_t step, void* stream) {
   ADDHIP_REQUIRE(param && grad && momentum_buf && count > 0 && step >= 1, "sgd: bad arguments");
+  ADDHIP_RECORDABLE(addhip_sgd, param, grad, momentum_buf, count, lr, momentum, weight_decay, step);
   hipLaunchKernelGGL(sgd_kernel, dim3(elem_grid(count)), dim3(256), 0, ST, param, grad, momentum_buf, (long long)count, lr, momentum, weight_decay,
                      step == 1 ? 1 : 0);
   return addhip::check_launch("sgd_kernel");
@@ -903,6 +930,7 @@ extern "C" int addhip_sgd(float* param, const float* grad, float* momentum_buf, 
 
 extern "C" int addhip_optimizer_step(const addhip_optimizer_t* op, void* stream) {
   ADDHIP_REQUIRE(op, "optimizer_step: null descriptor");
+  ADDHIP_RECORDABLE(addhip_optimizer_step, op);
   const addhip_optimizer_t o = *op;
   ADDHIP_REQUIRE(o.type == ADDHIP_OPT_ADAMW || o.type == ADDHIP_OPT_SGD, "optimizer_step: type must be ADDHIP_OPT_ADAMW or ADDHIP_OPT_SGD");
   ADDHIP_REQUIRE(o.param && o.grad && o.state1 && (o.state2 || o.type == ADDHIP_OPT_SGD) && o.count > 0 && o.step >= 1, "optimizer_step: bad arguments");
@@ -922,6 +950,7 @@ extern "C" int addhip_optimizer_step(const addhip_optimizer_t* op, void* stream)
 extern "C" int addhip_grad_clip(float* grad, int64_t count, float max_norm, float* scratch, float* norm_out, void* stream) {
   ADDHIP_REQUIRE(grad && scratch && count > 0 && max_norm > 0.0f, "grad_clip: bad arguments");
   ADDHIP_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7u) == 0, "grad_clip: scratch must be 8-byte aligned");
+  ADDHIP_RECORDABLE(addhip_grad_clip, grad, count, max_norm, scratch, norm_out);
   double* sc = reinterpret_cast<double*>(scratch);
   ADDHIP_HIP(hipMemsetAsync(sc, 0, sizeof(double), ST));
   const int grid = elem_grid(count) < 1024 ? elem_grid(count) : 1024;
@@ -933,6 +962,7 @@ extern "C" int addhip_grad_clip(float* grad, int64_t count, float max_norm, floa
 
 extern "C" int addhip_return_tracker_fold(const float* ep_stats, int32_t T, float* state, void* stream) {
   ADDHIP_REQUIRE(ep_stats && state && T > 0, "return_tracker_fold: bad arguments");
+  ADDHIP_RECORDABLE(addhip_return_tracker_fold, ep_stats, T, state);
   hipLaunchKernelGGL(return_tracker_fold_kernel, dim3(1), dim3(64), 0, ST, ep_stats, T, state);
   return addhip::check_launch("return_tracker_fold_kernel");
 }

@@ -1,0 +1,377 @@
+// Composite entry points (include/addhip.h, "composite entry points"): the MLP passes and the loss sections of one optimiser step,
+// assembled from the library's own entry points.  Host code only -- every launch goes through an extern "C" function of this library, so a
+// call made while a plan is being recorded (record.h) records those launches instead.
+//
+// Restates the Sequential stacks of PPOModel / ADDModel (learning/ppo_model.py:13-59, learning/add/add_model.py:12-46: Linear + ReLU, linear
+// heads), PPOAgent._compute_actor_loss / _compute_critic_loss with their autograd backward (learning/ppo_agent.py:194-275,
+// base_agent.py:522-546) and ADDAgent._compute_disc_loss (learning/add/add_agent.py:141-202, amp_agent.py:177-192) as explicit launches.
+#include "common.h"
+
+namespace {
+
+addhip_gemm_t gemm(int M, int N, int K, const void* A, int lda, int akc, const void* B, int ldb, int bkc, float* C, int ldc, int epilogue = ADDHIP_EPI_NONE,
+                   const float* bias = nullptr) {
+  addhip_gemm_t g;
+  memset(&g, 0, sizeof(g));
+  g.M = M; g.N = N; g.K = K;
+  g.A = static_cast<const float*>(A); g.lda = lda; g.a_kcontig = akc;
+  g.B = static_cast<const float*>(B); g.ldb = ldb; g.b_kcontig = bkc;
+  g.C = C; g.ldc = ldc;
+  g.epilogue = epilogue;
+  g.bias = bias;
+  g.split_k = 1;
+  g.alpha = 1.0f;
+  g.precision = ADDHIP_PREC_F32;
+  return g;
+}
+
+// K slices of a weight-gradient GEMM dW[out, in] over `rows` rows: enough 128x128 tiles x slices to fill the chip, at least 256 rows a slice
+int split_k_for(int out_dim, int in_dim, int64_t rows) {
+  const int tiles = ((out_dim + 127) / 128) * ((in_dim + 127) / 128);
+  int s = (512 + tiles - 1) / tiles;
+  s = s < 1 ? 1 : (s > 32 ? 32 : s);
+  while (s > 1 && rows / s < 256) s /= 2;
+  return s;
+}
+
+bool storage16(const addhip_mlp_t& n) { return n.precision == ADDHIP_PREC_BF16; }
+void set_prec(addhip_gemm_t& g, const addhip_mlp_t& n) {
+  g.precision = n.precision;
+  g.operands_bf16 = storage16(n) ? 1 : 0;
+}
+
+// A few rows past a multiple of 128 (the discriminator's extra zero-difference sample: Mb + 1 rows) would cost a whole extra round of
+// 128-row tiles: they go into a second, tiny launch instead.  (Not with bf16 storage: its GEMM keeps 4 workgroups per CU in flight, so
+// eight more tiles cost less than the launch, which sits on the discriminator's serial chain.)
+struct Chunks { int n; int64_t r0[2], cnt[2]; };
+Chunks row_chunks(const addhip_mlp_t& net, int64_t rows) {
+  const int64_t rem = rows % 128;
+  if (rows > 128 && rem > 0 && rem <= 8 && !storage16(net)) return {2, {0, rows - rem}, {rows - rem, rem}};
+  return {1, {0, 0}, {rows, 0}};
+}
+
+// mask of the backward pass through the ReLU of `layer` for rows [r0, r0 + cnt): the sign bits where the forward pass wrote them (row
+// chunks of more than 8 rows), the fp32 activations otherwise
+void set_mask(addhip_gemm_t& g, const addhip_mlp_t& net, int layer, int64_t r0, int64_t cnt, bool bits_valid) {
+  const int h = net.hidden[layer];
+  if (bits_valid && (cnt > 8 || storage16(net))) {
+    const int ldb = (h + 31) / 32;
+    g.mask_bits = net.hbits[layer] + r0 * ldb;
+    g.ldbits = ldb;
+  } else {
+    g.mask = net.h[layer] + r0 * h;
+    g.ldmask = h;
+  }
+}
+
+int check_net(const addhip_mlp_t* net, int64_t rows, const char* who) {
+  ADDHIP_REQUIRE(net, "%s: null net", who);
+  ADDHIP_REQUIRE(net->num_hidden >= 1 && net->num_hidden <= ADDHIP_MLP_MAX_HIDDEN, "%s: 1..%d hidden layers", who, ADDHIP_MLP_MAX_HIDDEN);
+  ADDHIP_REQUIRE(rows > 0 && rows <= net->rows_cap, "%s: %lld rows, workspace holds %d", who, (long long)rows, net->rows_cap);
+  ADDHIP_REQUIRE(net->in_ld >= net->in_dim && net->in_dim > 0, "%s: bad input width", who);
+  for (int i = 0; i < net->num_hidden; ++i) {
+    ADDHIP_REQUIRE(net->hidden[i] > 0 && net->W[i] && net->b[i] && net->hbits[i], "%s: layer %d incomplete", who, i);
+    if (storage16(*net)) ADDHIP_REQUIRE(net->W16[i] && net->h16[i] && net->dz16[i], "%s: layer %d lacks its bf16 buffers (precision = bf16 storage)", who, i);
+    else ADDHIP_REQUIRE(net->h[i] && net->dz[i], "%s: layer %d lacks its fp32 buffers", who, i);
+  }
+  ADDHIP_REQUIRE(!storage16(*net) || net->h[net->num_hidden - 1], "%s: the last hidden layer is kept in fp32 too (loss heads)", who);
+  return 0;
+}
+
+#define LAUNCH(call)                \
+  do {                              \
+    if (int rc_ = (call)) return rc_; \
+    ++launches;                     \
+  } while (0)
+
+int refresh_transposed(const addhip_mlp_t& net, int& launches, void* stream) {
+  if (storage16(net) && net.t_count > 0)
+    LAUNCH(addhip_shadow_refresh(net.flat_params, nullptr, net.flat_trans16, net.flat_count, net.t_offset, net.t_rows, net.t_cols, net.t_count, stream));
+  return 0;
+}
+
+int forward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64_t rows, const float* a_mean, const float* a_std, bool sign_bits, int& launches,
+            void* stream) {
+  const int n = net.num_hidden;
+  const bool s16 = storage16(net);
+  const char* prev = reinterpret_cast<const char*>(s16 ? static_cast<const void*>(x16) : static_cast<const void*>(x));
+  const int esz = s16 ? 2 : 4;
+  int ld = net.in_ld, k = net.in_ld;
+  for (int i = 0; i < n; ++i) {
+    const int h = net.hidden[i];
+    const Chunks ch = row_chunks(net, rows);
+    for (int c = 0; c < ch.n; ++c) {
+      const int64_t r0 = ch.r0[c], cnt = ch.cnt[c];
+      float* C = s16 ? (i == n - 1 ? net.h[i] + r0 * h : nullptr) : net.h[i] + r0 * h;
+      addhip_gemm_t g = gemm((int)cnt, h, k, prev + (size_t)esz * r0 * ld, ld, 1, s16 ? static_cast<const void*>(net.W16[i]) : static_cast<const void*>(net.W[i]), k, 1,
+                             C, h, ADDHIP_EPI_BIAS_RELU, net.b[i]);
+      set_prec(g, net);
+      if (s16) {
+        g.C16 = net.h16[i] + r0 * h;
+        g.ldc16 = h;
+      } else if (i == 0) {
+        g.a_mean = a_mean;
+        g.a_std = a_std;
+      }
+      if (sign_bits && (s16 || cnt > 8)) {
+        g.relu_bits = net.hbits[i] + r0 * ((h + 31) / 32);
+        g.ldbits = (h + 31) / 32;
+      }
+      LAUNCH(addhip_gemm_f32(&g, stream));
+    }
+    prev = reinterpret_cast<const char*>(s16 ? static_cast<const void*>(net.h16[i]) : static_cast<const void*>(net.h[i]));
+    ld = h;
+    k = h;
+  }
+  return 0;
+}
+
+int backward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64_t rows, const addhip_extra_dw_t* extra, int flags, addhip_mlp_marks_t* marks,
+             int& launches, void* stream) {
+  const int n = net.num_hidden;
+  const bool s16 = storage16(net);
+  const int esz = s16 ? 2 : 4;
+  const bool zeroed = flags & ADDHIP_BWD_GRADS_ZEROED, bits_valid = flags & ADDHIP_BWD_SIGN_BITS;
+  const int base = launches;
+  auto dz_ptr = [&](int i) { return reinterpret_cast<const char*>(s16 ? static_cast<const void*>(net.dz16[i]) : static_cast<const void*>(net.dz[i])); };
+  if (s16 && !(flags & ADDHIP_BWD_TOP_CAST_DONE))
+    LAUNCH(addhip_to_bf16(net.dz[n - 1], net.dz16[n - 1], rows, net.hidden[n - 1], net.hidden[n - 1], net.hidden[n - 1], stream));
+  for (int i = n - 1; i >= 0; --i) {
+    const int out_d = net.hidden[i], in_ld = i == 0 ? net.in_ld : net.hidden[i - 1];
+    const void* inp = i == 0 ? (s16 ? static_cast<const void*>(x16) : static_cast<const void*>(x))
+                             : (s16 ? static_cast<const void*>(net.h16[i - 1]) : static_cast<const void*>(net.h[i - 1]));
+    const int s = split_k_for(out_d, in_ld, rows);
+    const int64_t slab = (int64_t)out_d * in_ld;
+    float* slabs = (net.slabs_top && i == n - 1) ? net.slabs_top : net.slabs;
+    const bool has_extra = extra && extra[i].A;
+    ADDHIP_REQUIRE((has_extra ? 2 : 1) * (int64_t)s * slab <= net.slab_floats, "mlp_backward: split-K scratch holds %lld floats, layer %d needs %lld",
+                   (long long)net.slab_floats, i, (long long)((has_extra ? 2 : 1) * (int64_t)s * slab));
+    if (marks) marks->dw_first[i] = launches - base;
+    {  // dW = dz^T x  (both operands row-contiguous: m/n-contiguous for this product), K = rows cut into s slices
+      addhip_gemm_t g = gemm(out_d, in_ld, (int)rows, dz_ptr(i), out_d, 0, inp, in_ld, 0, slabs, in_ld);
+      g.split_k = s;
+      set_prec(g, net);
+      LAUNCH(addhip_gemm_f32(&g, stream));
+    }
+    int total = s;
+    if (has_extra) {
+      addhip_gemm_t g = gemm(out_d, in_ld, (int)extra[i].rows, extra[i].A, extra[i].lda, 0, extra[i].B, extra[i].ldb, 0, slabs + (int64_t)s * slab, in_ld);
+      g.split_k = s;
+      set_prec(g, net);
+      LAUNCH(addhip_gemm_f32(&g, stream));
+      total = 2 * s;
+    }
+    LAUNCH(addhip_slab_reduce(slabs, total, slab, net.gW[i], slab, 1.0f, (flags & ADDHIP_BWD_ACCUMULATE_DW) ? 1 : 0, stream));
+    if (marks) marks->dw_last[i] = launches - base;
+    // every gradient of this net except W[0] / b[0] is final here (b[1] came with the dX GEMM of layer 2, the head's with the loss
+    // kernels): an early bucket for the data-parallel exchange
+    if (marks && i == 1) marks->early = launches - base;
+    if (i == n - 1 && !(flags & ADDHIP_BWD_TOP_BIAS_DONE)) {
+      ADDHIP_REQUIRE(net.dz[i], "mlp_backward: the top bias gradient is summed from the fp32 dz[last]");
+      LAUNCH(addhip_col_sum(net.dz[i], (int)rows, out_d, out_d, net.gb[i], 1.0f, zeroed ? 1 : 0, stream));
+    }
+    if (i > 0) {
+      const int prev_d = net.hidden[i - 1];
+      if (!zeroed) LAUNCH(addhip_fill_zero(net.gb[i - 1], prev_d, stream));
+      const Chunks ch = row_chunks(net, rows);
+      for (int c = 0; c < ch.n; ++c) {
+        const int64_t r0 = ch.r0[c], cnt = ch.cnt[c];
+        // dX = dz W: the fp32 path reads W[out, in] n-contiguously; bf16 storage reads the transposed shadow W^T[in, out] k-contiguously
+        addhip_gemm_t g = s16 ? gemm((int)cnt, prev_d, out_d, dz_ptr(i) + (size_t)esz * r0 * out_d, out_d, 1, net.W16t[i], out_d, 1, nullptr, prev_d, ADDHIP_EPI_MASK)
+                              : gemm((int)cnt, prev_d, out_d, dz_ptr(i) + (size_t)esz * r0 * out_d, out_d, 1, net.W[i], prev_d, 0, net.dz[i - 1] + r0 * prev_d,
+                                     prev_d, ADDHIP_EPI_MASK);
+        ADDHIP_REQUIRE(!s16 || net.W16t[i], "mlp_backward: layer %d lacks its transposed bf16 shadow", i);
+        g.colsum = net.gb[i - 1];
+        set_prec(g, net);
+        if (s16) {
+          g.C16 = net.dz16[i - 1] + r0 * prev_d;
+          g.ldc16 = prev_d;
+        }
+        set_mask(g, net, i - 1, r0, cnt, bits_valid);
+        LAUNCH(addhip_gemm_f32(&g, stream));
+      }
+    }
+  }
+  if (marks) marks->launches = launches - base;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int addhip_mlp_forward(const addhip_mlp_t* net, const float* x, const uint16_t* x16, int64_t rows, const float* a_mean, const float* a_std,
+                                  int32_t sign_bits, void* stream) {
+  if (int rc = check_net(net, rows, "mlp_forward")) return rc;
+  ADDHIP_REQUIRE(storage16(*net) ? (x16 && !a_mean) : (x != nullptr), "mlp_forward: bf16 storage takes x16 (already normalised), the other modes x");
+  ADDHIP_REQUIRE((a_mean == nullptr) == (a_std == nullptr), "mlp_forward: a_mean and a_std come together");
+  int launches = 0;
+  return forward(*net, x, x16, rows, a_mean, a_std, sign_bits != 0, launches, stream);
+}
+
+extern "C" int addhip_mlp_backward(const addhip_mlp_t* net, const float* x, const uint16_t* x16, int64_t rows, const addhip_extra_dw_t* extra, int32_t flags,
+                                   addhip_mlp_marks_t* marks, void* stream) {
+  if (int rc = check_net(net, rows, "mlp_backward")) return rc;
+  ADDHIP_REQUIRE(storage16(*net) ? (x16 != nullptr) : (x != nullptr), "mlp_backward: input rows missing");
+  ADDHIP_REQUIRE(net->slabs && net->slab_floats > 0, "mlp_backward: split-K scratch missing");
+  ADDHIP_REQUIRE(!storage16(*net) || (flags & ADDHIP_BWD_GRADS_ZEROED), "mlp_backward: bf16 storage expects the gradient buffer zeroed by the caller");
+  for (int i = 0; i < net->num_hidden; ++i) ADDHIP_REQUIRE(net->gW[i] && net->gb[i], "mlp_backward: gradient of layer %d missing", i);
+  if (marks) memset(marks, 0, sizeof(*marks));
+  int launches = 0;
+  return backward(*net, x, x16, rows, extra, flags, marks, launches, stream);
+}
+
+extern "C" int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, void* stream) {
+  ADDHIP_REQUIRE(d && d->actor && d->critic, "ppo_loss_fwd_bwd: null argument");
+  const addhip_mlp_t &A = *d->actor, &Cn = *d->critic;
+  const int Mb = d->rows;
+  if (int rc = check_net(&A, Mb, "ppo_loss_fwd_bwd (actor)")) return rc;
+  if (int rc = check_net(&Cn, Mb, "ppo_loss_fwd_bwd (critic)")) return rc;
+  ADDHIP_REQUIRE(A.head_rows == 32 && Cn.head_rows == 1, "ppo_loss_fwd_bwd: the actor's head is 32 rows (29 + padding), the critic's 1");
+  ADDHIP_REQUIRE(d->norm_obs && d->norm_action && d->old_logp && d->adv && d->tar_val && d->rand_mask, "ppo_loss_fwd_bwd: minibatch rows missing");
+  ADDHIP_REQUIRE(d->mean && d->d_mean && d->dv && d->num_valid && d->stats, "ppo_loss_fwd_bwd: workspace missing");
+  ADDHIP_REQUIRE(A.Wh && A.bh && A.gWh && A.gbh && Cn.Wh && Cn.bh && Cn.gWh && Cn.gbh && A.slabs && Cn.slabs, "ppo_loss_fwd_bwd: head parameters / scratch missing");
+  const bool s16 = storage16(A);
+  ADDHIP_REQUIRE(storage16(Cn) == s16 && (!s16 || d->norm_obs16), "ppo_loss_fwd_bwd: both nets in one storage mode (bf16 storage: norm_obs16 too)");
+  const int nA = A.num_hidden, nC = Cn.num_hidden, hA = A.hidden[nA - 1], hC = Cn.hidden[nC - 1];
+  ADDHIP_REQUIRE(32LL * 32 * hA <= A.slab_floats, "ppo_loss_fwd_bwd: the actor's split-K scratch is smaller than its head gradient's 32 slabs");
+  const int bwd = ADDHIP_BWD_GRADS_ZEROED | ADDHIP_BWD_TOP_BIAS_DONE | ADDHIP_BWD_TOP_CAST_DONE | ADDHIP_BWD_SIGN_BITS;
+  int launches = 0;
+  addhip_mlp_marks_t mk;
+  // ---- actor (ppo_agent.py:194-232, 247-275)
+  if (int rc = forward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, nullptr, true, launches, stream)) return rc;
+  if (int rc = refresh_transposed(A, launches, stream)) return rc;  // beside the other nets' GEMMs (the optimiser step wrote the flat shadow)
+  {
+    addhip_gemm_t g = gemm(Mb, 32, hA, A.h[nA - 1], hA, 1, A.Wh, hA, 1, d->mean, 32, ADDHIP_EPI_BIAS, A.bh);
+    g.precision = d->head_precision;
+    LAUNCH(addhip_gemm_f32(&g, stream));
+  }
+  LAUNCH(addhip_count_mask(d->rand_mask, Mb, d->num_valid, stream));
+  LAUNCH(addhip_actor_loss(d->mean, d->norm_action, d->old_logp, d->adv, d->rand_mask, Mb, d->action_std, d->logp_const, d->ppo_clip_ratio,
+                           d->action_bound_weight, d->action_reg_weight, d->grad_scale, d->num_valid, d->d_mean, d->stats, stream));
+  {  // head weight gradient: d_mean^T h over Mb rows, 32 K slices
+    addhip_gemm_t g = gemm(32, hA, Mb, d->d_mean, 32, 0, A.h[nA - 1], hA, 0, A.slabs, hA);
+    g.split_k = 32;
+    g.precision = d->head_precision;
+    LAUNCH(addhip_gemm_f32(&g, stream));
+  }
+  LAUNCH(addhip_slab_reduce(A.slabs, 32, 32LL * hA, A.gWh, 32LL * hA, 1.0f, 0, stream));
+  LAUNCH(addhip_col_sum(d->d_mean, Mb, 32, 32, A.gbh, 1.0f, 1, stream));
+  {  // dz[last] = (d_mean Wh) * relu'(h[last]); bf16 storage: written as bf16 directly
+    addhip_gemm_t g = gemm(Mb, hA, 32, d->d_mean, 32, 1, A.Wh, hA, 0, s16 ? nullptr : A.dz[nA - 1], hA, ADDHIP_EPI_MASK);
+    g.colsum = A.gb[nA - 1];
+    g.precision = d->head_precision;
+    if (s16) {
+      g.C16 = A.dz16[nA - 1];
+      g.ldc16 = hA;
+    }
+    set_mask(g, A, nA - 1, 0, Mb, true);
+    LAUNCH(addhip_gemm_f32(&g, stream));
+  }
+  int at = launches;
+  if (int rc = backward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, bwd, &mk, launches, stream)) return rc;
+  const int actor_early = at + mk.early, actor_end = launches;
+  // ---- critic (ppo_agent.py:234-245, base_agent.py:522-546)
+  if (int rc = forward(Cn, d->norm_obs, d->norm_obs16, Mb, nullptr, nullptr, true, launches, stream)) return rc;
+  if (int rc = refresh_transposed(Cn, launches, stream)) return rc;
+  LAUNCH(addhip_critic_head(Cn.h[nC - 1], hC, hC, Mb, Cn.Wh, Cn.bh, d->tar_val, d->critic_loss_weight * d->grad_scale, nullptr, d->dv, d->stats + 8, stream));
+  LAUNCH(addhip_head_backward(d->dv, Cn.Wh, Cn.h[nC - 1], hC, hC, Mb, s16 ? nullptr : Cn.dz[nC - 1], s16 ? Cn.dz16[nC - 1] : nullptr, Cn.gWh, Cn.gbh, Cn.gb[nC - 1],
+                              stream));
+  at = launches;
+  if (int rc = backward(Cn, d->norm_obs, d->norm_obs16, Mb, nullptr, bwd, &mk, launches, stream)) return rc;
+  if (marks) *marks = addhip_ppo_marks_t{launches, actor_end, actor_early, at + mk.early};
+  return 0;
+}
+
+extern "C" int addhip_disc_loss_fwd_bwd(const addhip_disc_loss_t* d, addhip_disc_marks_t* marks, void* stream) {
+  ADDHIP_REQUIRE(d && d->disc, "disc_loss_fwd_bwd: null argument");
+  const addhip_mlp_t& D = *d->disc;
+  const int Mb = d->rows, Md = Mb + 1;
+  if (int rc = check_net(&D, Md, "disc_loss_fwd_bwd")) return rc;
+  ADDHIP_REQUIRE(D.num_hidden == 2, "disc_loss_fwd_bwd: the gradient-penalty chain is written for 2-hidden-layer discriminators (fc_2layers_*)");
+  ADDHIP_REQUIRE(D.head_rows == 1 && D.Wh && D.bh && D.gWh && D.gbh && D.slabs && D.slabs_top, "disc_loss_fwd_bwd: head parameters / both split-K scratches missing");
+  const bool s16 = storage16(D);
+  ADDHIP_REQUIRE(d->norm_diff && d->dlogit && d->g && d->da2 && d->stats && d->disc_dim > 0 && d->disc_dim <= D.in_ld, "disc_loss_fwd_bwd: buffers missing");
+  ADDHIP_REQUIRE(s16 ? (d->norm_diff16 && d->a2_16 && d->a1_16 && d->G16 && d->e1_16 && D.W16t[0] && D.W16t[1]) : (d->a2 && d->a1 && d->G && d->e1),
+                 "disc_loss_fwd_bwd: the penalty chain's buffers for this storage mode are missing");
+  const int d1 = D.hidden[0], d2 = D.hidden[1], DS = D.in_ld;
+  const float ls = d->loss_scale, wd = d->weight_decay;
+  int launches = 0;
+  // L2 terms (add_agent.py:161-164, 181-186): logit regularisation on the head weights, weight decay on every weight.  They go into the
+  // freshly zeroed gradient FIRST (the weight gradients are added to them by the split-K combines), where they run beside the other
+  // nets' GEMMs instead of alone at the end of the step's longest chain.
+  LAUNCH(addhip_l2_grad(D.W[0], D.gW[0], (int64_t)d1 * DS, 2.0f * ls * wd, d->stats + 24, stream));
+  LAUNCH(addhip_l2_grad(D.W[1], D.gW[1], (int64_t)d2 * d1, 2.0f * ls * wd, d->stats + 24, stream));
+  LAUNCH(addhip_l2_grad(D.Wh, D.gWh, (int64_t)d2, 2.0f * ls * (wd + d->logit_reg), d->stats + 25, stream));
+  if (int rc = forward(D, d->norm_diff, d->norm_diff16, Md, nullptr, nullptr, true, launches, stream)) return rc;
+  if (int rc = refresh_transposed(D, launches, stream)) return rc;
+  const int m_head = launches;
+  // logit loss on Mb agent rows (negative) and the demo... rows of h[last]: row Mb = the zero-difference sample (positive)
+  LAUNCH(addhip_disc_head(D.h[1], d2, d2, Mb, D.h[1] + (size_t)Mb * d2, D.Wh, D.bh, ls, d->dlogit, d->dlogit + Mb, d->stats + 12, stream));
+  LAUNCH(addhip_head_backward(d->dlogit, D.Wh, D.h[1], d2, d2, Md, s16 ? nullptr : D.dz[1], s16 ? D.dz16[1] : nullptr, D.gWh, D.gbh, D.gb[1], stream));
+  const int m_chain = launches;
+  // gradient penalty (hand-derived double backward of add_agent.py:166-178):  g = ((w3 * m2) W2 * m1) W1 ;  penalty = mean |g|^2 ;
+  // second-order terms  G = d penalty / d g ;  e1 = (G W1^T) * m1 ;  da2 = (e1 W2^T) * m2
+  LAUNCH(addhip_bcast_mask(D.Wh, D.h[1], d2, d2, Mb, s16 ? nullptr : d->a2, s16 ? d->a2_16 : nullptr, stream));
+  addhip_extra_dw_t extra[ADDHIP_MLP_MAX_HIDDEN];
+  memset(extra, 0, sizeof(extra));
+  auto chain = [&](addhip_gemm_t g, int mask_layer) -> int {
+    set_prec(g, D);
+    if (mask_layer >= 0) set_mask(g, D, mask_layer, 0, Mb, true);
+    return addhip_gemm_f32(&g, stream);
+  };
+  if (s16) {  // a2 and G are written as bf16 by their kernels, a1 / e1 leave their GEMMs as bf16, g and da2 as fp32
+    addhip_gemm_t g1 = gemm(Mb, d1, d2, d->a2_16, d2, 1, D.W16t[1], d2, 1, nullptr, d1, ADDHIP_EPI_MASK);
+    g1.C16 = d->a1_16; g1.ldc16 = d1;
+    LAUNCH(chain(g1, 0));
+    LAUNCH(chain(gemm(Mb, DS, d1, d->a1_16, d1, 1, D.W16t[0], d1, 1, d->g, DS), -1));
+    LAUNCH(addhip_grad_penalty(d->g, DS, d->disc_dim, Mb, ls * d->grad_penalty, nullptr, d->G16, d->stats + 20, stream));
+    addhip_gemm_t g3 = gemm(Mb, d1, DS, d->G16, DS, 1, D.W16[0], DS, 1, nullptr, d1, ADDHIP_EPI_MASK);
+    g3.C16 = d->e1_16; g3.ldc16 = d1;
+    LAUNCH(chain(g3, 0));
+    LAUNCH(chain(gemm(Mb, d2, d1, d->e1_16, d1, 1, D.W16[1], d1, 1, d->da2, d2, ADDHIP_EPI_MASK), 1));
+    extra[0] = {d->a1_16, d1, d->G16, DS, Mb};
+    extra[1] = {d->a2_16, d2, d->e1_16, d1, Mb};
+  } else {
+    LAUNCH(chain(gemm(Mb, d1, d2, d->a2, d2, 1, D.W[1], d1, 0, d->a1, d1, ADDHIP_EPI_MASK), 0));
+    LAUNCH(chain(gemm(Mb, DS, d1, d->a1, d1, 1, D.W[0], DS, 0, d->g, DS), -1));
+    LAUNCH(addhip_grad_penalty(d->g, DS, d->disc_dim, Mb, ls * d->grad_penalty, d->G, nullptr, d->stats + 20, stream));
+    LAUNCH(chain(gemm(Mb, d1, DS, d->G, DS, 1, D.W[0], DS, 1, d->e1, d1, ADDHIP_EPI_MASK), 0));
+    LAUNCH(chain(gemm(Mb, d2, d1, d->e1, d1, 1, D.W[1], d1, 1, d->da2, d2, ADDHIP_EPI_MASK), 1));
+    extra[0] = {d->a1, d1, d->G, DS, Mb};
+    extra[1] = {d->a2, d2, d->e1, d1, Mb};
+  }
+  LAUNCH(addhip_col_sum(d->da2, Mb, d2, d2, D.gWh, 1.0f, 1, stream));
+  const int m_bwd = launches;
+  addhip_mlp_marks_t mk;
+  if (int rc = backward(D, d->norm_diff, d->norm_diff16, Md, extra,
+                        ADDHIP_BWD_GRADS_ZEROED | ADDHIP_BWD_TOP_BIAS_DONE | ADDHIP_BWD_ACCUMULATE_DW | ADDHIP_BWD_TOP_CAST_DONE | ADDHIP_BWD_SIGN_BITS, &mk, launches,
+                        stream))
+    return rc;
+  if (marks) *marks = addhip_disc_marks_t{launches, m_head, m_chain, m_bwd, m_bwd + mk.dw_first[1], m_bwd + mk.dw_last[1]};
+  return 0;
+}
+
+extern "C" int addhip_update_schedule(int32_t base, const addhip_ppo_marks_t* ppo, const addhip_disc_marks_t* disc, addhip_section_t* out, int32_t capacity) {
+  ADDHIP_REQUIRE(ppo && disc && out && capacity >= 10 && base >= 0, "update_schedule: bad arguments (10 sections)");
+  const int a0 = base, ea = base + ppo->actor_early, end_a = base + ppo->actor_end, ec = base + ppo->critic_early, end_ac = base + ppo->launches;
+  const int d0 = end_ac, d_head = d0 + disc->head, d_gp = d0 + disc->chain, d_bwd = d0 + disc->backward, dw_first = d0 + disc->top_dw_first,
+            dw_last = d0 + disc->top_dw_last, end_d = d0 + disc->launches;
+  // Actor and critic hand over everything but their first layers as soon as it is final; the collectives are issued in the order they
+  // become ready, because one communicator runs them in issue order.  The discriminator's section is the longest chain of the step, so
+  // its independent pieces run side by side on two streams: the logit loss and its backward step through the head (stream 3) beside the
+  // gradient-penalty chain (stream 2), then the top layer's weight gradient (stream 3, own split-K scratch) beside the dX GEMM and the
+  // first layer's.  {stream, first, last, wait_before, wait_after, bucket}
+  const addhip_section_t s[10] = {
+      {0, a0, ea, -1, -1, 0},            // 0: actor up to its early mark -> bucket 0
+      {1, end_a, ec, -1, -1, 1},         // 1: critic likewise -> bucket 1
+      {2, d0, d_head, -1, -1, -1},       // 2: L2 terms, forward
+      {3, d_head, d_gp, 2, -1, -1},      // 3: logit loss, head backward -> top dz
+      {2, d_gp, d_bwd, -1, -1, -1},      // 4: gradient-penalty chain
+      {3, d_bwd, dw_first, -1, -1, -1},  // 5: (bf16 storage without a pre-cast top gradient: its rounding)
+      {3, dw_first, dw_last, 4, -1, -1}, // 6: top-layer weight gradient (needs the chain's a2 / e1)
+      {2, dw_last, end_d, 5, 6, 2},      // 7: dX, first-layer weight gradient -> bucket 2 once section 6 is in too
+      {0, ea, end_a, -1, -1, -1},        // 8, 9: the two first layers (one bucket after the join: the host's)
+      {1, ec, end_ac, -1, -1, -1},
+  };
+  for (int i = 0; i < 10; ++i) out[i] = s[i];
+  return 10;
+}

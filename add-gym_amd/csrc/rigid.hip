@@ -21,6 +21,7 @@
 // 4 branch accumulators x 27 floats = 532 floats (133 KB per workgroup) + 11 KB of model constants staged once per workgroup;
 // body velocities / up-vectors live in private (scratch) arrays that stay in L2.
 #include "common.h"
+#include "record.h"
 #include "philox.h"
 
 namespace {
@@ -967,6 +968,7 @@ extern "C" int addhip_rigid_randomize(const addhip_rigid_dr_t* dr, float* env_sc
   ADDHIP_REQUIRE(dr && env_scale && sim_vel && step_counter && num_envs > 0, "rigid_randomize: bad arguments");
   ADDHIP_REQUIRE(dr->resample_interval >= 0 && dr->push_interval >= 0, "rigid_randomize: negative interval");
   ADDHIP_REQUIRE(dr->gain_lo > 0.f && dr->gain_hi >= dr->gain_lo && dr->friction_lo >= 0.f && dr->friction_hi >= dr->friction_lo, "rigid_randomize: bad ranges");
+  ADDHIP_RECORDABLE(addhip_rigid_randomize, dr, env_scale, sim_vel, num_envs, step_counter, advance);
   long long g = ((num_envs + 1) / 2 + 255) / 256;
   if (g > 256) g = 256;
   hipLaunchKernelGGL(rigid_dr_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *dr, env_scale, sim_vel, num_envs,
@@ -982,6 +984,7 @@ extern "C" int addhip_rigid_step(const addhip_rigid_model_t* m, float* sim_pose,
   ADDHIP_REQUIRE(m->body && m->topo && (m->points || m->num_points == 0), "rigid_step: model tables missing");
   ADDHIP_REQUIRE(m->num_points >= 0 && m->num_points <= MAXP, "rigid_step: at most %d collision points", MAXP);
   ADDHIP_REQUIRE(m->substeps >= 1 && m->substeps <= 64 && m->dt > 0.f, "rigid_step: bad dt / substeps");
+  ADDHIP_RECORDABLE(addhip_rigid_step, m, sim_pose, sim_vel, target, target_stride, num_envs, contact_flag, contact_bits);
   if (m->chains) {  // four lanes per environment
     // two waves per CU (the all-LDS form) serve up to 2 x 16 envs per CU; beyond that the register form runs four
     int dev = 0, cus = 0;

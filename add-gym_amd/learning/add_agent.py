@@ -24,7 +24,7 @@ from .. import hotpath as H
 from ..hotpath import gemm, make_task
 from ..util.logger import Logger
 from ..util.tb_logger import TBLogger
-from .model import Model, NetRunner, Plan, merge_sections
+from .model import Model, NetRunner, Plan, Schedule
 
 
 _SIDE_STREAMS = {}
@@ -82,9 +82,6 @@ class ADDAgent:
         # value / discriminator evaluation passes keep fp32 operands (formed by the bf16x2 products)
         self._storage16 = prec == "bf16"
         self._prec_small = H.PRECISIONS["bf16x2"] if self._storage16 else self._prec
-        # agent.group_actor_critic (default off): the actor's and the critic's equal-shaped forward / dX GEMMs of an update step run as
-        # grouped launches (addhip_gemm_grouped) on one stream; off = one launch per net and layer on two streams, same results
-        self._group_actor_critic = bool(cfg.get("group_actor_critic", False))
 
         # ---- motion library + sampler (add_motion.py:14-33)
         kin = env.robot._kin_char_model
@@ -288,135 +285,30 @@ class ADDAgent:
                                              L.ptr(B["reward"][t]), L.ptr(B["done"][t]), L.ptr(B["motion_id"][t]), L.ptr(B["motion_time"][t]),
                                              L.ptr(B["ep_stats"][t])))
 
-        # ---- update step on one gathered minibatch (ppo_agent.py:194-275, add_agent.py:141-202)
-        # The actor's and the critic's sections are recorded into plans of their own.  Default: they follow each other in the step's
-        # plan and run on two streams (beside the discriminator's two).  agent.group_actor_critic: they are MERGED onto one stream --
-        # the two nets have the same hidden shapes, so their forward and dX GEMMs pair up into grouped launches (addhip_gemm_grouped:
-        # one launch of two rounds of tiles); everything else keeps its order within its net.  Grouped launches are 2-20 % faster
-        # than their two halves launched alone (profiles/r03_gemm_hint_sweep_*.log), but inside the step the two-stream form wins:
-        # there a net's loss-head / reduction kernels run beside the other net's GEMMs.
-        p = self._update_plan = Plan()
-        p_actor, p_critic = Plan(), Plan()
-        # every loss coefficient carries 1/world: the all-reduce SUM of the gradients is then their mean over ranks
-        gs = 1.0 / self._world
-        ls_d = self._disc_loss_weight * gs
-        # (the whole flat gradient is zeroed once per step, before the three sections fork: _run_update_sections; bias and head
+        # ---- update step on one gathered minibatch (ppo_agent.py:194-275, add_agent.py:141-202): the library records it itself.
+        # addhip_ppo_loss_fwd_bwd = the actor's and the critic's sections (forward, loss heads, backward), addhip_disc_loss_fwd_bwd = the
+        # discriminator's (L2 terms, forward over Mb differences + one zero-difference row, logit loss, gradient-penalty chain with its
+        # second-order terms, backward); csrc/learner.hip assembles the ~55 launches, this host only hands over the buffers.
+        # (the whole flat gradient is zeroed once per step, before the sections fork: _run_update_sections; bias and head
         # gradients are then accumulated by atomics from the kernels that already hold the data)
-        # actor
-        s16 = self._storage16
-        x16 = L.ptr(W["norm_obs16"]) if s16 else None
-        p = p_actor
-        ra.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True, x16_ptr=x16)
-        if s16:  # the transposed weight copies the backward pass reads: refreshed here, beside the other nets' GEMMs (the optimiser step wrote the flat shadow)
-            p.add("addhip_shadow_refresh", *m.transposed_refresh_args("actor"))
-        self._gemm(p, Mb, 32, hA, L.ptr(ra.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
-        p.add("addhip_count_mask", L.ptr(W["mb_mask"]), Mb, L.ptr(W["nv"]))
-        p.add("addhip_actor_loss", L.ptr(W["mean"]), L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_mask"]), Mb, m.std32,
-              m.logp_const, self._ppo_clip_ratio, self._action_bound_weight, self._action_reg_weight, gs, L.ptr(W["nv"]), L.ptr(W["d_mean"]), L.ptr(W["stats"]))
-        sA = 32
-        self._gemm(p, 32, hA, Mb, L.ptr(W["d_mean"]), 32, 0, L.ptr(ra.h[-1]), hA, 0, L.ptr(self._slabs), hA, split_k=sA)
-        p.add("addhip_slab_reduce", L.ptr(self._slabs), sA, 32 * hA, m.g("actor", "Wh"), 32 * hA, 1.0, 0)
-        p.add("addhip_col_sum", L.ptr(W["d_mean"]), Mb, 32, 32, m.g("actor", "bh"), 1.0, 1)
-        # (bf16-storage mode: the producers of the three top gradients write them as bf16 directly -- dz16[-1] -- and skip the fp32 copy)
-        top16 = (lambda r: dict(C16=L.ptr(r.dz16[-1]), ldc16=r.net.hidden[-1])) if s16 else (lambda r: {})
-        self._gemm(p, Mb, hA, 32, L.ptr(W["d_mean"]), 32, 1, m.p("actor", "Wh"), hA, 0, None if s16 else L.ptr(ra.dz[-1]), hA, L.EPI_MASK,
-                   colsum=m.g("actor", f"b{len(m.actor.hidden) - 1}"), **top16(ra), **ra.mask_args(len(m.actor.hidden) - 1, 0, Mb))
-        ra.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True, x16_ptr=x16, top_cast_done=True)
-        # critic
-        p = p_critic
-        rc.forward(p, L.ptr(W["norm_obs"]), Mb, sign_bits=True, x16_ptr=x16)
-        if s16:
-            p.add("addhip_shadow_refresh", *m.transposed_refresh_args("critic"))
-        p.add("addhip_critic_head", L.ptr(rc.h[-1]), hC, hC, Mb, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(W["mb_tar"]), self._critic_loss_weight * gs,
-              None, L.ptr(W["dv"]), L.ptr(W["stats"]) + 4 * 8)
-        p.add("addhip_head_backward", L.ptr(W["dv"]), m.p("critic", "Wh"), L.ptr(rc.h[-1]), hC, hC, Mb, None if s16 else L.ptr(rc.dz[-1]),
-              L.ptr(rc.dz16[-1]) if s16 else None, m.g("critic", "Wh"), m.g("critic", "bh"), m.g("critic", f"b{len(m.critic.hidden) - 1}"))
-        rc.backward(p, L.ptr(W["norm_obs"]), Mb, grads_zeroed=True, top_bias_done=True, x16_ptr=x16, top_cast_done=True)
-        p = self._update_plan
-        pos_a, pos_c = merge_sections(p, p_actor, p_critic, group=self._group_actor_critic)
-        end_a, end_ac = pos_a[-1] + 1, len(p.calls)
-        ea, ec = pos_a[ra.early_mark - 1] + 1, pos_c[rc.early_mark - 1] + 1  # the net's gradient, first layer excepted, is final after this many calls
-        self._update_marks = [("actor", end_a), ("critic", end_ac)] if not self._group_actor_critic else [("actor+critic", end_ac)]
-        # discriminator: Mb agent/demo differences + one zero-difference row (row Mb of norm_diff stays 0)
-        Md = Mb + 1
-        # L2 terms (add_agent.py:161-164, 181-186): logit reg on the head weights, weight decay on all disc weights.  They go into the
-        # freshly zeroed gradient buffer FIRST (the weight gradients are added to them by the split-K combines below), where they run
-        # beside the other nets' GEMMs instead of alone at the end of the step's longest chain.
-        wd = self._disc_weight_decay
-        p.add("addhip_l2_grad", m.p("disc", "W0"), m.g("disc", "W0"), m.n_elem("disc", "W0"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
-        p.add("addhip_l2_grad", m.p("disc", "W1"), m.g("disc", "W1"), m.n_elem("disc", "W1"), 2.0 * ls_d * wd, L.ptr(W["stats"]) + 4 * 24)
-        p.add("addhip_l2_grad", m.p("disc", "Wh"), m.g("disc", "Wh"), m.n_elem("disc", "Wh"), 2.0 * ls_d * (wd + self._disc_logit_reg), L.ptr(W["stats"]) + 4 * 25)
-        nd = L.ptr(W["norm_diff"])
-        nd16 = L.ptr(W["norm_diff16"]) if s16 else None
-        rd.forward(p, nd, Md, sign_bits=True, x16_ptr=nd16)
-        if s16:
-            p.add("addhip_shadow_refresh", *m.transposed_refresh_args("disc"))
-        d_head = len(p.calls)
-        p.add("addhip_disc_head", L.ptr(rd.h[-1]), hD, hD, Mb, L.ptr(rd.h[-1]) + 4 * Mb * hD, m.p("disc", "Wh"), m.p("disc", "bh"), ls_d,
-              L.ptr(W["dlogit"]), L.ptr(W["dlogit"]) + 4 * Mb, L.ptr(W["stats"]) + 4 * 12)
-        p.add("addhip_head_backward", L.ptr(W["dlogit"]), m.p("disc", "Wh"), L.ptr(rd.h[-1]), hD, hD, Md, None if s16 else L.ptr(rd.dz[-1]),
-              L.ptr(rd.dz16[-1]) if s16 else None, m.g("disc", "Wh"), m.g("disc", "bh"), m.g("disc", f"b{len(m.disc.hidden) - 1}"))
-        # gradient penalty chain (hand-derived double backward, add_agent.py:166-178): g = ((w3*m2) W2 * m1) W1
-        h1, h2 = rd.h[0], rd.h[1] if len(rd.h) > 1 else None
-        if len(m.disc.hidden) != 2:
-            raise NotImplementedError("the gradient-penalty chain is written for the 2-hidden-layer discriminator (fc_2layers_*)")
-        d1, d2 = m.disc.hidden
-        d_gp = len(p.calls)
-        p.add("addhip_bcast_mask", m.p("disc", "Wh"), L.ptr(h2), d2, d2, Mb, None if s16 else L.ptr(W["a2"]), L.ptr(W["a2_16"]) if s16 else None)
-        if s16:
-            # the same chain on bf16 operands: a2 and G are written as bf16 by their kernels, a1 / e1 leave their GEMMs as bf16, g and
-            # da2 as fp32 (the penalty and the column sum read them)
-            k16 = dict(precision=L.PREC_BF16, operands_bf16=1)
-            self._gemm(p, Mb, d1, d2, L.ptr(W["a2_16"]), d2, 1, m.p16t("disc", "W1"), d2, 1, None, d1, L.EPI_MASK, C16=L.ptr(W["a1_16"]), ldc16=d1,
-                       **k16, **rd.mask_args(0, 0, Mb))
-            self._gemm(p, Mb, DS, d1, L.ptr(W["a1_16"]), d1, 1, m.p16t("disc", "W0"), d1, 1, L.ptr(W["g"]), DS, **k16)
-            p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, None, L.ptr(W["G16"]), L.ptr(W["stats"]) + 4 * 20)
-            self._gemm(p, Mb, d1, DS, L.ptr(W["G16"]), DS, 1, m.p16("disc", "W0"), DS, 1, None, d1, L.EPI_MASK, C16=L.ptr(W["e1_16"]), ldc16=d1,
-                       **k16, **rd.mask_args(0, 0, Mb))
-            self._gemm(p, Mb, d2, d1, L.ptr(W["e1_16"]), d1, 1, m.p16("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **k16, **rd.mask_args(1, 0, Mb))
-            p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
-            d_bwd = len(p.calls)
-            rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1_16"]), d1, L.ptr(W["G16"]), DS, Mb), 1: (L.ptr(W["a2_16"]), d2, L.ptr(W["e1_16"]), d1, Mb)},
-                        grads_zeroed=True, top_bias_done=True, x16_ptr=nd16, accumulate_dw=True, top_cast_done=True)
-        else:
-            self._gemm(p, Mb, d1, d2, L.ptr(W["a2"]), d2, 1, m.p("disc", "W1"), d1, 0, L.ptr(W["a1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
-            self._gemm(p, Mb, DS, d1, L.ptr(W["a1"]), d1, 1, m.p("disc", "W0"), DS, 0, L.ptr(W["g"]), DS)
-            p.add("addhip_grad_penalty", L.ptr(W["g"]), DS, tk.disc_dim, Mb, ls_d * self._disc_grad_penalty, L.ptr(W["G"]), None, L.ptr(W["stats"]) + 4 * 20)
-            # second-order terms: da1 = G W1^T ; e1 = da1 * m1 ; da2 = (e1 W2^T) * m2
-            self._gemm(p, Mb, d1, DS, L.ptr(W["G"]), DS, 1, m.p("disc", "W0"), DS, 1, L.ptr(W["e1"]), d1, L.EPI_MASK, **rd.mask_args(0, 0, Mb))
-            self._gemm(p, Mb, d2, d1, L.ptr(W["e1"]), d1, 1, m.p("disc", "W1"), d1, 1, L.ptr(W["da2"]), d2, L.EPI_MASK, **rd.mask_args(1, 0, Mb))
-            p.add("addhip_col_sum", L.ptr(W["da2"]), Mb, d2, d2, m.g("disc", "Wh"), 1.0, 1)
-            d_bwd = len(p.calls)
-            rd.backward(p, nd, Md, extra_dw={0: (L.ptr(W["a1"]), d1, L.ptr(W["G"]), DS, Mb), 1: (L.ptr(W["a2"]), d2, L.ptr(W["e1"]), d1, Mb)},
-                        grads_zeroed=True, top_bias_done=True, accumulate_dw=True)
-        self._update_marks.append(("disc", len(p.calls)))
-        # Launch / exchange schedule of one optimiser step: entries (stream, first call, last call, gradient range to all-reduce after
-        # it, entry whose completion the stream waits for before it starts, entry it waits for before the all-reduce), issued in
-        # list order.  Actor and critic (one merged section on the main stream) hand over everything but their first layers as soon as it is final; the collectives are
-        # issued in the order they become ready, because one communicator runs them in issue order.
-        # The discriminator's section is the longest chain of the step, so its independent pieces run side by side on two
-        # streams: the logit loss and its backward step through the head (stream 3) beside the gradient-penalty chain (stream 2),
-        # then the top layer's weight gradient (stream 3, own split-K scratch) beside the dX GEMM and the first layer's.
-        end_d = self._update_marks[-1][1]
+        import ctypes as C
+        p = self._update_plan = Plan()
+        ppo, disc = self._loss_descs()
+        pm, dm = L.PpoMarksT(), L.DiscMarksT()
+        p.hold(ppo, disc, self._mlp_c)
+        p.add("addhip_ppo_loss_fwd_bwd", ppo, C.byref(pm))
+        p.add("addhip_disc_loss_fwd_bwd", disc, C.byref(dm))
+        self._update_marks = [("actor", pm.actor_end), ("critic", pm.launches), ("disc", pm.launches + dm.launches)]
+        # Launch / exchange schedule of one optimiser step (addhip_update_schedule): ten sections on four streams -- actor | critic |
+        # discriminator x 2 -- with event dependencies; actor and critic hand over everything but their first layers as soon as it is final
+        # (buckets 0, 1), the discriminator after its two-stream backward (bucket 2); the two first layers are one bucket after the join.
+        secs = (L.SectionT * 10)()
+        if L.load().addhip_update_schedule(0, C.byref(pm), C.byref(dm), secs, 10) != 10:  # (returns the number of sections)
+            raise L.AddhipError("addhip_update_schedule: " + L.load().addhip_last_error().decode())
         br = m.bucket_ranges
-        dw_first, dw_last = rd.dw_marks[len(m.disc.hidden) - 1]
-        if self._group_actor_critic:
-            ac_early = max(ea, ec)
-            head = [(0, 0, ac_early, br["actor_tail"], None, None), (0, ac_early, ac_early, br["critic_tail"], None, None)]  # (no calls: the second bucket)
-            tail = [(0, ac_early, end_ac, None, None, None)]
-        else:
-            head = [(0, 0, ea, br["actor_tail"], None, None), (1, end_a, ec, br["critic_tail"], None, None)]
-            tail = [(0, ea, end_a, None, None, None), (1, ec, end_ac, None, None, None)]
-        sched = head + [
-                 (2, end_ac, d_head, None, None, None),         # 2: L2 terms, forward
-                 (3, d_head, d_gp, None, 2, None),              # 3: logit loss, head backward -> top dz
-                 (2, d_gp, d_bwd, None, None, None),            # 4: gradient-penalty chain
-                 (3, d_bwd, dw_first, None, None, None),        # 5: (bf16 storage: the top dz rounded to bf16)
-                 (3, dw_first, dw_last, None, 4, None),         # 6: top-layer weight gradient (needs the chain's a2 / e1)
-                 (2, dw_last, end_d, br["disc"], 5, 6)          # 7: dX, first-layer weight gradient
-                 ] + tail                                        # the two first layers: one bucket after the join
-        self._update_schedule = sched
-        self._sched_events = sorted({e[4] for e in sched if e[4] is not None} | {e[5] for e in sched if e[5] is not None})
+        # the plan and its schedule live in the library (include/addhip.h, "recorded plans"): one optimiser step's sections are ONE C
+        # call (addhip_schedule_run: launches, stream forks / joins by HIP events, bucket call-backs), for this host or any other
+        self._schedule = Schedule(p, secs, 1 + len(self._side_streams), buckets=[br["actor_tail"], br["critic_tail"], br["disc"]])
 
         # ---- build-train-data: critic over the T+1 obs slots and the N obs_timeout rows, discriminator over the T*N
         # differences, in chunks of _eval_rows rows (plans prebuilt once like the act / update plans)
@@ -444,6 +336,25 @@ class ADDAgent:
                                    L.ptr(B["disc_obs"]), L.ptr(B["disc_demo"]), DS, tk.disc_dim, L.ptr(Nm["d_abs"]), 1e-4, L.ptr(W["norm_obs"]),
                                    L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_tar"]), L.ptr(W["mb_mask"]), L.ptr(W["norm_diff"]),
                                    L.ptr(W["norm_obs16"]) if s16 else None, L.ptr(W["norm_diff16"]) if s16 else None)
+
+    def _loss_descs(self):
+        """The update step's two loss sections as parameter blocks of the composite entry points (include/addhip.h:
+        addhip_ppo_loss_fwd_bwd, addhip_disc_loss_fwd_bwd) over this agent's buffers."""
+        m, W, tk, Mb = self._model, self._W, self._task, self.Mb
+        s16 = self._storage16
+        gs = 1.0 / self._world  # every loss coefficient carries 1/world: the all-reduce SUM of the gradients is then their mean over ranks
+        self._mlp_c = {r.net.name: r.c_struct() for r in (self._run_actor, self._run_critic, self._run_disc)}
+        import ctypes as C
+        ppo = L.PpoLossT(C.pointer(self._mlp_c["actor"]), C.pointer(self._mlp_c["critic"]), Mb, L.ptr(W["norm_obs"]), L.ptr(W["norm_obs16"]) if s16 else None,
+                         L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_tar"]), L.ptr(W["mb_mask"]), m.std32, m.logp_const,
+                         self._ppo_clip_ratio, self._action_bound_weight, self._action_reg_weight, self._critic_loss_weight, gs, self._prec_small,
+                         L.ptr(W["mean"]), L.ptr(W["d_mean"]), L.ptr(W["dv"]), L.ptr(W["nv"]), L.ptr(W["stats"]))
+        o = (lambda k: L.ptr(W[k])) if s16 else (lambda k: None)
+        f = (lambda k: None) if s16 else (lambda k: L.ptr(W[k]))
+        disc = L.DiscLossT(C.pointer(self._mlp_c["disc"]), Mb, tk.disc_dim, L.ptr(W["norm_diff"]), o("norm_diff16"), self._disc_loss_weight * gs,
+                           self._disc_logit_reg, self._disc_grad_penalty, self._disc_weight_decay, L.ptr(W["dlogit"]), f("a2"), f("a1"), L.ptr(W["g"]), f("G"),
+                           f("e1"), L.ptr(W["da2"]), o("a2_16"), o("a1_16"), o("G16"), o("e1_16"), L.ptr(W["stats"]))
+        return ppo, disc
 
     # ------------------------------------------------------------------ public surface
     def get_num_envs(self):
@@ -726,14 +637,12 @@ class ADDAgent:
         net's MFMA phases (all tiles of one GEMM launch are in phase with each other).  With more than one rank each
         section is followed, on its own stream, by the asynchronous all-reduce of that net's gradient bucket (the exchange
         step: mean gradient over ranks, RCCL over xGMI), which therefore also overlaps the other nets' GEMMs."""
-        m, plan = self._model, self._update_plan
+        m = self._model
         main = torch.cuda.current_stream()
         streams = [main] + self._side_streams
         if zero_grad:  # MPOptimizer.step's zero_grad (mp_optimizer.py:14-16); inside an update phase addhip_optimizer_step has done it
             L.call("addhip_fill_zero", L.ptr(m.grads), m.count, main.cuda_stream)
         # (bf16-storage mode: the gather wrote the bf16 copies of the minibatch rows too; row Mb of norm_diff16 stays 0 from its allocation)
-        fork = torch.cuda.Event()
-        fork.record(main)
         # stream-ordered asynchronous collectives are an nccl (RCCL) property; any other backend (gloo in rehearsals) gets one
         # blocking all-reduce of the whole gradient after the join
         # (a 1-rank process group takes the same path: the collectives are identities there, which is how the single-GPU
@@ -741,26 +650,13 @@ class ADDAgent:
         exchange = self._distributed
         overlap = exchange and torch.distributed.get_backend() == "nccl"
         pending = []
-        for s in self._side_streams:
-            s.wait_event(fork)
-        events = {}
-        for k, (si, first, last, bucket, after, join) in enumerate(self._update_schedule):
-            s = streams[si]
-            if after is not None:
-                s.wait_event(events[after])
-            plan.run(s.cuda_stream, first, last)
-            if join is not None:
-                s.wait_event(events[join])
-            if k in self._sched_events:
-                events[k] = torch.cuda.Event()
-                events[k].record(s)
-            if overlap and bucket is not None:
-                with torch.cuda.stream(s):
-                    pending.append(D.all_reduce_sum_async(m.grads[bucket[0]:bucket[1]]))
-        for s in self._side_streams:
-            done = torch.cuda.Event()
-            done.record(s)
-            main.wait_event(done)
+
+        def on_bucket(bucket, stream_index):  # called by addhip_schedule_run where the bucket is final in the issue order of its stream
+            with torch.cuda.stream(streams[stream_index]):
+                pending.append(D.all_reduce_sum_async(m.grads[bucket[0]:bucket[1]]))
+
+        # the sections on their streams: fork from `main`, event dependencies between sections, join back into `main`
+        self._schedule.run([s.cuda_stream for s in streams], on_bucket if overlap else None)
         # (every loss coefficient of the plan carries 1/world, so the SUM over ranks is already the mean: no scaling pass)
         if overlap:
             a, b = m.bucket_ranges["first_layers"]

@@ -218,6 +218,7 @@ class Model:
 
 
 def split_k_for(out_dim, in_dim, rows):
+    """K slices of a weight-gradient GEMM (the rule of csrc/learner.hip, restated to size the split-K scratch)."""
     tiles = ((out_dim + 127) // 128) * ((in_dim + 127) // 128)
     s = max(1, min(32, -(-512 // tiles)))
     while s > 1 and rows // s < 256:
@@ -226,74 +227,121 @@ def split_k_for(out_dim, in_dim, rows):
 
 
 class Plan:
-    """A recorded sequence of C-ABI calls (argument tuples are prebuilt once; replay costs one
-    ctypes call per kernel)."""
+    """A recorded sequence of launches held by libaddhip (addhip_plan_t; include/addhip.h, "recorded plans").  add() calls an entry point
+    in recording mode: its arguments are checked, its parameter blocks copied, and its launch -- or, for a composite entry point such as
+    addhip_mlp_forward, each of its launches -- is appended to the plan.  len(plan) counts launches; run() replays a range with ONE C call."""
 
     def __init__(self):
-        self.calls = []
-        self.keep = []
+        import ctypes as C
+
         self._lib = L.load()
+        self.keep = []
+        self._handle = C.c_void_p()
+        self._check(self._lib.addhip_plan_create(C.byref(self._handle)), "addhip_plan_create")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise L.AddhipError(f"{what} failed ({rc}): {self._lib.addhip_last_error().decode()}")
 
     def add(self, name, *args):
-        self.calls.append((name, getattr(self._lib, name), args))
+        """Record one entry-point call (without its stream argument); returns the plan's length before it."""
+        lib, at = self._lib, len(self)
+        self._check(lib.addhip_plan_record_begin(self._handle), "addhip_plan_record_begin")
+        try:
+            rc = getattr(lib, name)(*args, None)  # recorded, not launched
+            msg = lib.addhip_last_error().decode() if rc != 0 else ""
+        finally:
+            self._check(lib.addhip_plan_record_end(self._handle), "addhip_plan_record_end")
+        if rc != 0:
+            raise L.AddhipError(f"{name} failed ({rc}) while being recorded: {msg}")
+        return at
 
     def hold(self, *objs):
+        """Keep Python objects alive with the plan (host tables a recorded block points at are copied by the library; this is for the rest)."""
         self.keep.extend(objs)
 
+    def __len__(self):
+        return self._lib.addhip_plan_size(self._handle)
+
+    @property
+    def handle(self):
+        return self._handle
+
+    def launches(self):
+        """[(entry point name, [addhip_gemm_t, ...])] per recorded launch: what tools and the bench's roofline accounting read."""
+        lib, out = self._lib, []
+        buf = (L.GemmT * L.GEMM_MAX_GROUP)()
+        for i in range(len(self)):
+            k = lib.addhip_plan_call_gemms(self._handle, i, buf, L.GEMM_MAX_GROUP)
+            gemms = []
+            for j in range(max(k, 0)):
+                g = L.GemmT()
+                import ctypes as C
+                C.memmove(C.byref(g), C.byref(buf[j]), C.sizeof(L.GemmT))
+                gemms.append(g)
+            out.append((lib.addhip_plan_call_name(self._handle, i).decode(), gemms))
+        return out
+
     def run(self, stream, first=0, last=None):
-        for name, fn, args in self.calls[first:last]:
-            rc = fn(*args, stream)
-            if rc != 0:
-                raise L.AddhipError(f"{name} failed ({rc}): {self._lib.addhip_last_error().decode()}")
+        rc = self._lib.addhip_plan_run(self._handle, first, -1 if last is None else last, stream)
+        if rc != 0:
+            raise L.AddhipError(f"addhip_plan_run failed ({rc}): {self._lib.addhip_last_error().decode()}")
+
+    def __del__(self):
+        if getattr(self, "_handle", None) is not None and self._handle:
+            self._lib.addhip_plan_destroy(self._handle)
+            self._handle = None
 
 
-def _group_key(call):
-    """Signature under which two recorded GEMM calls may share a grouped launch (None: never)."""
-    name, _, args = call
-    if name != "addhip_gemm_f32":
-        return None
-    g = args[0]
-    if g.split_k > 1 or g.M <= 8 or g.a_mean:  # split-K weight gradients gain nothing from grouping (measured), few-row launches take another kernel
-        return None
-    return (g.M, g.N, g.K, g.a_kcontig, g.b_kcontig, g.epilogue, g.precision, g.operands_bf16, g.accumulate, bool(g.mask_bits), bool(g.relu_bits),
-            bool(g.C16), bool(g.C), bool(g.colsum))
+class Schedule:
+    """addhip_schedule_t over a Plan: `sections` is an array of addhip_section_t (e.g. from addhip_update_schedule), issued in list order;
+    bucket k of a section is reported to run()'s call-back as buckets[k]."""
 
+    def __init__(self, plan, sections, num_streams, buckets=()):
+        import ctypes as C
 
-def merge_sections(plan, sec_a, sec_b, group=True):
-    """Append the calls of two independent recorded sections to `plan`, pairing GEMMs of equal signature -- in the order they occur in
-    either section -- into addhip_gemm_grouped launches; every other call keeps its order within its own section.  Returns
-    (pos_a, pos_b): the index in `plan.calls` at which each call of either section ended up."""
-    lib = plan._lib
-    base = len(plan.calls)
-    out, pos_a, pos_b, ib = [], [], [None] * len(sec_b.calls), 0
-    for ca in sec_a.calls:
-        key = _group_key(ca) if group else None
-        j = None
-        if key is not None:
-            j = next((j for j in range(ib, len(sec_b.calls)) if _group_key(sec_b.calls[j]) == key), None)
-        if j is not None:
-            for i in range(ib, j):
-                pos_b[i] = base + len(out)
-                out.append(sec_b.calls[i])
-            arr = (L.GemmT * 2)(ca[2][0], sec_b.calls[j][2][0])
-            plan.hold(arr)
-            pos_a.append(base + len(out))
-            pos_b[j] = base + len(out)
-            out.append(("addhip_gemm_grouped", lib.addhip_gemm_grouped, (arr, 2)))
-            ib = j + 1
-        else:
-            pos_a.append(base + len(out))
-            out.append(ca)
-    for i in range(ib, len(sec_b.calls)):
-        pos_b[i] = base + len(out)
-        out.append(sec_b.calls[i])
-    plan.calls.extend(out)
-    plan.keep.extend(sec_a.keep + sec_b.keep)
-    return pos_a, pos_b
+        self._lib, self._plan = L.load(), plan
+        self.sections = [(s.stream, s.first, s.last, s.wait_before, s.wait_after, s.bucket) for s in sections]
+        self.buckets = list(buckets)
+        self._bucket_stream = {s.bucket: s.stream for s in sections if s.bucket >= 0}
+        assert all(0 <= k < len(self.buckets) for k in self._bucket_stream)
+        h = C.c_void_p()
+        rc = self._lib.addhip_schedule_create(plan.handle, sections, len(sections), num_streams, C.byref(h))
+        if rc != 0:
+            raise L.AddhipError(f"addhip_schedule_create failed ({rc}): {self._lib.addhip_last_error().decode()}")
+        self._handle, self._num_streams = h, num_streams
+        self._null_cb = C.cast(None, L.BUCKET_FN)
+
+    def run(self, streams, on_bucket=None):
+        """streams: raw hipStream_t handles (ints); on_bucket(bucket, stream index) is called, inside this call, at the point of the
+        issue order where that section's bucket is final on that stream."""
+        import ctypes as C
+
+        arr = (C.c_void_p * self._num_streams)(*streams)
+        cb = self._null_cb
+        err = []
+        if on_bucket is not None:
+            def _cb(user, k, stream):
+                try:
+                    on_bucket(self.buckets[k], self._bucket_stream[k])
+                except BaseException as e:  # must not propagate through the C frame
+                    err.append(e)
+            cb = L.BUCKET_FN(_cb)
+        rc = self._lib.addhip_schedule_run(self._handle, arr, cb, None)
+        if err:
+            raise err[0]
+        if rc != 0:
+            raise L.AddhipError(f"addhip_schedule_run failed ({rc}): {self._lib.addhip_last_error().decode()}")
+
+    def __del__(self):
+        if getattr(self, "_handle", None) is not None and self._handle:
+            self._lib.addhip_schedule_destroy(self._handle)
+            self._handle = None
 
 
 class NetRunner:
-    """Forward / backward call recording for one Mlp over `rows` rows with its own activation buffers."""
+    """One Mlp's activation / gradient workspace for up to `rows` rows, as the addhip_mlp_t the library's composite entry points take
+    (addhip_mlp_forward / _backward, addhip_ppo_loss_fwd_bwd, addhip_disc_loss_fwd_bwd: csrc/learner.hip assembles the launches)."""
 
     def __init__(self, model, net, rows, device, slabs, precision=L.PREC_F32, storage16=False):
         self.m, self.net, self.rows, self.slabs = model, net, rows, slabs
@@ -305,119 +353,45 @@ class NetRunner:
         if self.storage16:
             self.h16 = [torch.zeros(rows, h, dtype=torch.bfloat16, device=device) for h in net.hidden]
             self.dz16 = [torch.zeros(rows, h, dtype=torch.bfloat16, device=device) for h in net.hidden]
-        self.early_mark = None
-        self.dw_marks = {}      # layer -> (first, last) plan call index of its weight-gradient group (GEMMs + split-K combine)
-        self.aux_slabs = None   # (layer, buffer): that layer's weight-gradient group uses its own split-K scratch, so that it
-        self._bits_valid = False  # may run on another stream than the rest of the backward pass
+        self.aux_slabs = None   # (layer, buffer): the top layer's weight-gradient group uses its own split-K scratch, so that it may run on
+                                # another stream than the rest of the backward pass (addhip_mlp_t.slabs_top)
         # ReLU sign bits of the hidden activations (1 bit per element): what the backward GEMMs read as their mask instead of
         # the fp32 activations themselves (64 MB -> 2 MB per 16384 x 1024 layer)
         self.hb = [torch.zeros(rows, (h + 31) // 32, dtype=torch.int32, device=device) for h in net.hidden]
         self.h = [torch.zeros(rows, h, device=device) for h in net.hidden]
         self.dz = [torch.zeros(rows, h, device=device) for h in net.hidden]
 
-    def _row_chunks(self, rows):
-        """A few rows past a multiple of 128 (the discriminator's extra zero-difference sample: Mb + 1 rows) would cost a
-        whole extra wave of 128-row tiles; they go into a second, tiny launch instead.  -> [(first_row, count), ...]
-        (not in bf16-storage mode: its GEMM keeps 4 workgroups per CU in flight, so eight more tiles cost less than the
-        launch, which sits on the discriminator's serial chain)"""
-        rem = rows % 128
-        if rows > 128 and 0 < rem <= 8 and not self.storage16:
-            return [(0, rows - rem), (rows - rem, rem)]
-        return [(0, rows)]
-
-    def mask_args(self, layer, r0, cnt):
-        """Mask of the backward pass through the ReLU of `layer` for rows [r0, r0+cnt): the sign bits where the forward pass
-        of this plan wrote them (row chunks of more than 8 rows), the fp32 activations otherwise."""
-        h = self.net.hidden[layer]
-        if self._bits_valid and (cnt > 8 or self.storage16):
-            ldb = (h + 31) // 32
-            return dict(mask_bits=L.ptr(self.hb[layer]) + 4 * r0 * ldb, ldbits=ldb)
-        return dict(mask=L.ptr(self.h[layer]) + 4 * r0 * h, ldmask=h)
-
-    def forward(self, plan, x_ptr, rows, a_mean=None, a_std=None, sign_bits=False, x16_ptr=None):
-        """sign_bits: also write the ReLU sign bits (forward passes that are followed by a backward pass in the same plan).
-        x16_ptr: bf16 copy of the input rows (storage16 runners)."""
-        net, m = self.net, self.m
-        self._bits_valid = bool(sign_bits)
-        if self.storage16:
-            assert x16_ptr is not None and a_mean is None, "bf16-storage runners take a bf16 copy of their (already normalised) input"
-            prev, ld, k = x16_ptr, net.in_ld, net.in_ld
-            n = len(net.hidden)
-            for i, h in enumerate(net.hidden):
-                for r0, cnt in self._row_chunks(rows):
-                    bits = dict(relu_bits=L.ptr(self.hb[i]) + 4 * r0 * ((h + 31) // 32), ldbits=(h + 31) // 32) if sign_bits else {}
-                    g = gemm(cnt, h, k, prev + 2 * r0 * ld, ld, 1, m.p16(net.name, f"W{i}"), k, 1,
-                             L.ptr(self.h[i]) + 4 * r0 * h if i == n - 1 else None, h, L.EPI_BIAS_RELU, m.p(net.name, f"b{i}"),
-                             precision=L.PREC_BF16, operands_bf16=1, C16=L.ptr(self.h16[i]) + 2 * r0 * h, ldc16=h, **bits)
-                    plan.hold(g)
-                    plan.add("addhip_gemm_f32", g)
-                prev, ld, k = L.ptr(self.h16[i]), h, h
-            return
-        prev, ld, k = x_ptr, net.in_ld, net.in_ld
-        for i, h in enumerate(net.hidden):
-            for r0, cnt in self._row_chunks(rows):
-                bits = dict(relu_bits=L.ptr(self.hb[i]) + 4 * r0 * ((h + 31) // 32), ldbits=(h + 31) // 32) if sign_bits and cnt > 8 else {}
-                g = gemm(cnt, h, k, prev + 4 * r0 * ld, ld, 1, m.p(net.name, f"W{i}"), k, 1, L.ptr(self.h[i]) + 4 * r0 * h, h, L.EPI_BIAS_RELU,
-                         m.p(net.name, f"b{i}"), a_mean=a_mean if i == 0 else None, a_std=a_std if i == 0 else None, precision=self.precision, **bits)
-                plan.hold(g)
-                plan.add("addhip_gemm_f32", g)
-            prev, ld, k = L.ptr(self.h[i]), h, h
-
-    def backward(self, plan, x_ptr, rows, extra_dw=None, grads_zeroed=False, top_bias_done=False, x16_ptr=None, accumulate_dw=False, top_cast_done=False):
-        """dz[-1] must hold d loss / d (pre-activation of the last hidden layer).  extra_dw: {layer: (A_ptr, lda, B_ptr, ldb)}
-        second product accumulated into dW of that layer (the gradient-penalty terms).  grads_zeroed: the caller cleared the
-        whole gradient buffer at the start of the step (no per-bias memsets here); top_bias_done: the kernel that produced
-        dz[-1] also accumulated the top layer's bias gradient.  storage16 runners: x16_ptr = bf16 copy of the input rows, the
-        extra_dw operands are bf16 too, and the fp32 top gradient is rounded to bf16 once at the start (top_cast_done: its producer
-        already wrote dz16[-1]).  accumulate_dw: the
-        weight gradients are ADDED to what the gradient buffer holds (L2 terms written there earlier in the step)."""
+    def c_struct(self):
+        """addhip_mlp_t over this runner's buffers (include/addhip.h, "composite entry points")."""
         net, m = self.net, self.m
         n = len(net.hidden)
-        s16 = self.storage16
-        esz = 2 if s16 else 4
-        kw = dict(precision=L.PREC_BF16, operands_bf16=1) if s16 else dict(precision=self.precision)
-        dz = self.dz16 if s16 else self.dz
-        acts = self.h16 if s16 else self.h
-        if s16:
-            assert x16_ptr is not None and grads_zeroed
-            if not top_cast_done:
-                plan.add("addhip_to_bf16", L.ptr(self.dz[n - 1]), L.ptr(self.dz16[n - 1]), rows, net.hidden[n - 1], net.hidden[n - 1], net.hidden[n - 1])
-        for i in reversed(range(n)):
-            out_d = net.hidden[i]
-            in_ld = net.in_ld if i == 0 else net.hidden[i - 1]
-            inp = (x16_ptr if s16 else x_ptr) if i == 0 else L.ptr(acts[i - 1])
-            s = split_k_for(out_d, in_ld, rows)
-            slab = out_d * in_ld
-            slabs = self.aux_slabs[1] if self.aux_slabs is not None and self.aux_slabs[0] == i else self.slabs
-            dw_first = len(plan.calls)
-            g = gemm(out_d, in_ld, rows, L.ptr(dz[i]), out_d, 0, inp, in_ld, 0, L.ptr(slabs), in_ld, split_k=s, **kw)
-            plan.hold(g)
-            plan.add("addhip_gemm_f32", g)
-            total = s
-            if extra_dw and i in extra_dw:
-                a_ptr, lda, b_ptr, ldb, erows = extra_dw[i]
-                g2 = gemm(out_d, in_ld, erows, a_ptr, lda, 0, b_ptr, ldb, 0, L.ptr(slabs) + 4 * s * slab, in_ld, split_k=s, **kw)
-                plan.hold(g2)
-                plan.add("addhip_gemm_f32", g2)
-                total = 2 * s
-            plan.add("addhip_slab_reduce", L.ptr(slabs), total, slab, m.g(net.name, f"W{i}"), slab, 1.0, int(accumulate_dw))
-            self.dw_marks[i] = (dw_first, len(plan.calls))
-            if i == 1:
-                # every gradient of this net except W0 / b0 is final here (b1 came with the dX GEMM of layer 2, the head's
-                # with the loss kernels): an early bucket for the data-parallel exchange
-                self.early_mark = len(plan.calls)
-            if i == n - 1 and not top_bias_done:  # the top layer's dz comes from the loss kernels; the others get their bias
-                plan.add("addhip_col_sum", L.ptr(self.dz[i]), rows, out_d, out_d, m.g(net.name, f"b{i}"), 1.0, int(grads_zeroed))  # gradient from the dX GEMM below
-            if i > 0:
-                prev_d = net.hidden[i - 1]
-                if not grads_zeroed:
-                    plan.add("addhip_fill_zero", m.g(net.name, f"b{i - 1}"), prev_d)
-                for r0, cnt in self._row_chunks(rows):
-                    out = dict(C16=L.ptr(self.dz16[i - 1]) + 2 * r0 * prev_d, ldc16=prev_d) if s16 else {}
-                    # dX = dz W: fp32 path reads W[out,in] n-contiguously; the bf16-storage path reads the transposed shadow W^T[in,out]
-                    wb = (m.p16t(net.name, f"W{i}"), out_d, 1) if s16 else (m.p(net.name, f"W{i}"), prev_d, 0)
-                    g3 = gemm(cnt, prev_d, out_d, L.ptr(dz[i]) + esz * r0 * out_d, out_d, 1, wb[0], wb[1], wb[2],
-                              None if s16 else L.ptr(self.dz[i - 1]) + 4 * r0 * prev_d, prev_d, L.EPI_MASK, colsum=m.g(net.name, f"b{i - 1}"),
-                              **kw, **out, **self.mask_args(i - 1, r0, cnt))
-                    plan.hold(g3)
-                    plan.add("addhip_gemm_f32", g3)
+        c = L.MlpT()
+        c.num_hidden, c.in_dim, c.in_ld, c.head_rows, c.precision, c.rows_cap = n, net.in_dim, net.in_ld, net.head_rows, self.precision, self.rows
+        for i, h in enumerate(net.hidden):
+            c.hidden[i] = h
+            c.W[i], c.b[i], c.gW[i], c.gb[i] = m.p(net.name, f"W{i}"), m.p(net.name, f"b{i}"), m.g(net.name, f"W{i}"), m.g(net.name, f"b{i}")
+            c.h[i], c.dz[i], c.hbits[i] = L.ptr(self.h[i]), L.ptr(self.dz[i]), L.ptr(self.hb[i])
+            if self.storage16:
+                c.W16[i], c.h16[i], c.dz16[i] = m.p16(net.name, f"W{i}"), L.ptr(self.h16[i]), L.ptr(self.dz16[i])
+                if (net.name, f"W{i}") in m._transposed:
+                    c.W16t[i] = m.p16t(net.name, f"W{i}")
+        c.Wh, c.bh, c.gWh, c.gbh = m.p(net.name, "Wh"), m.p(net.name, "bh"), m.g(net.name, "Wh"), m.g(net.name, "bh")
+        if self.slabs is not None:
+            c.slabs, c.slab_floats = L.ptr(self.slabs), self.slabs.numel()
+        if self.aux_slabs is not None:
+            assert self.aux_slabs[0] == n - 1
+            c.slabs_top = L.ptr(self.aux_slabs[1])
+        if self.storage16:
+            offs, rows, cols, cnt = m._net_tables[net.name]
+            c.flat_params, c.flat_trans16, c.flat_count = L.ptr(m.params), L.ptr(m.params16t), m.count
+            import ctypes as C
+            c.t_offset, c.t_rows, c.t_cols, c.t_count = C.cast(offs, C.POINTER(C.c_int64)), C.cast(rows, C.POINTER(C.c_int32)), C.cast(cols, C.POINTER(C.c_int32)), cnt
+        self._c = c
+        return c
+
+    def forward(self, plan, x_ptr, rows, a_mean=None, a_std=None, sign_bits=False, x16_ptr=None):
+        """Record this net's forward pass over `rows` rows into `plan` (addhip_mlp_forward: one GEMM with fused bias + ReLU per layer).
+        sign_bits: also write the ReLU sign bits (a backward pass follows).  x16_ptr: bf16 copy of the input rows (storage16 runners)."""
+        if not hasattr(self, "_c"):
+            self.c_struct()
+        return plan.add("addhip_mlp_forward", self._c, x_ptr, x16_ptr, rows, a_mean, a_std, int(bool(sign_bits)))

@@ -68,19 +68,16 @@ def time_gemms(agent, reps=3):
     import add_gym_amd._lib as L
 
     st = torch.cuda.current_stream()
-    calls = [(fn, args) for name, fn, args in agent._update_plan.calls if name in ("addhip_gemm_f32", "addhip_gemm_grouped")]
-    flops = 0.0
-    for _, args in calls:
-        g = args[0][0] if len(args) == 2 else args[0]          # grouped: (array of equal-shaped problems, count)
-        flops += 2.0 * g.M * g.N * g.K * (args[1] if len(args) == 2 else 1)
+    plan = agent._update_plan  # the recorded optimiser step (addhip_plan_t): GEMM launches are found and replayed one by one through the C ABI
+    calls = [(i, gemms) for i, (name, gemms) in enumerate(plan.launches()) if gemms]
+    flops = sum(2.0 * g.M * g.N * g.K for _, gemms in calls for g in gemms)
     ms = 0.0
     for _ in range(reps):
-        for fn, args in calls:
+        for i, _ in calls:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
-            rc = fn(*args, st.cuda_stream)
+            plan.run(st.cuda_stream, i, i + 1)
             e1.record(st)
-            assert rc == 0
             e1.synchronize()
             ms += e0.elapsed_time(e1)
     ms /= reps

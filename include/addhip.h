@@ -36,8 +36,9 @@ enum { ADDHIP_DONE_NULL = 0, ADDHIP_DONE_FAIL = 1, ADDHIP_DONE_SUCC = 2, ADDHIP_
 
 const char* addhip_last_error(void);
 int addhip_version(void);
-/* sizeof() of addhip_motion_t, task_t, env_t, step_out_t, sampler_t, gemm_t, gather_t, rigid_model_t, rigid_dr_t, optimizer_t (in that order) -> out[0..9];
- * returns the number written (10) or -1.  For bindings to verify their struct layouts against the library they loaded. */
+/* sizeof() of addhip_motion_t, task_t, env_t, step_out_t, sampler_t, gemm_t, gather_t, rigid_model_t, rigid_dr_t, optimizer_t, section_t, mlp_t,
+ * extra_dw_t, mlp_marks_t, ppo_loss_t, ppo_marks_t, disc_loss_t, disc_marks_t (in that order) -> out[0..17]; returns the number written (18) or -1
+ * (count too small).  For bindings to verify their struct layouts against the library they loaded. */
 int addhip_abi_sizes(int32_t* out, int32_t count);
 
 /* ---- reference-motion step tables: MotionLib._step_* (anim/motion_lib.py:285-320) ---- */
@@ -450,6 +451,164 @@ int addhip_optimizer_step(const addhip_optimizer_t* o, void* stream);
 /* ReturnTracker running means over the T steps of an iteration (base_agent.py:596-621):
  * ep_stats [T,3] -> state {episodes, mean_return, mean_ep_len} updated step by step */
 int addhip_return_tracker_fold(const float* ep_stats, int32_t T, float* state, void* stream);
+
+/* ---- recorded plans and multi-stream schedules: the host-side runtime of the update step.
+ *
+ * The reference runs its optimiser step call by call from Python (PPOAgent._update_model / _compute_loss, learning/ppo_agent.py:171-275;
+ * ADDAgent._compute_disc_loss, learning/add/add_agent.py:141-202).  Here a host records the step ONCE and replays it with one call per
+ * stream section, in any language:
+ *
+ *   addhip_plan_create(&p); addhip_plan_record_begin(p);
+ *   ... any stream-taking entry point of this header, called on this thread: its arguments are checked as usual, then the call is
+ *       APPENDED to the plan instead of launched (the stream argument is ignored).  Scalars and device addresses are kept by value;
+ *       every parameter block (addhip_gemm_t, addhip_motion_t, ...) and host-side table is COPIED at record time, so the caller's
+ *       structs need not outlive the call.  The composite entry points below (addhip_mlp_forward, ...) record their launches the same way ...
+ *   addhip_plan_record_end(p);
+ *   addhip_plan_run(p, first, last, stream);      replays calls [first, last) on `stream` (last < 0: to the end)
+ *
+ * A plan holds host memory only (no device allocation, no HIP object); replaying it is exactly the recorded launches, so a replay
+ * is hipGraph-capturable like the calls themselves.  Plans are not thread-safe: record and run a plan from one thread at a time. ---- */
+typedef struct addhip_plan addhip_plan_t;
+int addhip_plan_create(addhip_plan_t** out);
+int addhip_plan_destroy(addhip_plan_t* plan);
+int addhip_plan_record_begin(addhip_plan_t* plan);
+int addhip_plan_record_end(addhip_plan_t* plan);
+/* number of recorded calls (>= 0) */
+int addhip_plan_size(const addhip_plan_t* plan);
+/* introspection (roofline accounting, tools): the entry point's name; for a GEMM launch its problem descriptor(s) -> out[0..n), returns
+ * n (0: not a GEMM; 2-4: a grouped launch) */
+const char* addhip_plan_call_name(const addhip_plan_t* plan, int32_t index);
+int addhip_plan_call_gemms(const addhip_plan_t* plan, int32_t index, addhip_gemm_t* out, int32_t capacity);
+int addhip_plan_run(const addhip_plan_t* plan, int32_t first, int32_t last, void* stream);
+
+/* A schedule runs ranges of a plan on several streams with the event dependencies between them -- one optimiser step of the ADD agent is
+ * eight such sections on four streams -- and tells the host where in the issue order a gradient bucket is final, so that
+ * the host issues its exchange step (RCCL all-reduce) there, on that stream, overlapped with the sections that follow.
+ * Sections are issued in list order:  wait for section `wait_before` (-1: none) -> calls [first, last) on streams[stream] -> wait for
+ * section `wait_after` (-1: none) -> on_bucket(user, bucket, streams[stream]) if bucket >= 0.  Before the first section every stream
+ * is made to wait for what streams[0] holds; after the last, streams[0] waits for all the others.  Only hipEventRecord /
+ * hipStreamWaitEvent are used (events created once, by addhip_schedule_create): capturable. */
+#define ADDHIP_MAX_STREAMS 8
+typedef struct {
+  int32_t stream;            /* index into the streams[] of addhip_schedule_run */
+  int32_t first, last;       /* plan calls [first, last); an empty range is allowed (a bucket that is final without further calls) */
+  int32_t wait_before;       /* index of an EARLIER section this one starts after, or -1 */
+  int32_t wait_after;        /* index of an earlier section whose end this one's bucket / successors also depend on, or -1 */
+  int32_t bucket;            /* >= 0: passed to on_bucket when the section has been issued; -1: none */
+} addhip_section_t;
+typedef struct addhip_schedule addhip_schedule_t;
+typedef void (*addhip_bucket_fn)(void* user, int32_t bucket, void* stream);
+int addhip_schedule_create(const addhip_plan_t* plan, const addhip_section_t* sections, int32_t count, int32_t num_streams, addhip_schedule_t** out);
+int addhip_schedule_destroy(addhip_schedule_t* schedule);
+int addhip_schedule_run(addhip_schedule_t* schedule, void* const* streams, addhip_bucket_fn on_bucket, void* user);
+
+/* ---- composite entry points: the networks' passes and the two loss sections of an optimiser step, assembled by the library from the
+ *      entry points above (no kernels of their own), so that a host in any language runs the measured step without re-deriving its ~70
+ *      launches.  Called with a stream they launch; called between addhip_plan_record_begin / _end they record their launches into the plan.
+ *      Restates PPOModel / ADDModel's Sequential stacks (learning/ppo_model.py:13-59, learning/add/add_model.py:12-46) and the loss /
+ *      backward of PPOAgent._compute_actor_loss / _compute_critic_loss (learning/ppo_agent.py:194-275, base_agent.py:522-546) and
+ *      ADDAgent._compute_disc_loss (learning/add/add_agent.py:141-202, amp_agent.py:177-192). ---- */
+#define ADDHIP_MLP_MAX_HIDDEN 4
+typedef struct {
+  int32_t num_hidden;                     /* Linear+ReLU layers, 1..ADDHIP_MLP_MAX_HIDDEN */
+  int32_t in_dim, in_ld;                  /* input columns / row stride of the input rows (pad columns hold zeros) */
+  int32_t hidden[ADDHIP_MLP_MAX_HIDDEN];  /* layer widths */
+  int32_t head_rows;                      /* rows of the head weight: 32 for the 29-wide action-mean head (zero rows as padding), 1 for a scalar head */
+  int32_t precision;                      /* ADDHIP_PREC_* of this net's GEMMs; ADDHIP_PREC_BF16 = bf16 STORAGE (the *16 buffers below) */
+  /* parameters: W[i] [hidden[i], in_ld | hidden[i-1]] row major, b[i] [hidden[i]], Wh [head_rows, hidden[last]], bh; g* = their gradients */
+  const float* W[ADDHIP_MLP_MAX_HIDDEN]; const float* b[ADDHIP_MLP_MAX_HIDDEN]; const float* Wh; const float* bh;
+  float* gW[ADDHIP_MLP_MAX_HIDDEN]; float* gb[ADDHIP_MLP_MAX_HIDDEN]; float* gWh; float* gbh;
+  /* bf16 storage: W16[i] = bf16(W[i]), same layout; W16t[i] = its transpose [in, out] for every i a dX GEMM or the penalty chain reads */
+  const uint16_t* W16[ADDHIP_MLP_MAX_HIDDEN]; const uint16_t* W16t[ADDHIP_MLP_MAX_HIDDEN];
+  /* caller-allocated workspace for up to rows_cap rows */
+  int32_t rows_cap;
+  float* h[ADDHIP_MLP_MAX_HIDDEN];        /* [rows_cap, hidden[i]] activations (bf16 storage: only the last layer's is written) */
+  float* dz[ADDHIP_MLP_MAX_HIDDEN];       /* [rows_cap, hidden[i]] pre-activation gradients (fp32-operand modes) */
+  uint32_t* hbits[ADDHIP_MLP_MAX_HIDDEN]; /* [rows_cap, ceil(hidden[i]/32)] ReLU sign bits (forward with sign_bits -> backward) */
+  uint16_t* h16[ADDHIP_MLP_MAX_HIDDEN]; uint16_t* dz16[ADDHIP_MLP_MAX_HIDDEN];  /* bf16 storage */
+  float* slabs; int64_t slab_floats;      /* split-K scratch of the weight gradients: 2 * split * out * in floats of the largest layer */
+  float* slabs_top;                       /* optional second scratch: the top layer's weight gradient may then run beside the rest (or NULL) */
+  /* bf16 storage, optional: this net's transposed shadows are rewritten (addhip_shadow_refresh, flat16 = NULL) between its forward and
+   * backward pass, on its own stream.  t_offset / t_rows / t_cols: HOST arrays of t_count entries (copied when recorded). */
+  const float* flat_params; uint16_t* flat_trans16; int64_t flat_count;
+  const int64_t* t_offset; const int32_t* t_rows; const int32_t* t_cols; int32_t t_count;
+} addhip_mlp_t;
+
+/* h[last] = MLP(x) for `rows` rows (<= rows_cap): one GEMM per layer with fused bias + ReLU (+ fused (x - a_mean) / a_std on the first
+ * layer's input when a_mean is given: Normalizer.normalize, normalizer.py:107-110; not with bf16 storage, whose input x16 is the
+ * already normalised rows rounded to bf16).  sign_bits: also write hbits (a backward pass follows). */
+int addhip_mlp_forward(const addhip_mlp_t* net, const float* x, const uint16_t* x16, int64_t rows, const float* a_mean, const float* a_std,
+                       int32_t sign_bits, void* stream);
+
+/* Backward pass through the hidden stack.  In: dz[last] (bf16 storage: dz16[last]) = d loss / d pre-activation of the last hidden layer,
+ * written by the caller (the loss sections below do).  Out: gW[i], gb[i] for every layer.  Weight gradients are split-K GEMMs combined
+ * by addhip_slab_reduce; a layer's bias gradient is the fused column sum of the dX GEMM above it. */
+enum {
+  ADDHIP_BWD_GRADS_ZEROED = 1,   /* the caller zeroed the whole gradient buffer at the start of the step (else each gb is cleared here) */
+  ADDHIP_BWD_TOP_BIAS_DONE = 2,  /* the producer of dz[last] also accumulated gb[last] */
+  ADDHIP_BWD_ACCUMULATE_DW = 4,  /* weight gradients are ADDED to what gW holds (L2 terms written there earlier in the step) */
+  ADDHIP_BWD_TOP_CAST_DONE = 8,  /* bf16 storage: dz16[last] is already written (else it is rounded from dz[last] first) */
+  ADDHIP_BWD_SIGN_BITS = 16      /* the forward pass of this step wrote hbits: masks are read from them */
+};
+typedef struct {                 /* a second product accumulated into a layer's weight gradient: gW += A^T B over `rows` rows */
+  const void* A; int32_t lda; const void* B; int32_t ldb; int64_t rows;   /* fp32, or bf16 with bf16 storage; A == NULL: none */
+} addhip_extra_dw_t;
+typedef struct {                 /* where things are final, as launch counts from this call's first launch (for schedules) */
+  int32_t launches;              /* launches issued by the call */
+  int32_t early;                 /* after this many, every gradient of the net but W[0] / b[0] is final (0 if the net has one layer) */
+  int32_t dw_first[ADDHIP_MLP_MAX_HIDDEN], dw_last[ADDHIP_MLP_MAX_HIDDEN];  /* launches [first, last) form layer i's weight gradient */
+} addhip_mlp_marks_t;
+int addhip_mlp_backward(const addhip_mlp_t* net, const float* x, const uint16_t* x16, int64_t rows, const addhip_extra_dw_t* extra /* [num_hidden] or NULL */,
+                        int32_t flags, addhip_mlp_marks_t* marks /* or NULL */, void* stream);
+
+/* The actor's and the critic's sections of one optimiser step on a gathered minibatch (addhip_gather_minibatch's outputs): forward,
+ * loss heads (addhip_actor_loss; addhip_critic_head), backward.  Needs the flat gradient zeroed (addhip_fill_zero / the zero_grad of
+ * addhip_optimizer_step).  grad_scale = 1 / world size: with it the SUM of the ranks' gradients is their mean. */
+typedef struct {
+  const addhip_mlp_t* actor; const addhip_mlp_t* critic;
+  int32_t rows;                                   /* minibatch rows Mb */
+  const float* norm_obs; const uint16_t* norm_obs16;   /* [Mb, in_ld] normalised observations (+ bf16 copy with bf16 storage) */
+  const float* norm_action;                       /* [Mb, 32] */
+  const float* old_logp; const float* adv; const float* tar_val; const float* rand_mask;   /* [Mb] */
+  float action_std, logp_const, ppo_clip_ratio, action_bound_weight, action_reg_weight, critic_loss_weight, grad_scale;
+  int32_t head_precision;                         /* ADDHIP_PREC_* of the three 32-wide head GEMMs (fp32 operands in every mode) */
+  float* mean; float* d_mean;                     /* workspace [Mb, 32] each */
+  float* dv;                                      /* workspace [Mb] */
+  float* num_valid;                               /* workspace [1] */
+  float* stats;                                   /* [32] loss diagnostics, accumulated over the steps of an iteration (slots: learn.hip) */
+} addhip_ppo_loss_t;
+typedef struct {
+  int32_t launches;                               /* actor's section = launches [0, actor_end), critic's = [actor_end, launches) */
+  int32_t actor_end, actor_early, critic_early;   /* *_early: that net's gradient but its first layer is final (absolute launch counts of this call) */
+} addhip_ppo_marks_t;
+int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks /* or NULL */, void* stream);
+
+/* The discriminator's section: L2 terms (logit regularisation, weight decay) into the zeroed gradient, forward over Mb agent/demo
+ * differences + one zero-difference row, logit loss + head backward, the gradient-penalty chain with its second-order terms
+ * (hand-derived double backward of add_agent.py:166-178; 2-hidden-layer discriminators), backward. */
+typedef struct {
+  const addhip_mlp_t* disc;
+  int32_t rows;                                   /* Mb; the net runs Mb + 1 rows (rows_cap >= Mb + 1) */
+  int32_t disc_dim;                               /* columns of a difference row that carry data (<= disc->in_ld) */
+  const float* norm_diff; const uint16_t* norm_diff16;   /* [Mb + 1, in_ld]; row Mb is all zeros */
+  float loss_scale;                               /* disc_loss_weight * grad_scale */
+  float logit_reg, grad_penalty, weight_decay;
+  float* dlogit;                                  /* workspace [Mb + 1] */
+  float* a2; float* a1; float* g; float* G; float* e1; float* da2;   /* workspace [Mb, hidden[1]] [Mb, hidden[0]] [Mb, in_ld] [Mb, in_ld] [Mb, hidden[0]] [Mb, hidden[1]] */
+  uint16_t* a2_16; uint16_t* a1_16; uint16_t* G16; uint16_t* e1_16;  /* bf16 storage: those four as bf16 instead (a2, a1, G, e1 may then be NULL) */
+  float* stats;
+} addhip_disc_loss_t;
+typedef struct {
+  int32_t launches;
+  int32_t head, chain, backward, top_dw_first, top_dw_last;   /* launch counts at which: the logit loss starts | the penalty chain starts | the
+                                                                  backward pass starts | the top layer's weight-gradient group is [first, last) */
+} addhip_disc_marks_t;
+int addhip_disc_loss_fwd_bwd(const addhip_disc_loss_t* d, addhip_disc_marks_t* marks /* or NULL */, void* stream);
+
+/* The schedule of one optimiser step recorded as  addhip_ppo_loss_fwd_bwd  then  addhip_disc_loss_fwd_bwd  into a plan whose size was
+ * `base` before the first: ten sections on four streams (actor | critic | discriminator x 2), buckets 0 = actor but its first layer,
+ * 1 = critic likewise, 2 = discriminator (the two first layers are final after the join).  -> out[0..10), returns 10. */
+int addhip_update_schedule(int32_t base, const addhip_ppo_marks_t* ppo, const addhip_disc_marks_t* disc, addhip_section_t* out, int32_t capacity);
 
 #ifdef __cplusplus
 }

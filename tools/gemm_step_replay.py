@@ -16,9 +16,10 @@ for r in (ag._run_actor, ag._run_critic, ag._run_disc):
 for k, w in ag._W.items():
     if w.dtype == torch.bfloat16: w.copy_(torch.randn(w.shape, device=w.device))
 st = torch.cuda.current_stream().cuda_stream
-calls = [(fn, args) for name, fn, args in ag._update_plan.calls if name in ("addhip_gemm_f32", "addhip_gemm_grouped")]
+plan = ag._update_plan
+calls = [i for i, (name, gemms) in enumerate(plan.launches()) if gemms]
 print("gemm launches per step:", len(calls))
 for _ in range(3):
-    for fn, args in calls:
-        assert fn(*args, st) == 0
+    for i in calls:
+        plan.run(st, i, i + 1)
 torch.cuda.synchronize()

@@ -17,19 +17,19 @@ st = torch.cuda.current_stream()
 _w = torch.randn(8192, 8192, device="cuda")
 for _ in range(60): _w @ _w
 torch.cuda.synchronize()
-calls = [(fn, args) for name, fn, args in ag._update_plan.calls if name in ("addhip_gemm_f32", "addhip_gemm_grouped")]
+plan = ag._update_plan   # the recorded optimiser step (addhip_plan_t): launches are listed and replayed one by one through the C ABI
+calls = [(i, gemms) for i, (name, gemms) in enumerate(plan.launches()) if gemms]
 tot_ms, tot_fl = 0.0, 0.0
-for i, (fn, args) in enumerate(calls):
-    cnt = args[1] if len(args) == 2 else 1   # grouped launch: (array of equal-shaped problems, count)
-    g = args[0][0] if len(args) == 2 else args[0]
+for n, (i, gemms) in enumerate(calls):
+    cnt, g = len(gemms), gemms[0]   # grouped launch: several equal-shaped problems
     ts = []
     for rep in range(8):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st); assert fn(*args, st.cuda_stream) == 0; e1.record(st); e1.synchronize()
+        e0.record(st); plan.run(st.cuda_stream, i, i + 1); e1.record(st); e1.synchronize()
         ts.append(e0.elapsed_time(e1))
     ms = sorted(ts[1:])[3]
     fl = 2.0 * g.M * g.N * g.K * cnt
     tot_ms += ms; tot_fl += fl
-    print(f"{i:2d} M={g.M:6d} N={g.N:5d} K={g.K:6d} akc={g.a_kcontig} bkc={g.b_kcontig} epi={g.epilogue} split={g.split_k:2d} x{cnt} "
+    print(f"{n:2d} M={g.M:6d} N={g.N:5d} K={g.K:6d} akc={g.a_kcontig} bkc={g.b_kcontig} epi={g.epilogue} split={g.split_k:2d} x{cnt} "
           f"{ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF  {fl/1e9:6.1f} GF", flush=True)
 print(f"sum of isolated launches: {tot_ms:.3f} ms, {tot_fl/1e9:.1f} GFLOP, {tot_fl/tot_ms/1e9:.1f} TFLOP/s")

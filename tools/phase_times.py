@@ -8,7 +8,7 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 engine = sys.argv[3] if len(sys.argv) > 3 else "kinematic"
 graph = sys.argv[4] if len(sys.argv) > 4 else "false"
-extra = sys.argv[5:]   # further config overrides, e.g. agent.group_actor_critic=false
+extra = sys.argv[5:]   # further config overrides, e.g. agent.rollout_graph=true
 ag = ADDAgent(load_config("train", [f"engine={engine}", f"engine.num_envs={N}", f"agent.matmul_precision={prec}", "task.motion_file=synthetic:1x3600",
                                     f"agent.rollout_graph={graph}"] + extra))
 ag.reset_all_envs(); ag._init_train()
