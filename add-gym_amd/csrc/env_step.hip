@@ -696,11 +696,11 @@ inline int env_grid(int num_envs) {
 
 extern "C" int addhip_env_step(const addhip_motion_t* m, const addhip_task_t* t, const addhip_env_t* e,
                                const addhip_step_out_t* o, int32_t head, void* stream) {
-  ADDHIP_RECORDABLE(addhip_env_step, m, t, e, o, head);
   if (int rc = check_common(m, t, e)) return rc;
   ADDHIP_REQUIRE(o, "null outputs");
   ADDHIP_REQUIRE(!o->obs_timeout || o->obs, "obs_timeout needs obs");
   ADDHIP_REQUIRE(head >= 0 && head < ADDHIP_HIST, "head out of range");
+  ADDHIP_RECORDABLE(addhip_env_step, m, t, e, o, head);
   hipStream_t st = (hipStream_t)stream;
   // envs per wave: enough waves to fill the chip (256 CUs x ~24 resident waves) first, then amortise the per-group part
   int epw = e->num_envs / 8192;
@@ -731,12 +731,12 @@ extern "C" int addhip_env_reset(const addhip_motion_t* m, const addhip_task_t* t
                                 const addhip_sampler_t* s, const float* u_clip, const float* u_seg, const float* u_jit,
                                 float* obs_out, float* disc_obs_out, float* disc_demo_out, int32_t reset_all, int32_t head,
                                 void* stream) {
-  ADDHIP_RECORDABLE(addhip_env_reset, m, t, e, s, u_clip, u_seg, u_jit, obs_out, disc_obs_out, disc_demo_out, reset_all, head);
   if (int rc = check_common(m, t, e)) return rc;
   ADDHIP_REQUIRE(s && s->errors && s->seg_size && s->clip_cdf && s->temp_bits, "sampler pointers missing");
   ADDHIP_REQUIRE(s->num_segments > 0 && s->num_segments <= 64, "num_segments must be in 1..64");
   ADDHIP_REQUIRE(u_clip && u_seg && u_jit, "uniform draws missing");
   ADDHIP_REQUIRE(head >= 0 && head < ADDHIP_HIST, "head out of range");
+  ADDHIP_RECORDABLE(addhip_env_reset, m, t, e, s, u_clip, u_seg, u_jit, obs_out, disc_obs_out, disc_demo_out, reset_all, head);
   hipStream_t st = (hipStream_t)stream;
   ADDHIP_HIP(hipMemsetAsync(s->temp_bits, 0, sizeof(uint32_t), st));
   hipLaunchKernelGGL(reset_draw_kernel, dim3((e->num_envs + 255) / 256), dim3(256), 0, st, e->num_envs, m->num_clips, e->done, e->motion_id, *s,

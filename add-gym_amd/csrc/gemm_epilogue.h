@@ -21,6 +21,93 @@ __device__ __forceinline__ unsigned short epi_bf16(float v) {
 // 16-byte stores along the rows (2-byte and 4-byte stores straight from the accumulators cost 4-8x the store instructions,
 // which is what a short-K launch then spends its time on).  The caller has passed a barrier behind the last LDS stage.
 template <int NT> struct EpiBuf { static constexpr int ERS = NT * 128 + 16, WAVE_BYTES = 32 * ERS; };  // bytes per staged row (+ one 16-byte pad), per wave
+
+typedef __bf16 epi_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float epi_f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> one dword of two bf16 (round to nearest even) by the hardware conversion (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned epi_pack_bf16(float lo, float hi) {
+  const epi_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, epi_bf16x2));
+}
+
+// r[lane] = v (v_writelane_b32) through the compiler's own intrinsic, so that it schedules the wait states a v_writelane needs behind the
+// v_cmp that produced its scalar operand (hand-written inline asm gets none and reads a stale mask)
+extern "C" __device__ unsigned addhip_llvm_writelane(unsigned val, unsigned lane, unsigned old) __asm("llvm.amdgcn.writelane.i32");
+
+// The wave's block lies wholly inside C and every output row is 16-byte aligned (all the tiles of this path's layer shapes but a few
+// edge ones): the same epilogue as straight-line code -- no per-element bounds, no alignment fallbacks, no atomics.  The general form
+// below executes ~2000 instructions per wave, which with 16 waves per CU is what a short-K launch took its time for (10-17 us); this
+// one ~600.  Masking is an AND with the sign-extended bit of the lane's column; bf16 results are rounded by v_cvt_pk_bf16_f32.
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue_full(const addhip_gemm_t& g, f32x16 (&acc)[MT][NT], char* ebuf, int lane, int row0, int col0, float* C,
+                                                   unsigned short* C16) {
+  constexpr int ERS = EpiBuf<NT>::ERS;
+  const int li = lane & 31, lh = lane >> 5;
+  const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
+  const bool has_bias = epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU;
+  const bool want_bits = epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits != nullptr;
+  const bool want_cs = epi == ADDHIP_EPI_MASK && g.colsum != nullptr;
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    const int rtile = row0 + a * 32;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int cgroup = col0 + b * 32, col = cgroup + li;
+      const float bias = has_bias ? g.bias[col] : 0.f;
+      // sign-bit word of tile row `lane` (lanes 0..31), fetched once and handed out by readlane (this form is only taken with mask_bits)
+      unsigned mword = 0u;
+      if (epi == ADDHIP_EPI_MASK && lane < 32) mword = g.mask_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)];
+      unsigned rword = 0u;
+      float cs = 0.f;
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int r0 = (x & 3) + 8 * (x >> 2), rloc = r0 + 4 * lh;
+        float v = g.alpha * acc[a][b][x] + bias;
+        if (epi == ADDHIP_EPI_BIAS_RELU) {
+          v = fmaxf(v, 0.f);
+          if (want_bits) {
+            const unsigned long long pos = __ballot(v > 0.f);
+            // rows r0 (lanes 0-31 of the ballot) and r0 + 4 (lanes 32-63): each half goes into the lane that owns that row's word
+            rword = addhip_llvm_writelane((unsigned)pos, r0, rword);
+            rword = addhip_llvm_writelane((unsigned)(pos >> 32), r0 + 4, rword);
+          }
+        }
+        if (epi == ADDHIP_EPI_MASK) {
+          const unsigned w0 = __builtin_amdgcn_readlane(mword, r0), w1 = __builtin_amdgcn_readlane(mword, r0 + 4);
+          const int keep = __builtin_amdgcn_sbfe((int)(lh ? w1 : w0), li, 1);  // 0 or -1: the sign-extended bit of this lane's column
+          v = __uint_as_float(__float_as_uint(v) & (unsigned)keep);
+          cs += v;
+        }
+        *reinterpret_cast<float*>(ebuf + rloc * ERS + (b * 32 + li) * 4) = v;
+      }
+      if (want_bits && lane < 32) g.relu_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)] = rword;
+      if (want_cs) {
+        cs += __shfl_xor(cs, 32, 64);
+        if (lh == 0) atomicAdd(&g.colsum[col], cs);
+      }
+    }
+    if (C) {  // NT*8 lanes x 4 columns per row
+      constexpr int CPR = NT * 8;
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) {
+        const int idx = lane + 64 * i, rloc = idx / CPR, c4 = (idx % CPR) * 4;
+        *reinterpret_cast<float4*>(C + (size_t)(rtile + rloc) * g.ldc + col0 + c4) = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c4 * 4);
+      }
+    }
+    if (C16) {  // NT*4 lanes x 8 columns per row
+      constexpr int CPR = NT * 4;
+#pragma unroll
+      for (int i = 0; i < NT * 2; ++i) {
+        const int idx = lane + 64 * i, rloc = idx / CPR, c8 = (idx % CPR) * 8;
+        const float4 lo = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4);
+        const float4 hi = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4 + 16);
+        *reinterpret_cast<uint4*>(C16 + (size_t)(rtile + rloc) * g.ldc16 + col0 + c8) =
+            make_uint4(epi_pack_bf16(lo.x, lo.y), epi_pack_bf16(lo.z, lo.w), epi_pack_bf16(hi.x, hi.y), epi_pack_bf16(hi.z, hi.w));
+      }
+    }
+  }
+}
+
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&acc)[MT][NT], char* ebuf, int lane, int row0, int col0, int zslab) {
   constexpr int ERS = EpiBuf<NT>::ERS;
@@ -32,6 +119,11 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
   u16* C16 = reinterpret_cast<u16*>(g.C16);
   const bool c_vec = C && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (g.ldc & 3) == 0;
   const bool c16_vec = C16 && (reinterpret_cast<uintptr_t>(C16) & 15) == 0 && (g.ldc16 & 7) == 0;
+  // (wave-uniform) the straight-line form for blocks wholly inside C with aligned rows
+  if (row0 + MT * 32 <= g.M && col0 + NT * 32 <= g.N && !accum && (!C || c_vec) && (!C16 || c16_vec) && (epi != ADDHIP_EPI_MASK || g.mask_bits)) {
+    gemm_epilogue_full<MT, NT, EPI>(g, acc, ebuf, lane, row0, col0, C, C16);
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
     const int rtile = row0 + a * 32;

@@ -331,6 +331,7 @@ class ADDAgent:
             p.add("addhip_head_gemv", L.ptr(ed.h[-1]), hD, hD, rows, m.p("disc", "Wh"), m.p("disc", "bh"), L.ptr(W["logits"]))
             self._disc_eval.append((r0, rows, p))
 
+        s16 = self._storage16
         self._gather_c = L.GatherT(L.ptr(W["perm_idx"]), Mb, L.ptr(B["obs"]), OS, tk.obs_dim, L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(B["action"]),
                                    L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), L.ptr(B["a_logp"]), L.ptr(B["adv"]), L.ptr(B["tar_val"]), L.ptr(B["rand_mask"]),
                                    L.ptr(B["disc_obs"]), L.ptr(B["disc_demo"]), DS, tk.disc_dim, L.ptr(Nm["d_abs"]), 1e-4, L.ptr(W["norm_obs"]),

@@ -94,6 +94,51 @@ def test_env_step_grouped_path_is_identical_to_one_env_per_wave(n_big, vname):
     assert float(o1["ep"][2]) == fin.sum()
 
 
+@pytest.mark.parametrize("n_small", [1, 3, 17])
+def test_env_step_tiny_and_ragged_env_counts_and_refused_calls(n_small):
+    """The smallest launches (one env; counts that fill neither a wave's group nor a workgroup) give, env by env and bit for bit, what the
+    32-env golden launch gives for the same envs; nothing past the last env is touched; calls without envs or tables are refused."""
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import make_task
+
+    v = variant(gload("obs_reward_done"), "default")
+    task = make_task(DEFAULT_TASK, 0.01)
+    mot = HipMotion()
+    n = v["time"].shape[0]
+    pose = pack_pose(v["root_pos"], v["root_rot"], v["dof_pos"])
+    vel = pack_vel(v["root_vel"], v["root_ang_vel"], v["dof_vel"])
+    head = int(v["hist_head"])
+
+    def run(sel, count):
+        # buffers hold len(sel) envs, the launch covers the first `count`
+        st, env = make_env(L, len(sel), pose[sel], vel[sel], v["time"][sel], v["time_off"][sel], v["motion_ids"][sel], fixture_hist(v)[sel], v["contact"][sel])
+        env.num_envs = count
+        o, out = make_out(L, len(sel), task)
+        L.call("addhip_env_step", mot.c, task, env, out, head, L.current_stream())
+        torch.cuda.synchronize()
+        return st, o, env, out
+
+    st0, o0, _, _ = run(np.arange(n), n)
+    sel = np.arange(n)[-(n_small + 2):]  # the last envs of the fixture, two more than the launch covers
+    st1, o1, env, out = run(sel, n_small)
+    at = torch.tensor(sel[:n_small], device="cuda")
+    for k in ("obs", "disc", "demo", "reward", "done", "mid", "mtime"):
+        assert torch.equal(o1[k][:n_small], o0[k][at]), k
+    for k in ("time", "done", "hist", "ref_pose", "ref_vel", "ret_acc", "len_acc"):
+        assert torch.equal(st1[k][:n_small], st0[k][at]), k
+    # the two envs past the launch: untouched (outputs keep their fill value, clocks their input)
+    assert float(o1["obs"][n_small:].min()) == 7.0 and float(o1["disc"][n_small:].min()) == 7.0 and int(o1["done"][n_small:].abs().sum()) == 0
+    assert np.array_equal(st1["time"][n_small:].cpu().numpy(), v["time"][sel][n_small:])
+    lib = L.load()
+    import ctypes as C
+    env.num_envs = 0
+    assert lib.addhip_env_step(C.byref(mot.c), C.byref(task), C.byref(env), C.byref(out), head, None) != 0 and lib.addhip_last_error()
+    env.num_envs = n_small
+    assert lib.addhip_env_step(None, C.byref(task), C.byref(env), C.byref(out), head, None) != 0
+    assert lib.addhip_env_step(C.byref(mot.c), C.byref(task), C.byref(env), C.byref(out), 3, None) != 0  # ring slot out of range
+
+
 def fixture_hist(v, prefix=""):
     return np.concatenate([v[prefix + "hist_root_pos"], v[prefix + "hist_root_rot"], v[prefix + "hist_dof_pos"]], axis=-1).astype(F)
 

@@ -39,7 +39,6 @@ def test_replay_equals_direct_calls_and_ranges_replay_alone():
     g2, rec = calls(Cp, sp)
     for name, args in rec:
         p.add(name, *args)
-    p.compile()
     g2.M = 1  # the plan replays its own copy of the descriptor, taken at record time
     del g2
     assert float(Cp.abs().sum()) == 0.0  # recording launched nothing
@@ -53,10 +52,7 @@ def test_replay_equals_direct_calls_and_ranges_replay_alone():
     p.run(st, 1, 2)
     torch.cuda.synchronize()
     assert torch.allclose(sp, torch.full_like(sp, 0.5 * 2.0 * M)) and float(Cp.min()) == 2.0
-    names = [p._lib.addhip_plan_call_name(p.compile(), i) for i in range(2)]
-    assert names == [b"addhip_gemm_f32", b"addhip_col_sum"]
-    out = (L.GemmT * 1)()
-    assert p._lib.addhip_plan_call_gemms(p.compile(), 0, out, 1) == 1 and (out[0].M, out[0].N, out[0].K) == (M, N, K)
+    assert [(n, [(x.M, x.N, x.K) for x in gs]) for n, gs in p.launches()] == [("addhip_gemm_f32", [(M, N, K)]), ("addhip_col_sum", [])]
 
 
 def test_schedule_orders_sections_across_streams_and_reports_buckets():
@@ -72,7 +68,9 @@ def test_schedule_orders_sections_across_streams_and_reports_buckets():
     p.add("addhip_fill_normal", L.ptr(x), n, 7, 1)                       # 0: x = N(0,1) draws            (stream 0)
     p.add("addhip_col_sum", L.ptr(x), n // 4, 4, 4, L.ptr(z), 1.0, 0)    # 1: z = column sums of x[n/4,4] (stream 1, after section 0)
     p.add("addhip_fill_zero", L.ptr(x), n)                               # 2: x = 0                       (stream 0, after section 1)
-    sched = Schedule(p, [(0, 0, 1, "a", None, None), (1, 1, 2, "b", 0, None), (0, 2, 3, None, 1, None), (0, 3, 3, "c", None, 1)], 2)
+    S = L.SectionT   # {stream, first, last, wait_before, wait_after, bucket}
+    secs = (S * 4)(S(0, 0, 1, -1, -1, 0), S(1, 1, 2, 0, -1, 1), S(0, 2, 3, 1, -1, -1), S(0, 3, 3, -1, 1, 2))
+    sched = Schedule(p, secs, 2, buckets=["a", "b", "c"])
     seen = []
     for _ in range(3):  # replays reuse the schedule's events
         seen.clear()
