@@ -57,7 +57,7 @@ class GemmT(C.Structure):
                 ("bias", f32p), ("mask", f32p), ("ldmask", C.c_int32), ("a_mean", f32p), ("a_std", f32p), ("split_k", C.c_int32),
                 ("alpha", C.c_float), ("colsum", f32p), ("precision", C.c_int32),
                 ("relu_bits", f32p), ("mask_bits", f32p), ("ldbits", C.c_int32), ("accumulate", C.c_int32),
-                ("operands_bf16", C.c_int32), ("C16", f32p), ("ldc16", C.c_int32), ("hint", C.c_int32)]
+                ("operands_bf16", C.c_int32), ("C16", f32p), ("ldc16", C.c_int32), ("hint", C.c_int32), ("colsum_replicas", C.c_int32), ("ldcs", C.c_int32)]
 
 
 class GatherT(C.Structure):
@@ -98,7 +98,8 @@ class MlpT(C.Structure):
     _fields_ = [("num_hidden", C.c_int32), ("in_dim", C.c_int32), ("in_ld", C.c_int32), ("hidden", C.c_int32 * _H), ("head_rows", C.c_int32), ("precision", C.c_int32),
                 ("W", f32p * _H), ("b", f32p * _H), ("Wh", f32p), ("bh", f32p), ("gW", f32p * _H), ("gb", f32p * _H), ("gWh", f32p), ("gbh", f32p),
                 ("W16", f32p * _H), ("W16t", f32p * _H), ("rows_cap", C.c_int32), ("h", f32p * _H), ("dz", f32p * _H), ("hbits", f32p * _H), ("h16", f32p * _H),
-                ("dz16", f32p * _H), ("slabs", f32p), ("slab_floats", C.c_int64), ("slabs_top", f32p), ("flat_params", f32p), ("flat_trans16", f32p),
+                ("dz16", f32p * _H), ("slabs", f32p), ("slab_floats", C.c_int64), ("slabs_top", f32p), ("bias_replicas", f32p), ("bias_replica_rows", C.c_int32),
+                ("flat_params", f32p), ("flat_trans16", f32p),
                 ("flat_count", C.c_int64), ("t_offset", C.POINTER(C.c_int64)), ("t_rows", C.POINTER(C.c_int32)), ("t_cols", C.POINTER(C.c_int32)), ("t_count", C.c_int32)]
 
 
@@ -158,6 +159,7 @@ SIGNATURES = {
     "addhip_to_bf16_t": [vp, vp, i32, i32, i32, i32, vp],
     "addhip_shadow_refresh": [vp, vp, vp, i64, vp, vp, vp, i32, vp],
     "addhip_slab_reduce": [vp, i32, i64, vp, i64, f32, i32, vp],
+    "addhip_slab_reduce_pair": [vp, i32, i64, vp, i64, f32, i32, vp, i32, i32, vp, i32, i32, i32, vp],
     "addhip_col_sum": [vp, i32, i32, i32, vp, f32, i32, vp],
     "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp],
     "addhip_fill_normal": [vp, i64, u64, u64, vp],

@@ -340,6 +340,43 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(const float4* in, int
   }
 }
 
+// addhip_slab_reduce_pair: blockIdx.y == 0 the slab reduction (float4 form), == 1 the replica rows -> out2, read and cleared
+__global__ __launch_bounds__(256) void slab_reduce_pair_kernel(const float4* in, int slabs, long long stride4, float4* out, long long count4, float scale, int accumulate,
+                                                               float* in2, int rows2, int ld2, float* out2, int count2, int accumulate2, int clear2) {
+  if (blockIdx.y == 0) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < count4; i += step) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      int k = 0;
+      for (; k + 4 <= slabs; k += 4) {  // (the summation order of slab_reduce4_kernel)
+        const float4 a = in[k * stride4 + i], b = in[(k + 1) * stride4 + i], c = in[(k + 2) * stride4 + i], d = in[(k + 3) * stride4 + i];
+        s.x = ((s.x + a.x) + b.x) + c.x + d.x; s.y = ((s.y + a.y) + b.y) + c.y + d.y;
+        s.z = ((s.z + a.z) + b.z) + c.z + d.z; s.w = ((s.w + a.w) + b.w) + c.w + d.w;
+      }
+      for (; k < slabs; ++k) {
+        const float4 a = in[k * stride4 + i];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      }
+      s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
+      if (accumulate) {
+        const float4 o = out[i];
+        s.x = o.x + s.x; s.y = o.y + s.y; s.z = o.z + s.z; s.w = o.w + s.w;
+      }
+      out[i] = s;
+    }
+    return;
+  }
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < count2; n += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < rows2; ++r) {
+      s += in2[(size_t)r * ld2 + n];
+      if (clear2) in2[(size_t)r * ld2 + n] = 0.f;
+    }
+    out2[n] = accumulate2 ? out2[n] + s : s;
+  }
+}
+
 // column sums of a row-major [M,N] matrix: each block reduces a 64-column strip over a slice of rows
 // into an LDS tile, then one atomicAdd per column per block (out must be pre-scaled/zeroed by the caller
 // when accumulate==0: handled in the wrapper with a memset)
@@ -388,6 +425,7 @@ int validate(addhip_gemm_t& g) {
   if (g.accumulate) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_NONE && !g.colsum, "gemm: accumulate takes no epilogue");
   if (g.a_mean || g.a_std) ADDHIP_REQUIRE(g.a_kcontig && g.a_mean && g.a_std, "gemm: fused normalisation needs a k-contiguous A and both mean/std");
   if (g.colsum) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && g.split_k <= 1, "gemm: colsum needs the MASK epilogue");
+  if (g.colsum_replicas > 1) ADDHIP_REQUIRE(g.colsum && g.ldcs >= g.N && g.colsum_replicas <= 64, "gemm: colsum_replicas (2..64) need colsum and ldcs >= N");
   ADDHIP_REQUIRE(g.precision == ADDHIP_PREC_F32 || g.precision == ADDHIP_PREC_BF16 || g.precision == ADDHIP_PREC_BF16X2 ||
                      g.precision == ADDHIP_PREC_BF16X3, "gemm: bad precision");
   ADDHIP_REQUIRE(g.C || g.split_k <= 1, "gemm: split-K slabs are fp32 (C)");
@@ -514,6 +552,22 @@ extern "C" int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_s
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, slabs, (long long)slab_stride, out,
                      (long long)count, scale, accumulate);
   return addhip::check_launch("slab_reduce_kernel");
+}
+
+extern "C" int addhip_slab_reduce_pair(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count, float scale, int32_t accumulate,
+                                       float* in2, int32_t rows2, int32_t ld2, float* out2, int32_t count2, int32_t accumulate2, int32_t clear2, void* stream) {
+  ADDHIP_REQUIRE(in && out && slabs > 0 && count > 0, "slab_reduce_pair: bad arguments");
+  ADDHIP_REQUIRE(count % 4 == 0 && slab_stride % 4 == 0 && aligned16(in) && aligned16(out), "slab_reduce_pair: the slab reduction takes 16-byte aligned buffers, count and stride %% 4 == 0");
+  ADDHIP_REQUIRE(in2 && out2 && rows2 > 0 && rows2 <= 64 && count2 > 0 && ld2 >= count2, "slab_reduce_pair: bad second reduction");
+  ADDHIP_RECORDABLE(addhip_slab_reduce_pair, in, slabs, slab_stride, out, count, scale, accumulate, in2, rows2, ld2, out2, count2, accumulate2, clear2);
+  long long b4 = (count / 4 + 255) / 256;
+  if (b4 > 2048) b4 = 2048;
+  const long long b2 = (count2 + 255) / 256;
+  if (b4 < b2) b4 = b2;
+  hipLaunchKernelGGL(slab_reduce_pair_kernel, dim3((unsigned)b4, 2), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(in), slabs,
+                     (long long)slab_stride / 4, reinterpret_cast<float4*>(out), (long long)count / 4, scale, accumulate, in2, rows2, ld2, out2, count2, accumulate2,
+                     clear2);
+  return addhip::check_launch("slab_reduce_pair_kernel");
 }
 
 extern "C" int addhip_fill_zero(float* p, int64_t count, void* stream) {

@@ -22,6 +22,11 @@ __device__ __forceinline__ unsigned short epi_bf16(float v) {
 // which is what a short-K launch then spends its time on).  The caller has passed a barrier behind the last LDS stage.
 template <int NT> struct EpiBuf { static constexpr int ERS = NT * 128 + 16, WAVE_BYTES = 32 * ERS; };  // bytes per staged row (+ one 16-byte pad), per wave
 
+// offset of the colsum row a 32-row block adds to (addhip_gemm_t.colsum_replicas: same-line float atomics of all row tiles serialise)
+__device__ __forceinline__ size_t epi_cs_row(const addhip_gemm_t& g, int rtile) {
+  return g.colsum_replicas > 1 ? (size_t)((rtile >> 5) % g.colsum_replicas) * (size_t)g.ldcs : (size_t)0;
+}
+
 typedef __bf16 epi_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float epi_f32x2 __attribute__((ext_vector_type(2)));
 // two fp32 -> one dword of two bf16 (round to nearest even) by the hardware conversion (v_cvt_pk_bf16_f32)
@@ -83,7 +88,7 @@ __device__ __forceinline__ void gemm_epilogue_full(const addhip_gemm_t& g, f32x1
       if (want_bits && lane < 32) g.relu_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)] = rword;
       if (want_cs) {
         cs += __shfl_xor(cs, 32, 64);
-        if (lh == 0) atomicAdd(&g.colsum[col], cs);
+        if (lh == 0) atomicAdd(&g.colsum[epi_cs_row(g, rtile) + col], cs);
       }
     }
     if (C) {  // NT*8 lanes x 4 columns per row
@@ -163,7 +168,7 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
         g.relu_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)] = rword;
       if (epi == ADDHIP_EPI_MASK && g.colsum) {
         cs += __shfl_xor(cs, 32, 64);
-        if (lh == 0 && col_ok) atomicAdd(&g.colsum[col], cs);
+        if (lh == 0 && col_ok) atomicAdd(&g.colsum[epi_cs_row(g, rtile) + col], cs);
       }
     }
     if (C) {  // NT*8 lanes x 4 columns per row

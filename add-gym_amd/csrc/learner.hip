@@ -161,7 +161,14 @@ int backward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64
       LAUNCH(addhip_gemm_f32(&g, stream));
       total = 2 * s;
     }
-    LAUNCH(addhip_slab_reduce(slabs, total, slab, net.gW[i], slab, 1.0f, (flags & ADDHIP_BWD_ACCUMULATE_DW) ? 1 : 0, stream));
+    // the combine of this layer's weight gradient; with it (replicated bias sums) the bias gradient the dX GEMM above left spread over the
+    // replica rows -- summed into gb[i] and cleared for the next step in the same launch
+    const bool reps = net.bias_replicas && net.bias_replica_rows > 1;
+    if (reps && i < n - 1 && slab % 4 == 0)
+      LAUNCH(addhip_slab_reduce_pair(slabs, total, slab, net.gW[i], slab, 1.0f, (flags & ADDHIP_BWD_ACCUMULATE_DW) ? 1 : 0, net.bias_replicas, net.bias_replica_rows,
+                                     out_d, net.gb[i], out_d, 1, 1, stream));
+    else
+      LAUNCH(addhip_slab_reduce(slabs, total, slab, net.gW[i], slab, 1.0f, (flags & ADDHIP_BWD_ACCUMULATE_DW) ? 1 : 0, stream));
     if (marks) marks->dw_last[i] = launches - base;
     // every gradient of this net except W[0] / b[0] is final here (b[1] came with the dX GEMM of layer 2, the head's with the loss
     // kernels): an early bucket for the data-parallel exchange
@@ -182,6 +189,12 @@ int backward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64
                                      prev_d, ADDHIP_EPI_MASK);
         ADDHIP_REQUIRE(!s16 || net.W16t[i], "mlp_backward: layer %d lacks its transposed bf16 shadow", i);
         g.colsum = net.gb[i - 1];
+        // (the big row chunk only: a few-row chunk adds straight to gb, which the paired combine of layer i-1 then adds the replicas to)
+        if (reps && cnt > 8 && ((int64_t)net.hidden[i - 1] * (i - 1 == 0 ? net.in_ld : net.hidden[i - 2])) % 4 == 0) {
+          g.colsum = net.bias_replicas;
+          g.colsum_replicas = net.bias_replica_rows;
+          g.ldcs = prev_d;
+        }
         set_prec(g, net);
         if (s16) {
           g.C16 = net.dz16[i - 1] + r0 * prev_d;

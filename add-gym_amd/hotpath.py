@@ -82,7 +82,8 @@ PRECISIONS = {"fp32": L.PREC_F32, "f32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "b
 
 
 def gemm(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, epilogue=L.EPI_NONE, bias=None, mask=None, ldmask=0, a_mean=None, a_std=None,
-         split_k=1, alpha=1.0, colsum=None, precision=L.PREC_F32, relu_bits=None, mask_bits=None, ldbits=0, accumulate=0, operands_bf16=0, C16=None, ldc16=0, hint=0):
+         split_k=1, alpha=1.0, colsum=None, precision=L.PREC_F32, relu_bits=None, mask_bits=None, ldbits=0, accumulate=0, operands_bf16=0, C16=None, ldc16=0, hint=0,
+         colsum_replicas=0, ldcs=0):
     """Descriptor for addhip_gemm_f32: C[M,N] = alpha * sum_k A(m,k) B(n,k).  Pointers are raw addresses."""
     return L.GemmT(M, N, K, A, lda, int(a_kc), B, ldb, int(b_kc), C, ldc, epilogue, bias, mask, ldmask, a_mean, a_std, split_k, alpha, colsum,
-                   precision, relu_bits, mask_bits, ldbits, int(accumulate), int(operands_bf16), C16, ldc16, int(hint))
+                   precision, relu_bits, mask_bits, ldbits, int(accumulate), int(operands_bf16), C16, ldc16, int(hint), int(colsum_replicas), int(ldcs))

@@ -360,6 +360,9 @@ class NetRunner:
         self.hb = [torch.zeros(rows, (h + 31) // 32, dtype=torch.int32, device=device) for h in net.hidden]
         self.h = [torch.zeros(rows, h, device=device) for h in net.hidden]
         self.dz = [torch.zeros(rows, h, device=device) for h in net.hidden]
+        # bias-gradient column sums of the dX GEMMs, spread over 16 rows (same-line float atomics of all row tiles serialise otherwise);
+        # summed into the gradient and cleared by the split-K combine that follows (addhip_slab_reduce_pair)
+        self.bias_rep = torch.zeros(16, max(net.hidden), device=device) if slabs is not None else None
 
     def c_struct(self):
         """addhip_mlp_t over this runner's buffers (include/addhip.h, "composite entry points")."""
@@ -381,6 +384,8 @@ class NetRunner:
         if self.aux_slabs is not None:
             assert self.aux_slabs[0] == n - 1
             c.slabs_top = L.ptr(self.aux_slabs[1])
+        if self.bias_rep is not None:
+            c.bias_replicas, c.bias_replica_rows = L.ptr(self.bias_rep), self.bias_rep.shape[0]
         if self.storage16:
             offs, rows, cols, cnt = m._net_tables[net.name]
             c.flat_params, c.flat_trans16, c.flat_count = L.ptr(m.params), L.ptr(m.params16t), m.count

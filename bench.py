@@ -61,26 +61,32 @@ def traffic(key):
         return None, None
 
 
-def time_gemms(agent, reps=3):
-    """Average duration of the gemm_kernel launches of one optimiser step, each bracketed by HIP events recorded on the
-    stream the kernel is launched on (torch's current stream == the stream handed to the C ABI)."""
+def time_gemms(agent, reps=10, warm=5):
+    """Duration of the GEMM launches of one optimiser step: every launch of the recorded step (addhip_plan_t) replayed alone through the C
+    ABI, in plan order, bracketed by HIP events recorded on the stream the kernel is launched on (torch's current stream == the stream
+    handed to the C ABI).  `warm` untimed replays first (an idle chip's clocks ramp over the first milliseconds of load), then `reps` timed
+    ones; a launch's duration is its median over the replays, the step's figure their sum."""
+    import statistics
     import torch
-    import add_gym_amd._lib as L
 
     st = torch.cuda.current_stream()
-    plan = agent._update_plan  # the recorded optimiser step (addhip_plan_t): GEMM launches are found and replayed one by one through the C ABI
+    plan = agent._update_plan
     calls = [(i, gemms) for i, (name, gemms) in enumerate(plan.launches()) if gemms]
     flops = sum(2.0 * g.M * g.N * g.K for _, gemms in calls for g in gemms)
-    ms = 0.0
-    for _ in range(reps):
+    for _ in range(warm):
         for i, _ in calls:
+            plan.run(st.cuda_stream, i, i + 1)
+    torch.cuda.synchronize()
+    per_launch = [[] for _ in calls]
+    for _ in range(reps):
+        for n, (i, _) in enumerate(calls):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             plan.run(st.cuda_stream, i, i + 1)
             e1.record(st)
             e1.synchronize()
-            ms += e0.elapsed_time(e1)
-    ms /= reps
+            per_launch[n].append(e0.elapsed_time(e1))
+    ms = sum(statistics.median(t) for t in per_launch)
     return dict(launches=len(calls), flops=flops, ms=ms)
 
 

@@ -261,6 +261,12 @@ typedef struct {
    * of its choices for measurements and tests (tools/gemm_*_one.py, tests/test_hip_gemm.py); the result is the same either way.
    * No process environment variable influences kernel selection. */
   int32_t hint;
+  /* colsum_replicas R > 1: `colsum` points at R rows of ldcs floats and the column sums of a 32-row block of C are added to row
+   * (block index % R).  All row tiles of a launch add to the same N floats otherwise, and same-line float atomics serialise in the memory
+   * system (~45 ns each: 6-8 us of a 16384-row launch); R = 16 removes that.  The rows are summed -- and cleared -- by
+   * addhip_slab_reduce_pair.  0 / 1: plain colsum[N]. */
+  int32_t colsum_replicas;
+  int32_t ldcs;
 } addhip_gemm_t;
 enum {
   ADDHIP_GEMM_HINT_BIG_TILE = 1,     /* bf16 operands: the 256x256 ring kernel on eligible shapes (M, N multiples of 256, K of 64) */
@@ -295,6 +301,11 @@ int addhip_shadow_refresh(const float* params, uint16_t* flat16, uint16_t* trans
 /* out[n] (+)= scale * sum over `slabs` of in[s*slab_stride + n]  (split-K combine, grads) */
 int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count,
                        float scale, int32_t accumulate, void* stream);
+/* Two reductions in one launch: the first exactly addhip_slab_reduce; the second  out2[n] (+)= sum over rows2 rows of in2[r*ld2 + n]  for
+ * n < count2, after which (clear2 != 0) the rows of in2 are zeroed -- the replicated bias-gradient column sums of a dX GEMM
+ * (addhip_gemm_t.colsum_replicas), folded into the split-K combine of the layer below that follows it in every backward pass. */
+int addhip_slab_reduce_pair(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count, float scale, int32_t accumulate,
+                            float* in2, int32_t rows2, int32_t ld2, float* out2, int32_t count2, int32_t accumulate2, int32_t clear2, void* stream);
 /* out[n] (+)= scale * sum_m X[m*ld+n]   (bias gradients) */
 int addhip_col_sum(const float* X, int32_t M, int32_t N, int32_t ld, float* out, float scale,
                    int32_t accumulate, void* stream);
@@ -528,6 +539,9 @@ typedef struct {
   uint16_t* h16[ADDHIP_MLP_MAX_HIDDEN]; uint16_t* dz16[ADDHIP_MLP_MAX_HIDDEN];  /* bf16 storage */
   float* slabs; int64_t slab_floats;      /* split-K scratch of the weight gradients: 2 * split * out * in floats of the largest layer */
   float* slabs_top;                       /* optional second scratch: the top layer's weight gradient may then run beside the rest (or NULL) */
+  /* optional: bias_replica_rows (16) x max(hidden) floats, ZERO at the first use (the library leaves them zero): the dX GEMMs add their
+   * bias-gradient column sums there, spread over the rows, and the split-K combine that follows sums them into gb (NULL: plain atomics on gb) */
+  float* bias_replicas; int32_t bias_replica_rows;
   /* bf16 storage, optional: this net's transposed shadows are rewritten (addhip_shadow_refresh, flat16 = NULL) between its forward and
    * backward pass, on its own stream.  t_offset / t_rows / t_cols: HOST arrays of t_count entries (copied when recorded). */
   const float* flat_params; uint16_t* flat_trans16; int64_t flat_count;

@@ -505,3 +505,52 @@ def test_gemm_bf16_storage_stage_configurations(a_kc, b_kc, hint):
     if not a_kc and not b_kc:
         run_gemm_bf16(1024, 272, 16385 + 7, 0, 0, split_k=22, hint=hint)
         run_gemm_bf16(1024, 1024, 16384, 0, 0, split_k=8, hint=hint)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_replicated_column_sums_and_the_paired_combine(bf16):
+    """addhip_gemm_t.colsum_replicas: the MASK epilogue's bias-gradient column sums spread over 16 rows (block index % 16) add up to the plain
+    colsum; addhip_slab_reduce_pair sums the rows into the gradient, clears them, and does the split-K combine of its first job exactly
+    like addhip_slab_reduce (ragged M: the last row tile takes the general epilogue, the others the straight-line one)."""
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import gemm
+
+    M, N, K, R = 16384 + 40, 512, 128, 16
+    rng = np.random.RandomState(11)
+    A, W = rng.uniform(-1, 1, (M, K)).astype(F), rng.uniform(-1, 1, (N, K)).astype(F)
+    bits = torch.tensor(rng.randint(-2**31, 2**31 - 1, (M, N // 32)), dtype=torch.int32, device="cuda")
+    if bf16:
+        dA, dW = torch.tensor(A).to(torch.bfloat16).cuda(), torch.tensor(W).to(torch.bfloat16).cuda()
+        kw = dict(precision=L.PREC_BF16, operands_bf16=1)
+    else:
+        dA, dW, kw = T(A), T(W), {}
+    st = L.current_stream()
+    out1, out2 = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda")
+    cs_plain, reps = torch.zeros(N, device="cuda"), torch.zeros(R, N, device="cuda")
+    L.call("addhip_gemm_f32", gemm(M, N, K, L.ptr(dA), K, 1, L.ptr(dW), K, 1, L.ptr(out1), N, 3, mask_bits=L.ptr(bits), ldbits=N // 32, colsum=L.ptr(cs_plain), **kw), st)
+    L.call("addhip_gemm_f32", gemm(M, N, K, L.ptr(dA), K, 1, L.ptr(dW), K, 1, L.ptr(out2), N, 3, mask_bits=L.ptr(bits), ldbits=N // 32, colsum=L.ptr(reps),
+                                   colsum_replicas=R, ldcs=N, **kw), st)
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2)
+    want = out1.double().sum(0)
+    assert float(reps.abs().min(1).values.max()) > 0  # every replica row received sums
+    torch.testing.assert_close(reps.double().sum(0), want, rtol=1e-5, atol=1e-2)
+    torch.testing.assert_close(cs_plain.double(), want, rtol=1e-5, atol=1e-2)
+    # row r of the replicas = the column sums of the 32-row blocks with index % 16 == r
+    blk = torch.arange(M, device="cuda") // 32 % R
+    for r in (0, 5, 15):
+        torch.testing.assert_close(reps[r].double(), out1[blk == r].double().sum(0), rtol=1e-5, atol=1e-2)
+    # the paired combine: job 1 == addhip_slab_reduce, job 2 sums and clears the replica rows
+    slabs = T(rng.standard_normal((6, 4096)).astype(F))
+    o_ref, o_pair = torch.ones(4096, device="cuda"), torch.ones(4096, device="cuda")
+    gb = torch.full((N,), 2.0, device="cuda")
+    L.call("addhip_slab_reduce", L.ptr(slabs), 6, 4096, L.ptr(o_ref), 4096, 0.5, 1, st)
+    L.call("addhip_slab_reduce_pair", L.ptr(slabs), 6, 4096, L.ptr(o_pair), 4096, 0.5, 1, L.ptr(reps), R, N, L.ptr(gb), N, 1, 1, st)
+    torch.cuda.synchronize()
+    assert torch.equal(o_pair, o_ref)
+    torch.testing.assert_close(gb.double(), 2.0 + want, rtol=1e-5, atol=1e-2)
+    assert float(reps.abs().max()) == 0.0
+    lib = L.load()
+    assert lib.addhip_gemm_f32(gemm(M, N, K, L.ptr(dA), K, 1, L.ptr(dW), K, 1, L.ptr(out2), N, 3, mask_bits=L.ptr(bits), ldbits=N // 32, colsum=L.ptr(reps),
+                                    colsum_replicas=R, ldcs=N - 4, **kw), st) != 0  # rows of the replicas shorter than N
