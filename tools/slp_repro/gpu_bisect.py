@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CSRC = os.path.join(ROOT, "add-gym_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 BASE = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wno-unused-function"]
-OTHERS = [os.path.join(CSRC, f) for f in ("capi.o", "env_step.o", "gemm.o", "gemm_split.o", "gemm_bf16.o", "learn.o")]
+OTHERS = [os.path.join(CSRC, f) for f in ("capi.o", "plan.o", "learner.o", "env_step.o", "gemm.o", "gemm_split.o", "gemm_bf16.o", "learn.o")]
 
 # Stage 2: the default -O3 build (SLP on: wrong) with ONE region of rigid_step4_kernel fenced off from the vectorizer -- an empty
 # `asm volatile` on the values that leave the region makes them opaque, so no SLP tree can span it.  (text anchor in rigid.hip,
