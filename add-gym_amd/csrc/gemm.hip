@@ -460,13 +460,14 @@ int dispatch_f32(const addhip_gemm_t& g, hipStream_t st) {
     else hipLaunchKernelGGL(gemm_small_m_kernel<false>, dim3((g.N + 31) / 32), dim3(256), 0, st, g);
     return addhip::check_launch("gemm_small_m_kernel");
   }
-  if (g.N <= 32) return launch_cfg<128, 32, 4, 1, 16>(g, st);
-  if (g.N <= 64) return launch_cfg<128, 64, 2, 2, 16>(g, st);
+  // (32-deep K tiles for these latency-bound launches: 16-deep 26 / 38 us for the actor head's forward / weight gradient, 32-deep 18 / 27, 64-deep 19 / 31)
+  if (g.N <= 32) return launch_cfg<128, 32, 4, 1, 32>(g, st);
+  if (g.N <= 64) return launch_cfg<128, 64, 2, 2, 32>(g, st);
   // keep >= ~1 block per CU on the skinny rollout shapes
   const long long tiles128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
   // the bf16-MFMA paths pay off from half a chip of 128x128 tiles (measured: 16384x128x1024 77 -> 53 us, 4096x512x1024 64 -> 50 us)
   if (g.precision != ADDHIP_PREC_F32 && tiles128 >= 128 && tiles128 <= 256) return addhip::gemm_split_dispatch(g, g.precision, st);
-  if (tiles128 <= 256) return launch_cfg<64, 128, 2, 2, 16>(g, st);  // (a bare chip of 128x128 tiles = one 4-wave workgroup per CU: two 64x128 ones overlap better)
+  if (tiles128 <= 256) return launch_cfg<64, 128, 2, 2, 32>(g, st);  // (a bare chip of 128x128 tiles = one 4-wave workgroup per CU: two 64x128 ones overlap better)
   // N just past a multiple of 96 but far from one of 128 (the 272-wide first-layer weight gradient): 96-wide tiles waste
   // 6 % of their columns instead of 29 %
   const int waste128 = (g.N + 127) / 128 * 128 - g.N, waste96 = (g.N + 95) / 96 * 96 - g.N;

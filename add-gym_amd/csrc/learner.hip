@@ -164,7 +164,7 @@ int backward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64
     // the combine of this layer's weight gradient; with it (replicated bias sums) the bias gradient the dX GEMM above left spread over the
     // replica rows -- summed into gb[i] and cleared for the next step in the same launch
     const bool reps = net.bias_replicas && net.bias_replica_rows > 1;
-    if (reps && i < n - 1 && slab % 4 == 0)
+    if (reps && (i < n - 1 || (flags & ADDHIP_BWD_TOP_BIAS_REPLICAS)) && slab % 4 == 0)
       LAUNCH(addhip_slab_reduce_pair(slabs, total, slab, net.gW[i], slab, 1.0f, (flags & ADDHIP_BWD_ACCUMULATE_DW) ? 1 : 0, net.bias_replicas, net.bias_replica_rows,
                                      out_d, net.gb[i], out_d, 1, 1, stream));
     else
@@ -247,6 +247,8 @@ extern "C" int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_ma
   const int nA = A.num_hidden, nC = Cn.num_hidden, hA = A.hidden[nA - 1], hC = Cn.hidden[nC - 1];
   ADDHIP_REQUIRE(32LL * 32 * hA <= A.slab_floats, "ppo_loss_fwd_bwd: the actor's split-K scratch is smaller than its head gradient's 32 slabs");
   const int bwd = ADDHIP_BWD_GRADS_ZEROED | ADDHIP_BWD_TOP_BIAS_DONE | ADDHIP_BWD_TOP_CAST_DONE | ADDHIP_BWD_SIGN_BITS;
+  // the actor's top bias gradient comes as column sums of the head's dz GEMM: replicated like the dX GEMMs' (same-line atomics serialise)
+  const bool top_reps = A.bias_replicas && A.bias_replica_rows > 1 && ((int64_t)hA * (nA > 1 ? A.hidden[nA - 2] : A.in_ld)) % 4 == 0;
   int launches = 0;
   addhip_mlp_marks_t mk;
   // ---- actor (ppo_agent.py:194-232, 247-275)
@@ -271,6 +273,11 @@ extern "C" int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_ma
   {  // dz[last] = (d_mean Wh) * relu'(h[last]); bf16 storage: written as bf16 directly
     addhip_gemm_t g = gemm(Mb, hA, 32, d->d_mean, 32, 1, A.Wh, hA, 0, s16 ? nullptr : A.dz[nA - 1], hA, ADDHIP_EPI_MASK);
     g.colsum = A.gb[nA - 1];
+    if (top_reps) {  // spread over the replica rows like the dX GEMMs' sums; the top layer's combine folds them into gb[last]
+      g.colsum = A.bias_replicas;
+      g.colsum_replicas = A.bias_replica_rows;
+      g.ldcs = hA;
+    }
     g.precision = d->head_precision;
     if (s16) {
       g.C16 = A.dz16[nA - 1];
@@ -280,7 +287,7 @@ extern "C" int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_ma
     LAUNCH(addhip_gemm_f32(&g, stream));
   }
   int at = launches;
-  if (int rc = backward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, bwd, &mk, launches, stream)) return rc;
+  if (int rc = backward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, bwd | (top_reps ? ADDHIP_BWD_TOP_BIAS_REPLICAS : 0), &mk, launches, stream)) return rc;
   const int actor_early = at + mk.early, actor_end = launches;
   // ---- critic (ppo_agent.py:234-245, base_agent.py:522-546)
   if (int rc = forward(Cn, d->norm_obs, d->norm_obs16, Mb, nullptr, nullptr, true, launches, stream)) return rc;

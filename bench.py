@@ -370,6 +370,8 @@ def main():
                             "frac": gbs2 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src, "us_per_launch": ms2 * 1e3, "envs": big,
                             "motion_library": motion, "step_tables_mb": table_mb}
             out["roofline_rigid_step"] = rigid_step_roofline(a.envs)
+            # (one wave per CU at the headline's env count; the same kernel with the chip full -- the register form, four waves per CU)
+            out["roofline_rigid_step_65536"] = rigid_step_roofline(65536)
     steps_per_iter = agent.T
     if a.precision == "fp32" and not a.no_alt:
         # Same workload with the bf16-MFMA product modes of addhip_gemm_f32 (operands, results and every other kernel stay fp32;

@@ -562,7 +562,8 @@ enum {
   ADDHIP_BWD_TOP_BIAS_DONE = 2,  /* the producer of dz[last] also accumulated gb[last] */
   ADDHIP_BWD_ACCUMULATE_DW = 4,  /* weight gradients are ADDED to what gW holds (L2 terms written there earlier in the step) */
   ADDHIP_BWD_TOP_CAST_DONE = 8,  /* bf16 storage: dz16[last] is already written (else it is rounded from dz[last] first) */
-  ADDHIP_BWD_SIGN_BITS = 16      /* the forward pass of this step wrote hbits: masks are read from them */
+  ADDHIP_BWD_SIGN_BITS = 16,     /* the forward pass of this step wrote hbits: masks are read from them */
+  ADDHIP_BWD_TOP_BIAS_REPLICAS = 32 /* the producer of dz[last] left gb[last] as column sums spread over bias_replicas: the top combine folds them in */
 };
 typedef struct {                 /* a second product accumulated into a layer's weight gradient: gW += A^T B over `rows` rows */
   const void* A; int32_t lda; const void* B; int32_t ldb; int64_t rows;   /* fp32, or bf16 with bf16 storage; A == NULL: none */
