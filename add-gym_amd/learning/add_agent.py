@@ -602,6 +602,10 @@ class ADDAgent:
         total = self.T * self.N
         num_batches = int(np.ceil(float(min(self._total_samples, total)) / self.Mb))
         W["stats"].zero_()
+        # (the bias-gradient replica rows are zero between steps by construction -- every combine clears what its dX GEMM wrote; an update
+        # phase still starts from a known state, e.g. after a tool replayed single launches of the plan)
+        for r in (self._run_actor, self._run_critic, self._run_disc):
+            r.bias_rep.zero_()
         steps, n_steps = 0, self._update_epochs * num_batches
         main, side = torch.cuda.current_stream(), self._side_streams[0]
         self._next_minibatch_indices()
