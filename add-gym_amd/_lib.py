@@ -57,7 +57,8 @@ class GemmT(C.Structure):
                 ("bias", f32p), ("mask", f32p), ("ldmask", C.c_int32), ("a_mean", f32p), ("a_std", f32p), ("split_k", C.c_int32),
                 ("alpha", C.c_float), ("colsum", f32p), ("precision", C.c_int32),
                 ("relu_bits", f32p), ("mask_bits", f32p), ("ldbits", C.c_int32), ("accumulate", C.c_int32),
-                ("operands_bf16", C.c_int32), ("C16", f32p), ("ldc16", C.c_int32), ("hint", C.c_int32), ("colsum_replicas", C.c_int32), ("ldcs", C.c_int32)]
+                ("operands_bf16", C.c_int32), ("C16", f32p), ("ldc16", C.c_int32), ("hint", C.c_int32), ("colsum_replicas", C.c_int32), ("ldcs", C.c_int32),
+                ("c16_planes", C.c_int32), ("a_amax", f32p), ("b_amax", f32p), ("amax_out", f32p)]
 
 
 class GatherT(C.Structure):
@@ -65,7 +66,8 @@ class GatherT(C.Structure):
                 ("obs_std", f32p), ("action", f32p), ("a_mean", f32p), ("a_std", f32p), ("a_logp", f32p), ("adv", f32p), ("tar_val", f32p),
                 ("rand_mask", f32p), ("disc_obs", f32p), ("disc_demo", f32p), ("disc_stride", C.c_int32), ("disc_dim", C.c_int32),
                 ("mean_abs", f32p), ("min_diff", C.c_float), ("norm_obs", f32p), ("norm_action", f32p), ("o_logp", f32p), ("o_adv", f32p),
-                ("o_tar_val", f32p), ("o_mask", f32p), ("norm_diff", f32p), ("norm_obs16", f32p), ("norm_diff16", f32p)]
+                ("o_tar_val", f32p), ("o_mask", f32p), ("norm_diff", f32p), ("norm_obs16", f32p), ("norm_diff16", f32p), ("planes16", C.c_int32),
+                ("obs_amax", f32p), ("diff_amax", f32p)]
 
 
 class RigidModelT(C.Structure):
@@ -83,7 +85,7 @@ class RigidDrT(C.Structure):
 class OptimizerT(C.Structure):
     _fields_ = [("type", C.c_int32), ("param", f32p), ("grad", f32p), ("state1", f32p), ("state2", f32p), ("count", C.c_int64), ("lr", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("step", C.c_int32), ("param16", f32p),
-                ("zero_grad", C.c_int32)]
+                ("zero_grad", C.c_int32), ("param16_planes", C.c_int32)]
 
 
 class SectionT(C.Structure):
@@ -96,15 +98,16 @@ _H = MLP_MAX_HIDDEN
 
 class MlpT(C.Structure):
     _fields_ = [("num_hidden", C.c_int32), ("in_dim", C.c_int32), ("in_ld", C.c_int32), ("hidden", C.c_int32 * _H), ("head_rows", C.c_int32), ("precision", C.c_int32),
-                ("W", f32p * _H), ("b", f32p * _H), ("Wh", f32p), ("bh", f32p), ("gW", f32p * _H), ("gb", f32p * _H), ("gWh", f32p), ("gbh", f32p),
+                ("storage", C.c_int32), ("W", f32p * _H), ("b", f32p * _H), ("Wh", f32p), ("bh", f32p), ("gW", f32p * _H), ("gb", f32p * _H), ("gWh", f32p), ("gbh", f32p),
                 ("W16", f32p * _H), ("W16t", f32p * _H), ("rows_cap", C.c_int32), ("h", f32p * _H), ("dz", f32p * _H), ("hbits", f32p * _H), ("h16", f32p * _H),
                 ("dz16", f32p * _H), ("slabs", f32p), ("slab_floats", C.c_int64), ("slabs_top", f32p), ("bias_replicas", f32p), ("bias_replica_rows", C.c_int32),
                 ("flat_params", f32p), ("flat_trans16", f32p),
-                ("flat_count", C.c_int64), ("t_offset", C.POINTER(C.c_int64)), ("t_rows", C.POINTER(C.c_int32)), ("t_cols", C.POINTER(C.c_int32)), ("t_count", C.c_int32)]
+                ("flat_count", C.c_int64), ("t_offset", C.POINTER(C.c_int64)), ("t_rows", C.POINTER(C.c_int32)), ("t_cols", C.POINTER(C.c_int32)), ("t_count", C.c_int32),
+                ("amax", f32p), ("w_amax", f32p)]
 
 
 class ExtraDwT(C.Structure):
-    _fields_ = [("A", f32p), ("lda", C.c_int32), ("B", f32p), ("ldb", C.c_int32), ("rows", C.c_int64)]
+    _fields_ = [("A", f32p), ("lda", C.c_int32), ("B", f32p), ("ldb", C.c_int32), ("rows", C.c_int64), ("a_amax", f32p), ("b_amax", f32p)]
 
 
 class MlpMarksT(C.Structure):
@@ -112,7 +115,8 @@ class MlpMarksT(C.Structure):
 
 
 class PpoLossT(C.Structure):
-    _fields_ = [("actor", C.POINTER(MlpT)), ("critic", C.POINTER(MlpT)), ("rows", C.c_int32), ("norm_obs", f32p), ("norm_obs16", f32p), ("norm_action", f32p),
+    _fields_ = [("actor", C.POINTER(MlpT)), ("critic", C.POINTER(MlpT)), ("rows", C.c_int32), ("norm_obs", f32p), ("norm_obs16", f32p), ("norm_obs_amax", f32p),
+                ("norm_action", f32p),
                 ("old_logp", f32p), ("adv", f32p), ("tar_val", f32p), ("rand_mask", f32p), ("action_std", C.c_float), ("logp_const", C.c_float),
                 ("ppo_clip_ratio", C.c_float), ("action_bound_weight", C.c_float), ("action_reg_weight", C.c_float), ("critic_loss_weight", C.c_float),
                 ("grad_scale", C.c_float), ("head_precision", C.c_int32), ("mean", f32p), ("d_mean", f32p), ("dv", f32p), ("num_valid", f32p), ("stats", f32p)]
@@ -123,7 +127,7 @@ class PpoMarksT(C.Structure):
 
 
 class DiscLossT(C.Structure):
-    _fields_ = [("disc", C.POINTER(MlpT)), ("rows", C.c_int32), ("disc_dim", C.c_int32), ("norm_diff", f32p), ("norm_diff16", f32p), ("loss_scale", C.c_float),
+    _fields_ = [("disc", C.POINTER(MlpT)), ("rows", C.c_int32), ("disc_dim", C.c_int32), ("norm_diff", f32p), ("norm_diff16", f32p), ("norm_diff_amax", f32p), ("loss_scale", C.c_float),
                 ("logit_reg", C.c_float), ("grad_penalty", C.c_float), ("weight_decay", C.c_float), ("dlogit", f32p), ("a2", f32p), ("a1", f32p), ("g", f32p),
                 ("G", f32p), ("e1", f32p), ("da2", f32p), ("a2_16", f32p), ("a1_16", f32p), ("G16", f32p), ("e1_16", f32p), ("stats", f32p)]
 
@@ -138,8 +142,10 @@ MAX_STREAMS = 8
 OPT_ADAMW, OPT_SGD = 0, 1
 RIGID_BODY_W, RIGID_TOPO_W = 32, 8
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
-PREC_F32, PREC_BF16, PREC_BF16X2, PREC_BF16X3 = 0, 1, 2, 3
-GEMM_HINT_BIG_TILE, GEMM_HINT_NO_BIG_TILE, GEMM_HINT_ONE_STAGE, GEMM_HINT_TWO_STAGE, GEMM_HINT_REG_STAGED = 1, 2, 4, 8, 16
+PREC_F32, PREC_BF16, PREC_BF16X2, PREC_BF16X3, PREC_F16X2 = 0, 1, 2, 3, 4
+AMAX_SLOTS, MLP_AMAX_TENSORS = 64, 12  # tracked operand maxima of PREC_F16X2 (include/addhip.h)
+STORE_BF16, STORE_BF16X3 = 1, 3  # 16-bit storage formats of GEMM operands (include/addhip.h, "plane storage")
+GEMM_HINT_BIG_TILE, GEMM_HINT_NO_BIG_TILE, GEMM_HINT_ONE_STAGE, GEMM_HINT_TWO_STAGE, GEMM_HINT_REG_STAGED, GEMM_HINT_WIDE_TILE = 1, 2, 4, 8, 16, 32
 GEMM_MAX_GROUP = 4
 
 i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
@@ -156,8 +162,10 @@ SIGNATURES = {
     "addhip_gemm_f32": [P(GemmT), vp],
     "addhip_gemm_grouped": [P(GemmT), i32, vp],
     "addhip_to_bf16": [vp, vp, i64, i32, i32, i32, vp],
+    "addhip_to_bf16x3": [vp, vp, i64, i32, i32, i32, vp],
     "addhip_to_bf16_t": [vp, vp, i32, i32, i32, i32, vp],
-    "addhip_shadow_refresh": [vp, vp, vp, i64, vp, vp, vp, i32, vp],
+    "addhip_shadow_refresh": [vp, vp, vp, i64, vp, vp, vp, i32, i32, vp],
+    "addhip_amax_f32": [vp, i64, vp, vp],
     "addhip_slab_reduce": [vp, i32, i64, vp, i64, f32, i32, vp],
     "addhip_slab_reduce_pair": [vp, i32, i64, vp, i64, f32, i32, vp, i32, i32, vp, i32, i32, i32, vp],
     "addhip_col_sum": [vp, i32, i32, i32, vp, f32, i32, vp],
@@ -180,10 +188,10 @@ SIGNATURES = {
     "addhip_count_mask": [vp, i32, vp, vp],
     "addhip_critic_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
     "addhip_disc_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
-    "addhip_head_backward": [vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp],
+    "addhip_head_backward": [vp, vp, vp, i32, i32, i64, vp, vp, i32, vp, vp, vp, vp, vp],
     "addhip_outer_mask": [vp, vp, vp, i32, i32, i64, vp, vp],
-    "addhip_bcast_mask": [vp, vp, i32, i32, i64, vp, vp, vp],
-    "addhip_grad_penalty": [vp, i32, i32, i32, f32, vp, vp, vp, vp],
+    "addhip_bcast_mask": [vp, vp, i32, i32, i64, vp, vp, i32, vp, vp],
+    "addhip_grad_penalty": [vp, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp],
     "addhip_weighted_col_sum": [vp, vp, i32, i32, i64, vp, f32, i32, vp],
     "addhip_l2_grad": [vp, vp, i64, f32, vp, vp],
     "addhip_grad_clip": [vp, i64, f32, vp, vp, vp],
@@ -204,8 +212,8 @@ SIGNATURES = {
     "addhip_schedule_destroy": [vp],
     "addhip_schedule_run": [vp, P(vp), BUCKET_FN, vp],
     # composite entry points (the library assembles the launches)
-    "addhip_mlp_forward": [P(MlpT), vp, vp, i64, vp, vp, i32, vp],
-    "addhip_mlp_backward": [P(MlpT), vp, vp, i64, P(ExtraDwT), i32, P(MlpMarksT), vp],
+    "addhip_mlp_forward": [P(MlpT), vp, vp, i64, vp, vp, i32, vp, vp],
+    "addhip_mlp_backward": [P(MlpT), vp, vp, i64, P(ExtraDwT), i32, P(MlpMarksT), vp, vp],
     "addhip_ppo_loss_fwd_bwd": [P(PpoLossT), P(PpoMarksT), vp],
     "addhip_disc_loss_fwd_bwd": [P(DiscLossT), P(DiscMarksT), vp],
     "addhip_update_schedule": [i32, P(PpoMarksT), P(DiscMarksT), P(SectionT), i32],   # returns the number of sections

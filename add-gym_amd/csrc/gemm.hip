@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void gemm_small_m_kernel(addhip_gemm_t g) {
   if (!writer) return;
   const int epi = g.epilogue;
   const float bias = (epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU) ? g.bias[n] : 0.f;
-  float cs = 0.f;
+  float cs = 0.f, amx = 0.f;
 #pragma unroll
   for (int m = 0; m < SMALL_M; ++m)
     if (m < g.M) {
@@ -299,8 +299,10 @@ __global__ __launch_bounds__(256) void gemm_small_m_kernel(addhip_gemm_t g) {
       if (epi == ADDHIP_EPI_MASK) v = g.mask[(size_t)m * g.ldmask + n] > 0.f ? v : 0.f;
       g.C[(size_t)m * g.ldc + n] = v;
       cs += v;
+      amx = fmaxf(amx, fabsf(v));
     }
   if (epi == ADDHIP_EPI_MASK && g.colsum) atomicAdd(&g.colsum[n], cs);
+  if (g.amax_out) atomicMax(&g.amax_out[blockIdx.x % ADDHIP_AMAX_SLOTS], __float_as_uint(amx));  // (one writer thread per column: few)
 }
 
 // ------------------------------------------------------------------ small reductions
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* X, int M, int
 namespace addhip {
 int gemm_split_dispatch(const addhip_gemm_t& g, int planes, hipStream_t st);       // gemm_split.hip
 int gemm_bf16_dispatch(const addhip_dma::GemmGroup& grp, int count, hipStream_t st);  // gemm_bf16.hip
+int gemm_x3_dispatch(const addhip_gemm_t& g, hipStream_t st);                          // gemm_x3.hip
 }
 
 namespace {
@@ -427,9 +430,14 @@ int validate(addhip_gemm_t& g) {
   if (g.colsum) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && g.split_k <= 1, "gemm: colsum needs the MASK epilogue");
   if (g.colsum_replicas > 1) ADDHIP_REQUIRE(g.colsum && g.ldcs >= g.N && g.colsum_replicas <= 64, "gemm: colsum_replicas (2..64) need colsum and ldcs >= N");
   ADDHIP_REQUIRE(g.precision == ADDHIP_PREC_F32 || g.precision == ADDHIP_PREC_BF16 || g.precision == ADDHIP_PREC_BF16X2 ||
-                     g.precision == ADDHIP_PREC_BF16X3, "gemm: bad precision");
+                     g.precision == ADDHIP_PREC_BF16X3 || g.precision == ADDHIP_PREC_F16X2, "gemm: bad precision");
+  if (g.amax_out) ADDHIP_REQUIRE(g.split_k <= 1 && !g.accumulate, "gemm: amax_out tracks final results, not split-K slabs");
   ADDHIP_REQUIRE(g.C || g.split_k <= 1, "gemm: split-K slabs are fp32 (C)");
   if (g.operands_bf16) ADDHIP_REQUIRE(!g.accumulate, "gemm: accumulate is not built for bf16-stored operands");
+  ADDHIP_REQUIRE(g.operands_bf16 == 0 || g.operands_bf16 == ADDHIP_STORE_BF16 || g.operands_bf16 == ADDHIP_STORE_BF16X3, "gemm: operands_bf16 is 0 or an ADDHIP_STORE_* format");
+  ADDHIP_REQUIRE(g.c16_planes == 0 || g.c16_planes == ADDHIP_STORE_BF16 || g.c16_planes == ADDHIP_STORE_BF16X3, "gemm: c16_planes is 0 or an ADDHIP_STORE_* format");
+  if (g.C16 && g.c16_planes == ADDHIP_STORE_BF16X3)
+    ADDHIP_REQUIRE(g.N % 8 == 0 && g.ldc16 % 8 == 0 && aligned16(g.C16), "gemm: a plane-storage C16 needs N and ldc16 multiples of 8 and a 16-byte aligned buffer");
   if (g.alpha == 0.0f) g.alpha = 1.0f;
   return 0;
 }
@@ -496,6 +504,7 @@ extern "C" int addhip_gemm_f32(const addhip_gemm_t* gp, void* stream) {
   if (addhip::recording())  // (record.h: the descriptor is kept by value, and kept visible to addhip_plan_call_gemms)
     return addhip::record_push("addhip_gemm_f32", [g](void* s) -> int { return addhip_gemm_f32(&g, s); }, &g, 1);
   hipStream_t st = (hipStream_t)stream;
+  if (g.operands_bf16 == ADDHIP_STORE_BF16X3) return addhip::gemm_x3_dispatch(g, st);
   if (g.operands_bf16) {
     addhip_dma::GemmGroup grp;
     grp.g[0] = g;
@@ -512,7 +521,7 @@ extern "C" int addhip_gemm_grouped(const addhip_gemm_t* problems, int32_t count,
     if (int rc = validate(grp.g[i])) return rc;
     const addhip_gemm_t &a = grp.g[0], &b = grp.g[i];
     ADDHIP_REQUIRE(a.M == b.M && a.N == b.N && a.K == b.K && a.a_kcontig == b.a_kcontig && a.b_kcontig == b.b_kcontig && a.epilogue == b.epilogue &&
-                       a.split_k == b.split_k && a.precision == b.precision && a.operands_bf16 == b.operands_bf16 && a.accumulate == b.accumulate &&
+                       a.split_k == b.split_k && a.precision == b.precision && a.operands_bf16 == b.operands_bf16 && a.c16_planes == b.c16_planes && a.accumulate == b.accumulate &&
                        (a.a_mean != nullptr) == (b.a_mean != nullptr) && a.hint == b.hint,
                    "gemm_grouped: problem %d differs from problem 0 in shape, layout, epilogue, split, precision or storage", i);
   }
@@ -523,7 +532,7 @@ extern "C" int addhip_gemm_grouped(const addhip_gemm_t* problems, int32_t count,
   if (count > 1) {
     // one launch over all problems where the shape takes the 128x128 LDS-DMA kernel ...
     const long long tiles128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.split_k > 1 ? g.split_k : 1);
-    if (g.operands_bf16 && !(g.hint & ADDHIP_GEMM_HINT_BIG_TILE)) return addhip::gemm_bf16_dispatch(grp, count, st);
+    if (g.operands_bf16 == ADDHIP_STORE_BF16 && !(g.hint & ADDHIP_GEMM_HINT_BIG_TILE)) return addhip::gemm_bf16_dispatch(grp, count, st);
     const int waste128 = (g.N + 127) / 128 * 128 - g.N, waste96 = (g.N + 95) / 96 * 96 - g.N;
     const bool narrow = waste128 >= 64 && waste96 < 32;
     if (!g.operands_bf16 && g.M > SMALL_M && g.N > 64 && !narrow && takes_dma_f32(g, tiles128 * count)) return launch_dma_f32(grp, count, st);

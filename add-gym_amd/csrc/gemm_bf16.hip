@@ -13,6 +13,7 @@
 #include "record.h"
 #include "gemm_epilogue.h"
 #include "gemm_dma.h"
+#include "planes.h"
 
 namespace {
 
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_q_kernel(addhip_gemm_t g, in
 }
 
 // fp32 -> bf16 (round to nearest even), row by row: dst[r*ld_dst + c] = bf16(src[r*ld_src + c]), cols % 4 == 0
+template <bool X3>
 __global__ void to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, long long rows, int cols, int ld_src, int ld_dst) {
   const int cq = cols >> 2;
   const long long n = rows * cq;
@@ -191,6 +193,10 @@ __global__ void to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ 
     const long long r = i / cq;
     const int c = (int)(i - r * cq) * 4;
     const float4 v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+    if (X3) {  // plane storage (planes.h): the exact 3-way split
+      addhip_planes::store4(dst + 3 * r * ld_dst, c, v);
+      continue;
+    }
     const unsigned lo = (unsigned)to_bf16(v.x) | ((unsigned)to_bf16(v.y) << 16), hi = (unsigned)to_bf16(v.z) | ((unsigned)to_bf16(v.w) << 16);
     *reinterpret_cast<uint2*>(dst + r * ld_dst + c) = make_uint2(lo, hi);
   }
@@ -221,6 +227,7 @@ struct ShadowMats {
   int rows[ADDHIP_SHADOW_MAX_MATS], cols[ADDHIP_SHADOW_MAX_MATS], tile_end[ADDHIP_SHADOW_MAX_MATS];
   int n;
 };
+template <bool X3>
 __global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __restrict__ params, u16* __restrict__ flat16, u16* __restrict__ trans16,
                                                              long long count, int flat_blocks, ShadowMats mats) {
   __shared__ float tile[32][33];
@@ -228,6 +235,10 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __rest
     const long long n4 = count >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)flat_blocks * 256) {
       const float4 v = reinterpret_cast<const float4*>(params)[i];
+      if (X3) {  // (count % 8 == 0)
+        addhip_planes::store4_flat(flat16, 4 * i, v);
+        continue;
+      }
       reinterpret_cast<uint2*>(flat16)[i] =
           make_uint2((unsigned)to_bf16(v.x) | ((unsigned)to_bf16(v.y) << 16), (unsigned)to_bf16(v.z) | ((unsigned)to_bf16(v.w) << 16));
     }
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __rest
   const int tcols = (cols + 31) / 32;
   const int r0 = (t / tcols) * 32, c0 = (t % tcols) * 32;
   const float* src = params + mats.offset[mi];
-  u16* dst = trans16 + mats.offset[mi];
+  u16* dst = trans16 + (X3 ? 3 : 1) * mats.offset[mi];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -249,6 +260,12 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __rest
     tile[ty + 8 * j][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
   }
   __syncthreads();
+  if (X3) {  // transposed row c = rows values (rows % 8 == 0): a thread writes 4 of them into the three planes
+    const int c = c0 + (threadIdx.x >> 3), rq = (threadIdx.x & 7) * 4, r = r0 + rq;
+    if (c < cols && r < rows)
+      addhip_planes::store4(dst + 3 * (size_t)c * rows, r, make_float4(tile[rq][c - c0], tile[rq + 1][c - c0], tile[rq + 2][c - c0], tile[rq + 3][c - c0]));
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int c = c0 + ty + 8 * j, r = r0 + tx;
@@ -324,8 +341,20 @@ extern "C" int addhip_to_bf16(const float* src, uint16_t* dst, int64_t rows, int
   const long long n = (long long)rows * (cols / 4);
   long long blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)rows, cols, ld_src, ld_dst);
+  hipLaunchKernelGGL(to_bf16_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)rows, cols, ld_src, ld_dst);
   return addhip::check_launch("to_bf16_kernel");
+}
+
+extern "C" int addhip_to_bf16x3(const float* src, uint16_t* dst, int64_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream) {
+  ADDHIP_REQUIRE(src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && ld_src >= cols && ld_dst >= cols && ld_src % 4 == 0 && ld_dst % 8 == 0,
+                 "to_bf16x3: bad arguments (cols and ld_dst multiples of 8, ld_src of 4)");
+  ADDHIP_REQUIRE(aligned16(src) && aligned16(dst), "to_bf16x3: misaligned buffers");
+  ADDHIP_RECORDABLE(addhip_to_bf16x3, src, dst, rows, cols, ld_src, ld_dst);
+  const long long n = (long long)rows * (cols / 4);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(to_bf16_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)rows, cols, ld_src, ld_dst);
+  return addhip::check_launch("to_bf16_kernel<x3>");
 }
 
 extern "C" int addhip_to_bf16_t(const float* src, uint16_t* dst, int32_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream) {
@@ -336,10 +365,13 @@ extern "C" int addhip_to_bf16_t(const float* src, uint16_t* dst, int32_t rows, i
 }
 
 extern "C" int addhip_shadow_refresh(const float* params, uint16_t* flat16, uint16_t* trans16, int64_t count, const int64_t* offset, const int32_t* rows,
-                                     const int32_t* cols, int32_t n_mats, void* stream) {
+                                     const int32_t* cols, int32_t n_mats, int32_t planes16, void* stream) {
   ADDHIP_REQUIRE(params && (flat16 || n_mats > 0) && count > 0 && n_mats >= 0 && n_mats <= ADDHIP_SHADOW_MAX_MATS, "shadow_refresh: bad arguments");
   ADDHIP_REQUIRE(n_mats == 0 || (trans16 && offset && rows && cols), "shadow_refresh: matrix table missing");
   ADDHIP_REQUIRE(aligned16(params) && (reinterpret_cast<uintptr_t>(flat16) & 7u) == 0, "shadow_refresh: misaligned buffers");
+  const bool x3 = planes16 == ADDHIP_STORE_BF16X3;
+  ADDHIP_REQUIRE(planes16 == 0 || planes16 == ADDHIP_STORE_BF16 || (x3 && count % 8 == 0 && aligned16(flat16) && aligned16(trans16)),
+                 "shadow_refresh: planes16 is an ADDHIP_STORE_* format (plane storage: count %% 8 == 0, 16-byte aligned shadows)");
   ShadowMats mats;
   mats.n = n_mats > 0 ? n_mats : 1;
   int tiles = 0;
@@ -347,6 +379,7 @@ extern "C" int addhip_shadow_refresh(const float* params, uint16_t* flat16, uint
     const bool on = i < n_mats;
     ADDHIP_REQUIRE(!on || (offset[i] >= 0 && rows[i] > 0 && cols[i] > 0 && offset[i] + (int64_t)rows[i] * cols[i] <= count),
                    "shadow_refresh: a matrix lies outside the flat buffer");
+    ADDHIP_REQUIRE(!on || !x3 || (offset[i] % 8 == 0 && rows[i] % 8 == 0), "shadow_refresh: plane storage needs matrix offsets and row counts %% 8 == 0");
     mats.offset[i] = on ? offset[i] : 0;
     mats.rows[i] = on ? rows[i] : 0;
     mats.cols[i] = on ? cols[i] : 0;
@@ -358,11 +391,15 @@ extern "C" int addhip_shadow_refresh(const float* params, uint16_t* flat16, uint
     const std::vector<int32_t> r(rows, rows + n_mats), c(cols, cols + n_mats);
     return addhip::record_push(
         "addhip_shadow_refresh",
-        [=](void* s) -> int { return addhip_shadow_refresh(params, flat16, trans16, count, o.data(), r.data(), c.data(), n_mats, s); }, nullptr, 0);
+        [=](void* s) -> int { return addhip_shadow_refresh(params, flat16, trans16, count, o.data(), r.data(), c.data(), n_mats, planes16, s); }, nullptr, 0);
   }
   long long fb = (count / 4 + 255) / 256;
   const int flat_blocks = flat16 ? (int)(fb < 1 ? 1 : fb > 2048 ? 2048 : fb) : 0;  // flat16 == NULL: the transposed copies only
-  hipLaunchKernelGGL(shadow_refresh_kernel, dim3((unsigned)(flat_blocks + tiles)), dim3(256), 0, (hipStream_t)stream, params, flat16, trans16,
-                     (long long)count, flat_blocks, mats);
+  if (x3)
+    hipLaunchKernelGGL(shadow_refresh_kernel<true>, dim3((unsigned)(flat_blocks + tiles)), dim3(256), 0, (hipStream_t)stream, params, flat16, trans16,
+                       (long long)count, flat_blocks, mats);
+  else
+    hipLaunchKernelGGL(shadow_refresh_kernel<false>, dim3((unsigned)(flat_blocks + tiles)), dim3(256), 0, (hipStream_t)stream, params, flat16, trans16,
+                       (long long)count, flat_blocks, mats);
   return addhip::check_launch("shadow_refresh_kernel");
 }

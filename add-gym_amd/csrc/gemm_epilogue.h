@@ -3,6 +3,7 @@
 // atomics) and C16 (bf16, round to nearest even).
 #pragma once
 #include "common.h"
+#include "planes.h"
 
 namespace addhip_epi {
 
@@ -43,15 +44,24 @@ extern "C" __device__ unsigned addhip_llvm_writelane(unsigned val, unsigned lane
 // edge ones): the same epilogue as straight-line code -- no per-element bounds, no alignment fallbacks, no atomics.  The general form
 // below executes ~2000 instructions per wave, which with 16 waves per CU is what a short-K launch took its time for (10-17 us); this
 // one ~600.  Masking is an AND with the sign-extended bit of the lane's column; bf16 results are rounded by v_cvt_pk_bf16_f32.
+// max |v| of a wave's block -> one atomic per wave on slot (workgroup % ADDHIP_AMAX_SLOTS) (addhip_gemm_t.amax_out; non-negative floats order as
+// their bit patterns)
+__device__ __forceinline__ void epi_amax(const addhip_gemm_t& g, float amx) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(&g.amax_out[(blockIdx.x + blockIdx.y * gridDim.x) % ADDHIP_AMAX_SLOTS], __float_as_uint(amx));
+}
+
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void gemm_epilogue_full(const addhip_gemm_t& g, f32x16 (&acc)[MT][NT], char* ebuf, int lane, int row0, int col0, float* C,
-                                                   unsigned short* C16) {
+                                                   unsigned short* C16, float alpha) {
   constexpr int ERS = EpiBuf<NT>::ERS;
   const int li = lane & 31, lh = lane >> 5;
   const int epi = EPI == EPI_RUNTIME ? g.epilogue : EPI;
   const bool has_bias = epi == ADDHIP_EPI_BIAS || epi == ADDHIP_EPI_BIAS_RELU;
   const bool want_bits = epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits != nullptr;
   const bool want_cs = epi == ADDHIP_EPI_MASK && g.colsum != nullptr;
+  float amx = 0.f;
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
     const int rtile = row0 + a * 32;
@@ -67,7 +77,7 @@ __device__ __forceinline__ void gemm_epilogue_full(const addhip_gemm_t& g, f32x1
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
         const int r0 = (x & 3) + 8 * (x >> 2), rloc = r0 + 4 * lh;
-        float v = g.alpha * acc[a][b][x] + bias;
+        float v = alpha * acc[a][b][x] + bias;
         if (epi == ADDHIP_EPI_BIAS_RELU) {
           v = fmaxf(v, 0.f);
           if (want_bits) {
@@ -83,6 +93,7 @@ __device__ __forceinline__ void gemm_epilogue_full(const addhip_gemm_t& g, f32x1
           v = __uint_as_float(__float_as_uint(v) & (unsigned)keep);
           cs += v;
         }
+        amx = fmaxf(amx, fabsf(v));
         *reinterpret_cast<float*>(ebuf + rloc * ERS + (b * 32 + li) * 4) = v;
       }
       if (want_bits && lane < 32) g.relu_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)] = rword;
@@ -106,15 +117,20 @@ __device__ __forceinline__ void gemm_epilogue_full(const addhip_gemm_t& g, f32x1
         const int idx = lane + 64 * i, rloc = idx / CPR, c8 = (idx % CPR) * 8;
         const float4 lo = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4);
         const float4 hi = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4 + 16);
-        *reinterpret_cast<uint4*>(C16 + (size_t)(rtile + rloc) * g.ldc16 + col0 + c8) =
-            make_uint4(epi_pack_bf16(lo.x, lo.y), epi_pack_bf16(lo.z, lo.w), epi_pack_bf16(hi.x, hi.y), epi_pack_bf16(hi.z, hi.w));
+        if (g.c16_planes == ADDHIP_STORE_BF16X3)  // plane storage: the exact 3-way split, 48 contiguous bytes per 8 columns
+          addhip_planes::store8(C16 + 3 * (size_t)(rtile + rloc) * g.ldc16, col0 + c8, lo, hi);
+        else
+          *reinterpret_cast<uint4*>(C16 + (size_t)(rtile + rloc) * g.ldc16 + col0 + c8) =
+              make_uint4(epi_pack_bf16(lo.x, lo.y), epi_pack_bf16(lo.z, lo.w), epi_pack_bf16(hi.x, hi.y), epi_pack_bf16(hi.z, hi.w));
       }
     }
   }
+  if (g.amax_out) epi_amax(g, amx);
 }
 
+// alpha: the factor applied to the accumulators (g.alpha; the F16X2 kernel folds the inverse of its operand scales in)
 template <int MT, int NT, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&acc)[MT][NT], char* ebuf, int lane, int row0, int col0, int zslab) {
+__device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&acc)[MT][NT], char* ebuf, int lane, int row0, int col0, int zslab, float alpha) {
   constexpr int ERS = EpiBuf<NT>::ERS;
   typedef unsigned short u16;
   const int li = lane & 31, lh = lane >> 5;
@@ -126,9 +142,10 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
   const bool c16_vec = C16 && (reinterpret_cast<uintptr_t>(C16) & 15) == 0 && (g.ldc16 & 7) == 0;
   // (wave-uniform) the straight-line form for blocks wholly inside C with aligned rows
   if (row0 + MT * 32 <= g.M && col0 + NT * 32 <= g.N && !accum && (!C || c_vec) && (!C16 || c16_vec) && (epi != ADDHIP_EPI_MASK || g.mask_bits)) {
-    gemm_epilogue_full<MT, NT, EPI>(g, acc, ebuf, lane, row0, col0, C, C16);
+    gemm_epilogue_full<MT, NT, EPI>(g, acc, ebuf, lane, row0, col0, C, C16, alpha);
     return;
   }
+  float amx = 0.f;
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
     const int rtile = row0 + a * 32;
@@ -147,7 +164,7 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
       for (int x = 0; x < 16; ++x) {
         const int r0 = (x & 3) + 8 * (x >> 2), rloc = r0 + 4 * lh, row = rtile + rloc;
         const bool ok = col_ok && row < g.M;
-        float v = g.alpha * acc[a][b][x] + bias;
+        float v = alpha * acc[a][b][x] + bias;
         if (epi == ADDHIP_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
         if (epi == ADDHIP_EPI_MASK) {
           if (g.mask_bits) {
@@ -158,6 +175,7 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
           }
           if (ok) cs += v;
         }
+        if (ok) amx = fmaxf(amx, fabsf(v));
         if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {
           const unsigned long long pos = __ballot(ok && v > 0.f);
           rword = lane == r0 ? (unsigned)pos : lane == r0 + 4 ? (unsigned)(pos >> 32) : rword;
@@ -200,7 +218,9 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
         const int idx = lane + 64 * i, rloc = idx / CPR, c8 = (idx % CPR) * 8, row = rtile + rloc, col = col0 + c8;
         const float4 lo = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4);
         const float4 hi = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4 + 16);
-        if (row < g.M) {
+        if (row < g.M && g.c16_planes == ADDHIP_STORE_BF16X3) {  // (N % 8 == 0: a group of 8 columns is in or out as a whole)
+          if (col < g.N) addhip_planes::store8(C16 + 3 * (size_t)row * g.ldc16, col, lo, hi);
+        } else if (row < g.M) {
           u16* dst = C16 + (size_t)row * g.ldc16 + col;
           const u16 e[8] = {epi_bf16(lo.x), epi_bf16(lo.y), epi_bf16(lo.z), epi_bf16(lo.w), epi_bf16(hi.x), epi_bf16(hi.y), epi_bf16(hi.z), epi_bf16(hi.w)};
           if (c16_vec && col + 7 < g.N) {
@@ -215,6 +235,11 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
       }
     }
   }
+  if (g.amax_out) epi_amax(g, amx);
+}
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&acc)[MT][NT], char* ebuf, int lane, int row0, int col0, int zslab) {
+  gemm_epilogue<MT, NT, EPI>(g, acc, ebuf, lane, row0, col0, zslab, g.alpha);
 }
 
 }  // namespace addhip_epi

@@ -9,6 +9,12 @@
 // with 64x less error than TF32 at half the MFMA work of the exact split.  PLANES = 1 is the plain bf16 product
 // (operands rounded toward zero to bf16, fp32 accumulate).
 //
+// F16 (ADDHIP_PREC_F16X2, include/addhip.h): two fp16 planes of x * s instead, s an exact power of two per operand tensor chosen from the
+// tensor's tracked maximum (addhip_gemm_t.a_amax / b_amax) so that the largest value sits just below 2^15; hi = fp16(x s) and
+// lo = fp16(x s - hi), round to nearest, keep 22 significant bits + the sign of the residual, and all FOUR products are formed
+// (v_mfma_f32_32x32x16_f16): per-product error bound 2^-21 |a||b| at 4 instead of 6 matrix instructions per k-step and ~5 instead of ~9
+// vector instructions per operand value.  The inverse of the two scales is folded into alpha (exact).
+//
 // Same interface, tiling and epilogues as gemm.hip: 128x128 tile, 4 wavefronts of 64x64 (2x2 MFMA accumulators),
 // operands stay fp32 in HBM and are split on their way into LDS.  LDS image of an operand tile: [row][plane][16 k] bf16
 // with a 16-byte pad per row (row stride 112 B = 28 dwords: a ds_read_b128 lane group covers all 64 banks); K advances 16
@@ -21,6 +27,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128, BN = 128, BK = 16;
 using addhip_epi::EPI_RUNTIME;
@@ -40,6 +48,23 @@ __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, uns
 }
 // two bf16 (high halves of a, b) -> one dword, a in the low half
 __device__ __forceinline__ unsigned pack2(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// (x0, x1), already scaled -> dwords of their fp16 hi parts and fp16 lo parts (round to nearest; x - float(hi) is exact in fp32)
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const f16x2 h = {(_Float16)x0, (_Float16)x1};
+  const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// power-of-two scale that puts `amax` (the maximum over the ADDHIP_AMAX_SLOTS float bit patterns at `slots`) into [2^14, 2^15): every
+// thread of the workgroup computes it (64 L2-resident loads per wave); amax == 0 -> 1
+__device__ __forceinline__ float scale_from_amax(const unsigned* __restrict__ slots) {
+  unsigned m = slots[threadIdx.x & (ADDHIP_AMAX_SLOTS - 1)];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  const int e = (int)((m >> 23) & 0xffu);                  // biased exponent of amax: amax in [2^(e-127), 2^(e-126))
+  const int se = min(max(268 - e, 1), 254);                // biased exponent of 2^(14 - (e - 127))
+  return m == 0u ? 1.0f : __uint_as_float((unsigned)se << 23);
+}
 
 // ---- k-contiguous operand P[r*ld + k]: each thread moves 2 float4 (4 k of one row) per stage --------------------
 // Loads are unconditional (addresses clamped into the K range) and NOTHING is done to the loaded registers until they
@@ -57,8 +82,8 @@ __device__ __forceinline__ void load_kc(float4* reg, const float* __restrict__ P
 }
 // nmean / nstd: LDS copies of the normaliser vectors, indexed by k - kbeg (NORM only).  One call = one of the thread's two
 // float4 (part i), so that the caller can spread the work between MFMA groups.  GUARD: K tail (k >= kend -> 0).
-template <int PLANES, bool NORM, bool GUARD>
-__device__ __forceinline__ void store_kc(char* lds, const float4* reg, int i, int k0, int kend, const float* nmean, const float* nstd, int kbeg) {
+template <int PLANES, bool NORM, bool GUARD, bool F16 = false>
+__device__ __forceinline__ void store_kc(char* lds, const float4* reg, int i, int k0, int kend, const float* nmean, const float* nstd, int kbeg, float sc = 1.f) {
   const int f = threadIdx.x + 256 * i;
   const int row = f >> 2, kq = (f & 3) * 4;
   const int k = k0 + kq;
@@ -74,6 +99,14 @@ __device__ __forceinline__ void store_kc(char* lds, const float4* reg, int i, in
     v = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
   }
   char* dst = lds + row * Img<PLANES>::RS + kq * 2;
+  if (F16) {
+    unsigned h0, l0, h1, l1;
+    split2h(v.x * sc, v.y * sc, h0, l0);
+    split2h(v.z * sc, v.w * sc, h1, l1);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + 32) = make_uint2(l0, l1);
+    return;
+  }
   unsigned h[4], m[4], l[4];
   split3(v.x, h[0], m[0], l[0]);
   split3(v.y, h[1], m[1], l[1]);
@@ -92,8 +125,8 @@ __device__ __forceinline__ void load_mc(float4* reg, const float* __restrict__ P
   for (int i = 0; i < 2; ++i) reg[i] = *reinterpret_cast<const float4*>(P + (size_t)min(k + i, kend - 1) * ld + r);
 }
 // part i = rows rq+2i, rq+2i+1
-template <int PLANES, bool GUARD>
-__device__ __forceinline__ void store_mc(char* lds, const float4* reg, int i, int k0, int kend) {
+template <int PLANES, bool GUARD, bool F16 = false>
+__device__ __forceinline__ void store_mc(char* lds, const float4* reg, int i, int k0, int kend, float sc = 1.f) {
   const int kk2 = threadIdx.x & 7, rq = (threadIdx.x >> 3) * 4;
   const int k = k0 + 2 * kk2;
   const bool in0 = !GUARD || k < kend, in1 = !GUARD || k + 1 < kend;
@@ -102,6 +135,13 @@ __device__ __forceinline__ void store_mc(char* lds, const float4* reg, int i, in
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     char* dst = lds + (rq + 2 * i + j) * Img<PLANES>::RS + kk2 * 4;
+    if (F16) {
+      unsigned h, l;
+      split2h(in0 ? a[j] * sc : 0.f, in1 ? b[j] * sc : 0.f, h, l);
+      *reinterpret_cast<unsigned*>(dst) = h;
+      *reinterpret_cast<unsigned*>(dst + 32) = l;
+      continue;
+    }
     unsigned ha, ma, la, hb, mb, lb;
     split3(in0 ? a[j] : 0.f, ha, ma, la);
     split3(in1 ? b[j] : 0.f, hb, mb, lb);
@@ -115,9 +155,10 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int row, int plane, int 
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + row * rs + plane * 32 + h * 16));
 }
 
-template <bool AKC, bool BKC, int EPI, bool NORM, int PLANES>
+template <bool AKC, bool BKC, int EPI, bool NORM, int PLANES, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
   static_assert(!NORM || AKC, "fused normalisation needs a k-contiguous A");
+  static_assert(!F16 || (PLANES == 2 && !NORM), "the fp16 split keeps two planes and takes no fused normalisation (its scale needs the operand's maximum)");
   using I = Img<PLANES>;
   constexpr int STAGE = 2 * I::SIZE;
   constexpr int EPI_BYTES = 4 * addhip_epi::EpiBuf<2>::WAVE_BYTES;
@@ -150,6 +191,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
+  // F16: the operands' power-of-two scales; their inverse goes into the epilogue's alpha (exact)
+  const float sc_a = F16 ? scale_from_amax(g.a_amax) : 1.f, sc_b = F16 ? scale_from_amax(g.b_amax) : 1.f;
+  const float alpha = F16 ? g.alpha / sc_a / sc_b : g.alpha;
 
   // Register ring, DEPTH stages deep: one stage is only 24 MFMAs (768 cycles) per wave, far less than a global-load
   // round trip, so the loads of stage t+DEPTH are issued while stage t is multiplied.  Static ring indices (the K loop is
@@ -179,11 +223,11 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
     const int k0 = kbeg + min(kt, nk - 1) * BK;
     char* a_dst = lds + (kt & 1) * STAGE;
     if (q < 2) {
-      if (AKC) store_kc<PLANES, NORM, GUARD>(a_dst, a_reg, q, k0, kend, nmean, nstd, kbeg);
-      else store_mc<PLANES, GUARD>(a_dst, a_reg, q, k0, kend);
+      if (AKC) store_kc<PLANES, NORM, GUARD, F16>(a_dst, a_reg, q, k0, kend, nmean, nstd, kbeg, sc_a);
+      else store_mc<PLANES, GUARD, F16>(a_dst, a_reg, q, k0, kend, sc_a);
     } else {
-      if (BKC) store_kc<PLANES, false, GUARD>(a_dst + I::SIZE, b_reg, q - 2, k0, kend, nullptr, nullptr, 0);
-      else store_mc<PLANES, GUARD>(a_dst + I::SIZE, b_reg, q - 2, k0, kend);
+      if (BKC) store_kc<PLANES, false, GUARD, F16>(a_dst + I::SIZE, b_reg, q - 2, k0, kend, nullptr, nullptr, 0, sc_b);
+      else store_mc<PLANES, GUARD, F16>(a_dst + I::SIZE, b_reg, q - 2, k0, kend, sc_b);
     }
   };
   auto lds_barrier = [&]() {
@@ -192,6 +236,14 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
     asm volatile("" ::: "memory");
   };
   auto mfma_group = [&](int a, int b, const bf16x8 (*fa)[PLANES], const bf16x8 (*fb)[PLANES]) {
+    if constexpr (F16) {  // all four products of the two-way fp16 split, smallest first (the fragments hold fp16 bit patterns)
+      auto h = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[a][1]), h(fb[b][1]), acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[a][0]), h(fb[b][1]), acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[a][1]), h(fb[b][0]), acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[a][0]), h(fb[b][0]), acc[a][b], 0, 0, 0);
+      return;
+    }
     if (PLANES == 3) {  // smallest terms first
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
@@ -232,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
     stash_part(std::false_type{}, 3, kt + 1, a_next, b_next);
     if (PLANES >= 2) {
       // pin the interleave: the split's VALU work spread evenly over the MFMAs, a DS write after every second (third) one
-      constexpr int NM = PLANES == 3 ? 24 : 12, PER = PLANES == 3 ? 5 : 8;
+      constexpr int NM = F16 ? 16 : PLANES == 3 ? 24 : 12, PER = F16 ? 6 : PLANES == 3 ? 5 : 8;
 #pragma unroll
       for (int i = 0; i < NM; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -273,19 +325,20 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
   // epilogue (gemm_epilogue.h): every wave's block leaves through its private slice of the stage buffers, once every wave is done
   // reading them
   __syncthreads();
-  addhip_epi::gemm_epilogue<2, 2, EPI>(g, acc, lds + wave * addhip_epi::EpiBuf<2>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z);
+  addhip_epi::gemm_epilogue<2, 2, EPI>(g, acc, lds + wave * addhip_epi::EpiBuf<2>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z, alpha);
 }
 
-template <int PLANES>
+template <int PLANES, bool F16 = false>
 int launch_split(const addhip_gemm_t& g, hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int split = g.split_k > 1 ? g.split_k : 1;
   dim3 grid(tiles_m * tiles_n, 1, split), block(256);
   const bool norm = g.a_mean != nullptr;
 #define ADDHIP_LAUNCH(AK, BKc, EPI, NORM) \
-  hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, EPI, NORM, PLANES>), grid, block, 0, st, g, tiles_m, tiles_n)
+  hipLaunchKernelGGL((gemm_split_kernel<AK, BKc, EPI, (NORM) && !F16, PLANES, F16>), grid, block, 0, st, g, tiles_m, tiles_n)
   if (g.a_kcontig && g.b_kcontig) {
     if (norm) {
+      if (F16) return (addhip::set_error("gemm: the fp16 split takes no fused normalisation"), -1);
       if (g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_BIAS_RELU, true);
       else return (addhip::set_error("gemm: fused normalisation is only built for the bias+ReLU epilogue"), -1);
     } else if (g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_BIAS_RELU, false);
@@ -310,6 +363,9 @@ namespace addhip {
 // called by addhip_gemm_f32 (gemm.hip) after argument validation, for the shapes that fill the chip with 128x128 tiles
 int gemm_split_dispatch(const addhip_gemm_t& g, int planes, hipStream_t st) {
   if (g.a_mean && g.K > 512) return (set_error("gemm: fused normalisation on the bf16 paths needs K <= 512"), -1);
+  // ADDHIP_PREC_F16X2 needs both operand bounds and no fused normalisation (the normalised values' maximum is not tracked): otherwise the
+  // exact bf16 split, which needs neither
+  if (planes == ADDHIP_PREC_F16X2) return (g.a_amax && g.b_amax && !g.a_mean) ? launch_split<2, true>(g, st) : launch_split<3>(g, st);
   return planes == 3 ? launch_split<3>(g, st) : planes == 2 ? launch_split<2>(g, st) : launch_split<1>(g, st);
 }
 }  // namespace addhip

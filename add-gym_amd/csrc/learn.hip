@@ -4,6 +4,7 @@
 // one wavefront per row with 64-lane shuffle reductions, or one thread per element, coalesced.
 // Reference functions restated: see include/addhip.h at each entry point.
 #include "common.h"
+#include "planes.h"
 #include "record.h"
 #include "philox.h"
 
@@ -36,6 +37,23 @@ __device__ __forceinline__ unsigned short bf16_rne(float v) {
 }
 __device__ __forceinline__ uint2 bf16_pack4(float4 o) {
   return make_uint2((unsigned)bf16_rne(o.x) | ((unsigned)bf16_rne(o.y) << 16), (unsigned)bf16_rne(o.z) | ((unsigned)bf16_rne(o.w) << 16));
+}
+
+// running max |v| of a thread -> one atomic per wave on slot (block % ADDHIP_AMAX_SLOTS) (the operand bounds of ADDHIP_PREC_F16X2 GEMMs)
+__device__ __forceinline__ void amax_commit(unsigned* slots, float amx) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(&slots[blockIdx.x % ADDHIP_AMAX_SLOTS], __float_as_uint(amx));
+}
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long count, unsigned* slots) {
+  float amx = 0.f;
+  const long long n4 = count >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (count & 3)) amx = fmaxf(amx, fabsf(x[(n4 << 2) + threadIdx.x]));
+  amax_commit(slots, amx);
 }
 
 inline int row_grid(long long rows) {  // 4 waves (rows) per 256-thread block, grid-stride
@@ -307,12 +325,17 @@ __global__ void diffnorm_merge_kernel(float* mean_abs, long long* count, float* 
 // ------------------------------------------------------------------ minibatch gather
 __global__ __launch_bounds__(256) void gather_kernel(addhip_gather_t g) {
   const int lane = threadIdx.x & 63;
+  float amx_o = 0.f, amx_d = 0.f;
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < g.count; r += gridDim.x * 4) {
     const long long src = g.idx[r];
     for (int c = lane; c < g.obs_stride; c += 64) {
       const float v = c < g.obs_dim ? (g.obs[src * g.obs_stride + c] - g.obs_mean[c]) / g.obs_std[c] : 0.f;
       g.norm_obs[(size_t)r * g.obs_stride + c] = v;
-      if (g.norm_obs16) g.norm_obs16[(size_t)r * g.obs_stride + c] = bf16_rne(v);
+      amx_o = fmaxf(amx_o, fabsf(v));
+      if (g.norm_obs16) {
+        if (g.planes16 == ADDHIP_STORE_BF16X3) addhip_planes::store1(g.norm_obs16 + 3 * (size_t)r * g.obs_stride, c, v);
+        else g.norm_obs16[(size_t)r * g.obs_stride + c] = bf16_rne(v);
+      }
     }
     if (lane < 32)
       g.norm_action[(size_t)r * 32 + lane] = lane < ADDHIP_NUM_DOF ? (g.action[src * 32 + lane] - g.a_mean[lane]) / g.a_std[lane] : 0.f;
@@ -320,7 +343,11 @@ __global__ __launch_bounds__(256) void gather_kernel(addhip_gather_t g) {
       float v = 0.f;
       if (c < g.disc_dim) v = (g.disc_demo[src * g.disc_stride + c] - g.disc_obs[src * g.disc_stride + c]) / fmaxf(g.mean_abs[c], g.min_diff);
       g.norm_diff[(size_t)r * g.disc_stride + c] = v;
-      if (g.norm_diff16) g.norm_diff16[(size_t)r * g.disc_stride + c] = bf16_rne(v);
+      amx_d = fmaxf(amx_d, fabsf(v));
+      if (g.norm_diff16) {
+        if (g.planes16 == ADDHIP_STORE_BF16X3) addhip_planes::store1(g.norm_diff16 + 3 * (size_t)r * g.disc_stride, c, v);
+        else g.norm_diff16[(size_t)r * g.disc_stride + c] = bf16_rne(v);
+      }
     }
     if (lane == 0) {
       g.o_logp[r] = g.a_logp[src];
@@ -329,6 +356,8 @@ __global__ __launch_bounds__(256) void gather_kernel(addhip_gather_t g) {
       g.o_mask[r] = g.rand_mask[src];
     }
   }
+  if (g.obs_amax) amax_commit(g.obs_amax, amx_o);
+  if (g.diff_amax) amax_commit(g.diff_amax, amx_d);
 }
 
 // ------------------------------------------------------------------ loss heads
@@ -450,8 +479,9 @@ __global__ __launch_bounds__(256) void disc_head_kernel(const float* H, int ld, 
   if (threadIdx.x == 0) { atomicAdd(&stats[0], t0); atomicAdd(&stats[2], t2); atomicAdd(&stats[4], t4); }
 }
 
-__global__ void outer_mask_kernel(const float* v, const float* w, const float* H, int ld, int K, long long rows, float* out, unsigned short* out16) {
+__global__ void outer_mask_kernel(const float* v, const float* w, const float* H, int ld, int K, long long rows, float* out, unsigned short* out16, int planes16, unsigned* amax) {
   const long long n = rows * (K / 4);
+  float amx = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     long long r = i / (K / 4);
     int k = (int)(i - r * (K / 4)) * 4;
@@ -460,8 +490,13 @@ __global__ void outer_mask_kernel(const float* v, const float* w, const float* H
     float s = v ? v[r] : 1.f;
     float4 o = make_float4(h.x > 0.f ? s * ww.x : 0.f, h.y > 0.f ? s * ww.y : 0.f, h.z > 0.f ? s * ww.z : 0.f, h.w > 0.f ? s * ww.w : 0.f);
     if (out) *reinterpret_cast<float4*>(out + r * ld + k) = o;
-    if (out16) *reinterpret_cast<uint2*>(out16 + r * ld + k) = bf16_pack4(o);
+    if (out16) {
+      if (planes16 == ADDHIP_STORE_BF16X3) addhip_planes::store4(out16 + 3 * r * ld, k, o);
+      else *reinterpret_cast<uint2*>(out16 + r * ld + k) = bf16_pack4(o);
+    }
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
+  if (amax) amax_commit(amax, amx);  // (uniform)
 }
 
 // One pass over the last hidden layer's activations H for everything a scalar head needs in the backward direction:
@@ -472,14 +507,14 @@ __global__ void outer_mask_kernel(const float* v, const float* w, const float* H
 // A lane owns the same columns for every row its wave visits, so the column sums are per-lane registers; the four waves
 // of a workgroup are combined in LDS and each workgroup issues one atomic per column.  K <= 1024.
 __global__ __launch_bounds__(256) void head_backward_kernel(const float* v, const float* w, const float* H, int ld, int K, long long rows, float* dZ,
-                                                            unsigned short* dZ16, float* dW, float* db, float* dbt) {
+                                                            unsigned short* dZ16, int planes16, float* dW, float* db, float* dbt, unsigned* amax) {
   __shared__ float red[4][1024];
   __shared__ float sh[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 gw[4], gb[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) gw[j] = gb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float sv = 0.f;
+  float sv = 0.f, amx = 0.f;
   for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
     const float s = v[r];
     if (lane == 0) sv += s;
@@ -491,9 +526,13 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* v, cons
         const float4 ww = *reinterpret_cast<const float4*>(w + k);
         const float4 o = make_float4(h.x > 0.f ? s * ww.x : 0.f, h.y > 0.f ? s * ww.y : 0.f, h.z > 0.f ? s * ww.z : 0.f, h.w > 0.f ? s * ww.w : 0.f);
         if (dZ) *reinterpret_cast<float4*>(dZ + r * ld + k) = o;
-        if (dZ16) *reinterpret_cast<uint2*>(dZ16 + r * ld + k) = bf16_pack4(o);
+        if (dZ16) {
+          if (planes16 == ADDHIP_STORE_BF16X3) addhip_planes::store4(dZ16 + 3 * r * ld, k, o);
+          else *reinterpret_cast<uint2*>(dZ16 + r * ld + k) = bf16_pack4(o);
+        }
         gw[j].x += s * h.x; gw[j].y += s * h.y; gw[j].z += s * h.z; gw[j].w += s * h.w;
         gb[j].x += o.x; gb[j].y += o.y; gb[j].z += o.z; gb[j].w += o.w;
+        amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
       }
     }
   }
@@ -511,12 +550,13 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* v, cons
   }
   const float t = block_sum(sv, sh);
   if (threadIdx.x == 0 && db) atomicAdd(db, t);
+  if (amax) amax_commit(amax, amx);
 }
 
-__global__ __launch_bounds__(256) void grad_penalty_kernel(const float* g, int ld, int dim, int M, float coef, float* G, unsigned short* G16, float* stats) {
+__global__ __launch_bounds__(256) void grad_penalty_kernel(const float* g, int ld, int dim, int M, float coef, float* G, unsigned short* G16, int planes16, float* stats, unsigned* amax) {
   __shared__ float sh[4];
   const int lane = threadIdx.x & 63;
-  float sp = 0.f;
+  float sp = 0.f, amx = 0.f;
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
     float sq = 0.f;
     for (int c = lane; c < dim; c += 64) { float x = g[(size_t)r * ld + c]; sq += x * x; }
@@ -526,12 +566,17 @@ __global__ __launch_bounds__(256) void grad_penalty_kernel(const float* g, int l
     for (int c = lane; c < ld; c += 64) {
       const float o = c < dim ? f * g[(size_t)r * ld + c] : 0.f;
       if (G) G[(size_t)r * ld + c] = o;
-      if (G16) G16[(size_t)r * ld + c] = bf16_rne(o);
+      amx = fmaxf(amx, fabsf(o));
+      if (G16) {
+        if (planes16 == ADDHIP_STORE_BF16X3) addhip_planes::store1(G16 + 3 * (size_t)r * ld, c, o);
+        else G16[(size_t)r * ld + c] = bf16_rne(o);
+      }
     }
     if (lane == 0) sp += (n - 1.f) * (n - 1.f);
   }
   float t = block_sum(sp, sh);
   if (threadIdx.x == 0) atomicAdd(&stats[0], t);
+  if (amax) amax_commit(amax, amx);
 }
 
 __global__ __launch_bounds__(256) void weighted_col_sum_kernel(const float* v, const float* X, int ld, int K, long long rows, float* out, float scale,
@@ -625,8 +670,10 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(addhip_optimizer_t 
     p4[i] = p;
     m4[i] = m;
     if (!SGD) v4[i] = v;
-    if (o.param16)
-      reinterpret_cast<uint2*>(o.param16)[i] = make_uint2((unsigned)opt_bf16(p.x) | ((unsigned)opt_bf16(p.y) << 16), (unsigned)opt_bf16(p.z) | ((unsigned)opt_bf16(p.w) << 16));
+    if (o.param16) {
+      if (o.param16_planes == ADDHIP_STORE_BF16X3) addhip_planes::store4_flat(o.param16, 4 * i, p);
+      else reinterpret_cast<uint2*>(o.param16)[i] = make_uint2((unsigned)opt_bf16(p.x) | ((unsigned)opt_bf16(p.y) << 16), (unsigned)opt_bf16(p.z) | ((unsigned)opt_bf16(p.w) << 16));
+    }
     if (o.zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (blockIdx.x == 0 && threadIdx.x < (o.count & 3)) {  // (count % 4 elements past the last float4)
@@ -810,11 +857,23 @@ extern "C" int addhip_diffnorm_merge(float* mean_abs, int64_t* count, float* abs
   return addhip::check_launch("diffnorm_merge_kernel");
 }
 
+extern "C" int addhip_amax_f32(const float* x, int64_t count, uint32_t* slots, void* stream) {
+  ADDHIP_REQUIRE(x && slots && count > 0 && aligned16(x), "amax_f32: bad arguments (16-byte aligned input)");
+  ADDHIP_RECORDABLE(addhip_amax_f32, x, count, slots);
+  long long blocks = ((count >> 2) + 255) / 256;
+  blocks = blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks;
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, ST, x, (long long)count, slots);
+  return addhip::check_launch("amax_kernel");
+}
+
 extern "C" int addhip_gather_minibatch(const addhip_gather_t* g, void* stream) {
   ADDHIP_REQUIRE(g && g->idx && g->count > 0, "gather: bad arguments");
   ADDHIP_REQUIRE(g->obs && g->obs_mean && g->obs_std && g->action && g->a_mean && g->a_std && g->a_logp && g->adv && g->tar_val && g->rand_mask &&
                      g->disc_obs && g->disc_demo && g->mean_abs, "gather: source pointers missing");
   ADDHIP_REQUIRE(g->norm_obs && g->norm_action && g->o_logp && g->o_adv && g->o_tar_val && g->o_mask && g->norm_diff, "gather: output pointers missing");
+  ADDHIP_REQUIRE(g->planes16 == 0 || g->planes16 == ADDHIP_STORE_BF16 ||
+                     (g->planes16 == ADDHIP_STORE_BF16X3 && g->obs_stride % 8 == 0 && g->disc_stride % 8 == 0 && aligned16(g->norm_obs16) && aligned16(g->norm_diff16)),
+                 "gather: planes16 is an ADDHIP_STORE_* format (plane storage: row strides %% 8 == 0, 16-byte aligned buffers)");
   ADDHIP_RECORDABLE(addhip_gather_minibatch, g);
   hipLaunchKernelGGL(gather_kernel, dim3(row_grid(g->count)), dim3(256), 0, ST, *g);
   return addhip::check_launch("gather_kernel");
@@ -859,29 +918,37 @@ extern "C" int addhip_disc_head(const float* H, int32_t ld, int32_t K, int32_t M
 extern "C" int addhip_outer_mask(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, void* stream) {
   ADDHIP_REQUIRE(v && w && H && out && rows > 0 && K % 4 == 0 && ld % 4 == 0, "outer_mask: bad arguments");
   ADDHIP_RECORDABLE(addhip_outer_mask, v, w, H, ld, K, rows, out);
-  hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, out, (unsigned short*)nullptr);
+  hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, out, (unsigned short*)nullptr, 0, (unsigned*)nullptr);
   return addhip::check_launch("outer_mask_kernel");
 }
-extern "C" int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, uint16_t* out16, void* stream) {
+#define ADDHIP_CHECK_PLANES16(who, buf, ldv)                                                                                                   \
+  ADDHIP_REQUIRE(planes16 == 0 || planes16 == ADDHIP_STORE_BF16 || (planes16 == ADDHIP_STORE_BF16X3 && (!(buf) || ((ldv) % 8 == 0 && aligned16(buf)))), \
+                 who ": planes16 is an ADDHIP_STORE_* format (plane storage: row length %% 8 == 0, 16-byte aligned buffer)")
+extern "C" int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, uint16_t* out16, int32_t planes16, uint32_t* amax,
+                                 void* stream) {
   ADDHIP_REQUIRE(w && H && (out || out16) && rows > 0 && K % 4 == 0 && ld % 4 == 0, "bcast_mask: bad arguments");
-  ADDHIP_RECORDABLE(addhip_bcast_mask, w, H, ld, K, rows, out, out16);
-  hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, (const float*)nullptr, w, H, ld, K, (long long)rows, out, out16);
+  ADDHIP_CHECK_PLANES16("bcast_mask", out16, ld);
+  ADDHIP_RECORDABLE(addhip_bcast_mask, w, H, ld, K, rows, out, out16, planes16, amax);
+  hipLaunchKernelGGL(outer_mask_kernel, dim3(elem_grid(rows * (K / 4))), dim3(256), 0, ST, (const float*)nullptr, w, H, ld, K, (long long)rows, out, out16, planes16, amax);
   return addhip::check_launch("outer_mask_kernel(bcast)");
 }
 
 extern "C" int addhip_head_backward(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* dZ, uint16_t* dZ16,
-                                    float* dW_head, float* db_head, float* db_top, void* stream) {
+                                    int32_t planes16, float* dW_head, float* db_head, float* db_top, uint32_t* amax, void* stream) {
   ADDHIP_REQUIRE(v && w && H && rows > 0 && K > 0 && K <= 1024 && K % 4 == 0 && ld % 4 == 0 && ld >= K, "head_backward: bad arguments (K <= 1024)");
-  ADDHIP_RECORDABLE(addhip_head_backward, v, w, H, ld, K, rows, dZ, dZ16, dW_head, db_head, db_top);
+  ADDHIP_CHECK_PLANES16("head_backward", dZ16, ld);
+  ADDHIP_RECORDABLE(addhip_head_backward, v, w, H, ld, K, rows, dZ, dZ16, planes16, dW_head, db_head, db_top, amax);
   const int grid = row_grid(rows) < 256 ? row_grid(rows) : 256;
-  hipLaunchKernelGGL(head_backward_kernel, dim3(grid), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, dZ, dZ16, dW_head, db_head, db_top);
+  hipLaunchKernelGGL(head_backward_kernel, dim3(grid), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, dZ, dZ16, planes16, dW_head, db_head, db_top, amax);
   return addhip::check_launch("head_backward_kernel");
 }
 
-extern "C" int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, uint16_t* G16, float* stats, void* stream) {
+extern "C" int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, uint16_t* G16, int32_t planes16, float* stats, uint32_t* amax,
+                                   void* stream) {
   ADDHIP_REQUIRE(g && (G || G16) && stats && M > 0 && dim <= ld, "grad_penalty: bad arguments");
-  ADDHIP_RECORDABLE(addhip_grad_penalty, g, ld, dim, M, coef, G, G16, stats);
-  hipLaunchKernelGGL(grad_penalty_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, g, ld, dim, M, coef, G, G16, stats);
+  ADDHIP_CHECK_PLANES16("grad_penalty", G16, ld);
+  ADDHIP_RECORDABLE(addhip_grad_penalty, g, ld, dim, M, coef, G, G16, planes16, stats, amax);
+  hipLaunchKernelGGL(grad_penalty_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, g, ld, dim, M, coef, G, G16, planes16, stats, amax);
   return addhip::check_launch("grad_penalty_kernel");
 }
 
@@ -936,6 +1003,8 @@ extern "C" int addhip_optimizer_step(const addhip_optimizer_t* op, void* stream)
   ADDHIP_REQUIRE(o.param && o.grad && o.state1 && (o.state2 || o.type == ADDHIP_OPT_SGD) && o.count > 0 && o.step >= 1, "optimizer_step: bad arguments");
   ADDHIP_REQUIRE(aligned16(o.param) && aligned16(o.grad) && aligned16(o.state1) && (o.type == ADDHIP_OPT_SGD || aligned16(o.state2)) &&
                      (reinterpret_cast<uintptr_t>(o.param16) & 7u) == 0, "optimizer_step: buffers must be 16-byte aligned (the bf16 shadow: 8)");
+  ADDHIP_REQUIRE(o.param16_planes == 0 || o.param16_planes == ADDHIP_STORE_BF16 || (o.param16_planes == ADDHIP_STORE_BF16X3 && o.count % 8 == 0 && aligned16(o.param16)),
+                 "optimizer_step: param16_planes is an ADDHIP_STORE_* format (plane storage: count %% 8 == 0, 16-byte aligned shadow)");
   long long blocks = ((o.count >> 2) + 255) / 256;
   blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
   if (o.type == ADDHIP_OPT_SGD) {

@@ -34,10 +34,24 @@ int split_k_for(int out_dim, int in_dim, int64_t rows) {
   return s;
 }
 
-bool storage16(const addhip_mlp_t& n) { return n.precision == ADDHIP_PREC_BF16; }
+// 16-bit storage of the net's GEMM operands: 0 = none (fp32 operands), ADDHIP_STORE_BF16 (bf16 storage), ADDHIP_STORE_BF16X3 (plane storage)
+int store_fmt(const addhip_mlp_t& n) { return n.storage == ADDHIP_STORE_BF16X3 ? ADDHIP_STORE_BF16X3 : n.precision == ADDHIP_PREC_BF16 ? ADDHIP_STORE_BF16 : 0; }
+bool storage16(const addhip_mlp_t& n) { return store_fmt(n) != 0; }  // (either format: the *16 buffers are the operands)
 void set_prec(addhip_gemm_t& g, const addhip_mlp_t& n) {
   g.precision = n.precision;
-  g.operands_bf16 = storage16(n) ? 1 : 0;
+  g.operands_bf16 = store_fmt(n);
+  g.c16_planes = store_fmt(n);
+}
+
+// ADDHIP_PREC_F16X2: the net's tracked-maximum slots of tensor t (include/addhip.h: ADDHIP_MLP_AMAX_*), or NULL in every other mode
+constexpr int AMAX_H = ADDHIP_MLP_AMAX_H, AMAX_DZ = ADDHIP_MLP_AMAX_DZ, AMAX_A2 = ADDHIP_MLP_AMAX_A2, AMAX_A1 = ADDHIP_MLP_AMAX_A1, AMAX_G = ADDHIP_MLP_AMAX_G,
+              AMAX_E1 = ADDHIP_MLP_AMAX_E1;
+bool f16x2(const addhip_mlp_t& n) { return n.precision == ADDHIP_PREC_F16X2 && n.amax && n.w_amax; }
+uint32_t* amax_of(const addhip_mlp_t& n, int t) { return f16x2(n) ? n.amax + (size_t)t * ADDHIP_AMAX_SLOTS : nullptr; }
+void set_amax(addhip_gemm_t& g, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  g.a_amax = a;
+  g.b_amax = b;
+  g.amax_out = out;
 }
 
 // A few rows past a multiple of 128 (the discriminator's extra zero-difference sample: Mb + 1 rows) would cost a whole extra round of
@@ -69,9 +83,11 @@ int check_net(const addhip_mlp_t* net, int64_t rows, const char* who) {
   ADDHIP_REQUIRE(net->num_hidden >= 1 && net->num_hidden <= ADDHIP_MLP_MAX_HIDDEN, "%s: 1..%d hidden layers", who, ADDHIP_MLP_MAX_HIDDEN);
   ADDHIP_REQUIRE(rows > 0 && rows <= net->rows_cap, "%s: %lld rows, workspace holds %d", who, (long long)rows, net->rows_cap);
   ADDHIP_REQUIRE(net->in_ld >= net->in_dim && net->in_dim > 0, "%s: bad input width", who);
+  ADDHIP_REQUIRE(net->storage == 0 || (net->storage == ADDHIP_STORE_BF16 && net->precision == ADDHIP_PREC_BF16) || net->storage == ADDHIP_STORE_BF16X3,
+                 "%s: storage is 0, ADDHIP_STORE_BF16 (with precision ADDHIP_PREC_BF16) or ADDHIP_STORE_BF16X3", who);
   for (int i = 0; i < net->num_hidden; ++i) {
     ADDHIP_REQUIRE(net->hidden[i] > 0 && net->W[i] && net->b[i] && net->hbits[i], "%s: layer %d incomplete", who, i);
-    if (storage16(*net)) ADDHIP_REQUIRE(net->W16[i] && net->h16[i] && net->dz16[i], "%s: layer %d lacks its bf16 buffers (precision = bf16 storage)", who, i);
+    if (storage16(*net)) ADDHIP_REQUIRE(net->W16[i] && net->h16[i] && net->dz16[i], "%s: layer %d lacks its bf16 / plane-storage buffers", who, i);
     else ADDHIP_REQUIRE(net->h[i] && net->dz[i], "%s: layer %d lacks its fp32 buffers", who, i);
   }
   ADDHIP_REQUIRE(!storage16(*net) || net->h[net->num_hidden - 1], "%s: the last hidden layer is kept in fp32 too (loss heads)", who);
@@ -86,16 +102,18 @@ int check_net(const addhip_mlp_t* net, int64_t rows, const char* who) {
 
 int refresh_transposed(const addhip_mlp_t& net, int& launches, void* stream) {
   if (storage16(net) && net.t_count > 0)
-    LAUNCH(addhip_shadow_refresh(net.flat_params, nullptr, net.flat_trans16, net.flat_count, net.t_offset, net.t_rows, net.t_cols, net.t_count, stream));
+    LAUNCH(addhip_shadow_refresh(net.flat_params, nullptr, net.flat_trans16, net.flat_count, net.t_offset, net.t_rows, net.t_cols, net.t_count, store_fmt(net), stream));
   return 0;
 }
 
 int forward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64_t rows, const float* a_mean, const float* a_std, bool sign_bits, int& launches,
-            void* stream) {
+            void* stream, const uint32_t* x_amax = nullptr) {
   const int n = net.num_hidden;
   const bool s16 = storage16(net);
+  // the fp16 split: this pass (and the loss / backward kernels behind it) rewrites the net's tracked maxima -- they start from zero
+  if (f16x2(net)) LAUNCH(addhip_fill_zero(reinterpret_cast<float*>(net.amax), ADDHIP_MLP_AMAX_TENSORS * ADDHIP_AMAX_SLOTS, stream));
   const char* prev = reinterpret_cast<const char*>(s16 ? static_cast<const void*>(x16) : static_cast<const void*>(x));
-  const int esz = s16 ? 2 : 4;
+  const int esz = s16 ? 2 * store_fmt(net) : 4;  // bytes per value of the operand rows
   int ld = net.in_ld, k = net.in_ld;
   for (int i = 0; i < n; ++i) {
     const int h = net.hidden[i];
@@ -107,7 +125,7 @@ int forward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64_
                              C, h, ADDHIP_EPI_BIAS_RELU, net.b[i]);
       set_prec(g, net);
       if (s16) {
-        g.C16 = net.h16[i] + r0 * h;
+        g.C16 = net.h16[i] + store_fmt(net) * r0 * h;
         g.ldc16 = h;
       } else if (i == 0) {
         g.a_mean = a_mean;
@@ -117,6 +135,7 @@ int forward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64_
         g.relu_bits = net.hbits[i] + r0 * ((h + 31) / 32);
         g.ldbits = (h + 31) / 32;
       }
+      if (f16x2(net)) set_amax(g, i == 0 ? x_amax : amax_of(net, AMAX_H + i - 1), net.w_amax, amax_of(net, AMAX_H + i));
       LAUNCH(addhip_gemm_f32(&g, stream));
     }
     prev = reinterpret_cast<const char*>(s16 ? static_cast<const void*>(net.h16[i]) : static_cast<const void*>(net.h[i]));
@@ -127,15 +146,17 @@ int forward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64_
 }
 
 int backward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64_t rows, const addhip_extra_dw_t* extra, int flags, addhip_mlp_marks_t* marks,
-             int& launches, void* stream) {
+             int& launches, void* stream, const uint32_t* x_amax = nullptr) {
   const int n = net.num_hidden;
   const bool s16 = storage16(net);
-  const int esz = s16 ? 2 : 4;
+  const int esz = s16 ? 2 * store_fmt(net) : 4;
   const bool zeroed = flags & ADDHIP_BWD_GRADS_ZEROED, bits_valid = flags & ADDHIP_BWD_SIGN_BITS;
   const int base = launches;
   auto dz_ptr = [&](int i) { return reinterpret_cast<const char*>(s16 ? static_cast<const void*>(net.dz16[i]) : static_cast<const void*>(net.dz[i])); };
-  if (s16 && !(flags & ADDHIP_BWD_TOP_CAST_DONE))
-    LAUNCH(addhip_to_bf16(net.dz[n - 1], net.dz16[n - 1], rows, net.hidden[n - 1], net.hidden[n - 1], net.hidden[n - 1], stream));
+  if (s16 && !(flags & ADDHIP_BWD_TOP_CAST_DONE)) {
+    if (store_fmt(net) == ADDHIP_STORE_BF16X3) LAUNCH(addhip_to_bf16x3(net.dz[n - 1], net.dz16[n - 1], rows, net.hidden[n - 1], net.hidden[n - 1], net.hidden[n - 1], stream));
+    else LAUNCH(addhip_to_bf16(net.dz[n - 1], net.dz16[n - 1], rows, net.hidden[n - 1], net.hidden[n - 1], net.hidden[n - 1], stream));
+  }
   for (int i = n - 1; i >= 0; --i) {
     const int out_d = net.hidden[i], in_ld = i == 0 ? net.in_ld : net.hidden[i - 1];
     const void* inp = i == 0 ? (s16 ? static_cast<const void*>(x16) : static_cast<const void*>(x))
@@ -151,6 +172,7 @@ int backward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64
       addhip_gemm_t g = gemm(out_d, in_ld, (int)rows, dz_ptr(i), out_d, 0, inp, in_ld, 0, slabs, in_ld);
       g.split_k = s;
       set_prec(g, net);
+      if (f16x2(net)) set_amax(g, amax_of(net, AMAX_DZ + i), i == 0 ? x_amax : amax_of(net, AMAX_H + i - 1), nullptr);
       LAUNCH(addhip_gemm_f32(&g, stream));
     }
     int total = s;
@@ -158,6 +180,7 @@ int backward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64
       addhip_gemm_t g = gemm(out_d, in_ld, (int)extra[i].rows, extra[i].A, extra[i].lda, 0, extra[i].B, extra[i].ldb, 0, slabs + (int64_t)s * slab, in_ld);
       g.split_k = s;
       set_prec(g, net);
+      if (f16x2(net)) set_amax(g, extra[i].a_amax, extra[i].b_amax, nullptr);
       LAUNCH(addhip_gemm_f32(&g, stream));
       total = 2 * s;
     }
@@ -197,10 +220,11 @@ int backward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64
         }
         set_prec(g, net);
         if (s16) {
-          g.C16 = net.dz16[i - 1] + r0 * prev_d;
+          g.C16 = net.dz16[i - 1] + store_fmt(net) * r0 * prev_d;
           g.ldc16 = prev_d;
         }
         set_mask(g, net, i - 1, r0, cnt, bits_valid);
+        if (f16x2(net)) set_amax(g, amax_of(net, AMAX_DZ + i), net.w_amax, amax_of(net, AMAX_DZ + i - 1));
         LAUNCH(addhip_gemm_f32(&g, stream));
       }
     }
@@ -212,16 +236,16 @@ int backward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64
 }  // namespace
 
 extern "C" int addhip_mlp_forward(const addhip_mlp_t* net, const float* x, const uint16_t* x16, int64_t rows, const float* a_mean, const float* a_std,
-                                  int32_t sign_bits, void* stream) {
+                                  int32_t sign_bits, const uint32_t* x_amax, void* stream) {
   if (int rc = check_net(net, rows, "mlp_forward")) return rc;
   ADDHIP_REQUIRE(storage16(*net) ? (x16 && !a_mean) : (x != nullptr), "mlp_forward: bf16 storage takes x16 (already normalised), the other modes x");
   ADDHIP_REQUIRE((a_mean == nullptr) == (a_std == nullptr), "mlp_forward: a_mean and a_std come together");
   int launches = 0;
-  return forward(*net, x, x16, rows, a_mean, a_std, sign_bits != 0, launches, stream);
+  return forward(*net, x, x16, rows, a_mean, a_std, sign_bits != 0, launches, stream, x_amax);
 }
 
 extern "C" int addhip_mlp_backward(const addhip_mlp_t* net, const float* x, const uint16_t* x16, int64_t rows, const addhip_extra_dw_t* extra, int32_t flags,
-                                   addhip_mlp_marks_t* marks, void* stream) {
+                                   addhip_mlp_marks_t* marks, const uint32_t* x_amax, void* stream) {
   if (int rc = check_net(net, rows, "mlp_backward")) return rc;
   ADDHIP_REQUIRE(storage16(*net) ? (x16 != nullptr) : (x != nullptr), "mlp_backward: input rows missing");
   ADDHIP_REQUIRE(net->slabs && net->slab_floats > 0, "mlp_backward: split-K scratch missing");
@@ -229,7 +253,7 @@ extern "C" int addhip_mlp_backward(const addhip_mlp_t* net, const float* x, cons
   for (int i = 0; i < net->num_hidden; ++i) ADDHIP_REQUIRE(net->gW[i] && net->gb[i], "mlp_backward: gradient of layer %d missing", i);
   if (marks) memset(marks, 0, sizeof(*marks));
   int launches = 0;
-  return backward(*net, x, x16, rows, extra, flags, marks, launches, stream);
+  return backward(*net, x, x16, rows, extra, flags, marks, launches, stream, x_amax);
 }
 
 extern "C" int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, void* stream) {
@@ -252,7 +276,7 @@ extern "C" int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_ma
   int launches = 0;
   addhip_mlp_marks_t mk;
   // ---- actor (ppo_agent.py:194-232, 247-275)
-  if (int rc = forward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, nullptr, true, launches, stream)) return rc;
+  if (int rc = forward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, nullptr, true, launches, stream, d->norm_obs_amax)) return rc;
   if (int rc = refresh_transposed(A, launches, stream)) return rc;  // beside the other nets' GEMMs (the optimiser step wrote the flat shadow)
   {
     addhip_gemm_t g = gemm(Mb, 32, hA, A.h[nA - 1], hA, 1, A.Wh, hA, 1, d->mean, 32, ADDHIP_EPI_BIAS, A.bh);
@@ -282,21 +306,23 @@ extern "C" int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_ma
     if (s16) {
       g.C16 = A.dz16[nA - 1];
       g.ldc16 = hA;
+      g.c16_planes = store_fmt(A);
     }
     set_mask(g, A, nA - 1, 0, Mb, true);
+    g.amax_out = amax_of(A, AMAX_DZ + nA - 1);  // (d_mean's own maximum is not tracked: this launch runs the exact bf16 split or the fp32 MFMA)
     LAUNCH(addhip_gemm_f32(&g, stream));
   }
   int at = launches;
-  if (int rc = backward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, bwd | (top_reps ? ADDHIP_BWD_TOP_BIAS_REPLICAS : 0), &mk, launches, stream)) return rc;
+  if (int rc = backward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, bwd | (top_reps ? ADDHIP_BWD_TOP_BIAS_REPLICAS : 0), &mk, launches, stream, d->norm_obs_amax)) return rc;
   const int actor_early = at + mk.early, actor_end = launches;
   // ---- critic (ppo_agent.py:234-245, base_agent.py:522-546)
-  if (int rc = forward(Cn, d->norm_obs, d->norm_obs16, Mb, nullptr, nullptr, true, launches, stream)) return rc;
+  if (int rc = forward(Cn, d->norm_obs, d->norm_obs16, Mb, nullptr, nullptr, true, launches, stream, d->norm_obs_amax)) return rc;
   if (int rc = refresh_transposed(Cn, launches, stream)) return rc;
   LAUNCH(addhip_critic_head(Cn.h[nC - 1], hC, hC, Mb, Cn.Wh, Cn.bh, d->tar_val, d->critic_loss_weight * d->grad_scale, nullptr, d->dv, d->stats + 8, stream));
-  LAUNCH(addhip_head_backward(d->dv, Cn.Wh, Cn.h[nC - 1], hC, hC, Mb, s16 ? nullptr : Cn.dz[nC - 1], s16 ? Cn.dz16[nC - 1] : nullptr, Cn.gWh, Cn.gbh, Cn.gb[nC - 1],
-                              stream));
+  LAUNCH(addhip_head_backward(d->dv, Cn.Wh, Cn.h[nC - 1], hC, hC, Mb, s16 ? nullptr : Cn.dz[nC - 1], s16 ? Cn.dz16[nC - 1] : nullptr, store_fmt(Cn), Cn.gWh,
+                              Cn.gbh, Cn.gb[nC - 1], amax_of(Cn, AMAX_DZ + nC - 1), stream));
   at = launches;
-  if (int rc = backward(Cn, d->norm_obs, d->norm_obs16, Mb, nullptr, bwd, &mk, launches, stream)) return rc;
+  if (int rc = backward(Cn, d->norm_obs, d->norm_obs16, Mb, nullptr, bwd, &mk, launches, stream, d->norm_obs_amax)) return rc;
   if (marks) *marks = addhip_ppo_marks_t{launches, actor_end, actor_early, at + mk.early};
   return 0;
 }
@@ -321,21 +347,22 @@ extern "C" int addhip_disc_loss_fwd_bwd(const addhip_disc_loss_t* d, addhip_disc
   LAUNCH(addhip_l2_grad(D.W[0], D.gW[0], (int64_t)d1 * DS, 2.0f * ls * wd, d->stats + 24, stream));
   LAUNCH(addhip_l2_grad(D.W[1], D.gW[1], (int64_t)d2 * d1, 2.0f * ls * wd, d->stats + 24, stream));
   LAUNCH(addhip_l2_grad(D.Wh, D.gWh, (int64_t)d2, 2.0f * ls * (wd + d->logit_reg), d->stats + 25, stream));
-  if (int rc = forward(D, d->norm_diff, d->norm_diff16, Md, nullptr, nullptr, true, launches, stream)) return rc;
+  if (int rc = forward(D, d->norm_diff, d->norm_diff16, Md, nullptr, nullptr, true, launches, stream, d->norm_diff_amax)) return rc;
   if (int rc = refresh_transposed(D, launches, stream)) return rc;
   const int m_head = launches;
   // logit loss on Mb agent rows (negative) and the demo... rows of h[last]: row Mb = the zero-difference sample (positive)
   LAUNCH(addhip_disc_head(D.h[1], d2, d2, Mb, D.h[1] + (size_t)Mb * d2, D.Wh, D.bh, ls, d->dlogit, d->dlogit + Mb, d->stats + 12, stream));
-  LAUNCH(addhip_head_backward(d->dlogit, D.Wh, D.h[1], d2, d2, Md, s16 ? nullptr : D.dz[1], s16 ? D.dz16[1] : nullptr, D.gWh, D.gbh, D.gb[1], stream));
+  LAUNCH(addhip_head_backward(d->dlogit, D.Wh, D.h[1], d2, d2, Md, s16 ? nullptr : D.dz[1], s16 ? D.dz16[1] : nullptr, store_fmt(D), D.gWh, D.gbh, D.gb[1], amax_of(D, AMAX_DZ + 1), stream));
   const int m_chain = launches;
   // gradient penalty (hand-derived double backward of add_agent.py:166-178):  g = ((w3 * m2) W2 * m1) W1 ;  penalty = mean |g|^2 ;
   // second-order terms  G = d penalty / d g ;  e1 = (G W1^T) * m1 ;  da2 = (e1 W2^T) * m2
-  LAUNCH(addhip_bcast_mask(D.Wh, D.h[1], d2, d2, Mb, s16 ? nullptr : d->a2, s16 ? d->a2_16 : nullptr, stream));
+  LAUNCH(addhip_bcast_mask(D.Wh, D.h[1], d2, d2, Mb, s16 ? nullptr : d->a2, s16 ? d->a2_16 : nullptr, store_fmt(D), amax_of(D, AMAX_A2), stream));
   addhip_extra_dw_t extra[ADDHIP_MLP_MAX_HIDDEN];
   memset(extra, 0, sizeof(extra));
-  auto chain = [&](addhip_gemm_t g, int mask_layer) -> int {
+  auto chain = [&](addhip_gemm_t g, int mask_layer, int t_in = -1, int t_out = -1) -> int {  // t_in / t_out: tracked-maximum slots of A / the result
     set_prec(g, D);
     if (mask_layer >= 0) set_mask(g, D, mask_layer, 0, Mb, true);
+    if (f16x2(D)) set_amax(g, t_in >= 0 ? amax_of(D, t_in) : nullptr, D.w_amax, t_out >= 0 ? amax_of(D, t_out) : nullptr);
     return addhip_gemm_f32(&g, stream);
   };
   if (s16) {  // a2 and G are written as bf16 by their kernels, a1 / e1 leave their GEMMs as bf16, g and da2 as fp32
@@ -343,28 +370,28 @@ extern "C" int addhip_disc_loss_fwd_bwd(const addhip_disc_loss_t* d, addhip_disc
     g1.C16 = d->a1_16; g1.ldc16 = d1;
     LAUNCH(chain(g1, 0));
     LAUNCH(chain(gemm(Mb, DS, d1, d->a1_16, d1, 1, D.W16t[0], d1, 1, d->g, DS), -1));
-    LAUNCH(addhip_grad_penalty(d->g, DS, d->disc_dim, Mb, ls * d->grad_penalty, nullptr, d->G16, d->stats + 20, stream));
+    LAUNCH(addhip_grad_penalty(d->g, DS, d->disc_dim, Mb, ls * d->grad_penalty, nullptr, d->G16, store_fmt(D), d->stats + 20, nullptr, stream));
     addhip_gemm_t g3 = gemm(Mb, d1, DS, d->G16, DS, 1, D.W16[0], DS, 1, nullptr, d1, ADDHIP_EPI_MASK);
     g3.C16 = d->e1_16; g3.ldc16 = d1;
     LAUNCH(chain(g3, 0));
     LAUNCH(chain(gemm(Mb, d2, d1, d->e1_16, d1, 1, D.W16[1], d1, 1, d->da2, d2, ADDHIP_EPI_MASK), 1));
-    extra[0] = {d->a1_16, d1, d->G16, DS, Mb};
-    extra[1] = {d->a2_16, d2, d->e1_16, d1, Mb};
+    extra[0] = {d->a1_16, d1, d->G16, DS, Mb, nullptr, nullptr};
+    extra[1] = {d->a2_16, d2, d->e1_16, d1, Mb, nullptr, nullptr};
   } else {
-    LAUNCH(chain(gemm(Mb, d1, d2, d->a2, d2, 1, D.W[1], d1, 0, d->a1, d1, ADDHIP_EPI_MASK), 0));
-    LAUNCH(chain(gemm(Mb, DS, d1, d->a1, d1, 1, D.W[0], DS, 0, d->g, DS), -1));
-    LAUNCH(addhip_grad_penalty(d->g, DS, d->disc_dim, Mb, ls * d->grad_penalty, d->G, nullptr, d->stats + 20, stream));
-    LAUNCH(chain(gemm(Mb, d1, DS, d->G, DS, 1, D.W[0], DS, 1, d->e1, d1, ADDHIP_EPI_MASK), 0));
-    LAUNCH(chain(gemm(Mb, d2, d1, d->e1, d1, 1, D.W[1], d1, 1, d->da2, d2, ADDHIP_EPI_MASK), 1));
-    extra[0] = {d->a1, d1, d->G, DS, Mb};
-    extra[1] = {d->a2, d2, d->e1, d1, Mb};
+    LAUNCH(chain(gemm(Mb, d1, d2, d->a2, d2, 1, D.W[1], d1, 0, d->a1, d1, ADDHIP_EPI_MASK), 0, AMAX_A2, AMAX_A1));
+    LAUNCH(chain(gemm(Mb, DS, d1, d->a1, d1, 1, D.W[0], DS, 0, d->g, DS), -1, AMAX_A1));
+    LAUNCH(addhip_grad_penalty(d->g, DS, d->disc_dim, Mb, ls * d->grad_penalty, d->G, nullptr, 0, d->stats + 20, amax_of(D, AMAX_G), stream));
+    LAUNCH(chain(gemm(Mb, d1, DS, d->G, DS, 1, D.W[0], DS, 1, d->e1, d1, ADDHIP_EPI_MASK), 0, AMAX_G, AMAX_E1));
+    LAUNCH(chain(gemm(Mb, d2, d1, d->e1, d1, 1, D.W[1], d1, 1, d->da2, d2, ADDHIP_EPI_MASK), 1, AMAX_E1));
+    extra[0] = {d->a1, d1, d->G, DS, Mb, amax_of(D, AMAX_A1), amax_of(D, AMAX_G)};
+    extra[1] = {d->a2, d2, d->e1, d1, Mb, amax_of(D, AMAX_A2), amax_of(D, AMAX_E1)};
   }
   LAUNCH(addhip_col_sum(d->da2, Mb, d2, d2, D.gWh, 1.0f, 1, stream));
   const int m_bwd = launches;
   addhip_mlp_marks_t mk;
   if (int rc = backward(D, d->norm_diff, d->norm_diff16, Md, extra,
                         ADDHIP_BWD_GRADS_ZEROED | ADDHIP_BWD_TOP_BIAS_DONE | ADDHIP_BWD_ACCUMULATE_DW | ADDHIP_BWD_TOP_CAST_DONE | ADDHIP_BWD_SIGN_BITS, &mk, launches,
-                        stream))
+                        stream, d->norm_diff_amax))
     return rc;
   if (marks) *marks = addhip_disc_marks_t{launches, m_head, m_chain, m_bwd, m_bwd + mk.dw_first[1], m_bwd + mk.dw_last[1]};
   return 0;

@@ -78,12 +78,15 @@ def make_task(task, dt, max_episode_length=None):
 
 
 # agent.matmul_precision -> ADDHIP_PREC_* (how addhip_gemm_f32 forms its products; a property of each descriptor)
-PRECISIONS = {"fp32": L.PREC_F32, "f32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16x2": L.PREC_BF16X2, "bf16": L.PREC_BF16}
+# ("bf16x3": every GEMM splits its fp32 operands on the fly, csrc/gemm_split.hip; "bf16x3_planes": the update step runs on plane-stored
+# operands, csrc/gemm_x3.hip -- same products and error, measured slower end to end: DESIGN.md section 4)
+PRECISIONS = {"fp32": L.PREC_F32, "f32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16x3_planes": L.PREC_BF16X3, "bf16x2": L.PREC_BF16X2, "bf16": L.PREC_BF16,
+              "f16x2": L.PREC_F16X2}  # f16x2: two-way fp16 split on per-tensor power-of-two scales, four products (fp32-class: 2^-21 |a||b| per product)
 
 
 def gemm(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, epilogue=L.EPI_NONE, bias=None, mask=None, ldmask=0, a_mean=None, a_std=None,
          split_k=1, alpha=1.0, colsum=None, precision=L.PREC_F32, relu_bits=None, mask_bits=None, ldbits=0, accumulate=0, operands_bf16=0, C16=None, ldc16=0, hint=0,
-         colsum_replicas=0, ldcs=0):
+         colsum_replicas=0, ldcs=0, c16_planes=0, a_amax=None, b_amax=None, amax_out=None):
     """Descriptor for addhip_gemm_f32: C[M,N] = alpha * sum_k A(m,k) B(n,k).  Pointers are raw addresses."""
     return L.GemmT(M, N, K, A, lda, int(a_kc), B, ldb, int(b_kc), C, ldc, epilogue, bias, mask, ldmask, a_mean, a_std, split_k, alpha, colsum,
-                   precision, relu_bits, mask_bits, ldbits, int(accumulate), int(operands_bf16), C16, ldc16, int(hint), int(colsum_replicas), int(ldcs))
+                   precision, relu_bits, mask_bits, ldbits, int(accumulate), int(operands_bf16), C16, ldc16, int(hint), int(colsum_replicas), int(ldcs), int(c16_planes), a_amax, b_amax, amax_out)

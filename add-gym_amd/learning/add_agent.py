@@ -78,8 +78,11 @@ class ADDAgent(AgentIO):
         # "bf16" = bf16 STORAGE in the update step: hidden activations, pre-activation gradients and a shadow of the weights live
         # in HBM as bf16 (fp32 master weights, fp32 accumulation, AdamW in fp32); the head / loss kernels, the rollout and the
         # value / discriminator evaluation passes keep fp32 operands (formed by the bf16x2 products)
-        self._storage16 = prec == "bf16"
-        self._prec_small = H.PRECISIONS["bf16x2"] if self._storage16 else self._prec
+        # "bf16x3_planes" = PLANE STORAGE in the update step: the same buffers hold three bf16 per value whose sum is the fp32 value exactly,
+        # written once by their producers; the GEMMs form the six bf16 products of the exact split from them (csrc/gemm_x3.hip): the error of
+        # "bf16x3", whose GEMMs split their fp32 operands on the fly (gemm_split.hip) -- as this mode's rollout / evaluation passes do.
+        self._storage16 = {"bf16": L.STORE_BF16, "bf16x3_planes": L.STORE_BF16X3}.get(prec, 0)
+        self._prec_small = H.PRECISIONS["bf16x2"] if self._storage16 == L.STORE_BF16 else self._prec
 
         # ---- motion library + sampler (add_motion.py:14-33)
         kin = env.robot._kin_char_model
@@ -162,11 +165,16 @@ class ADDAgent(AgentIO):
         if self._distributed:  # DDP ctor behaviour: every rank starts from rank 0's weights (base_agent.py:50-57)
             D.broadcast_(self._model.params, 0)
         if self._storage16:
-            self._model.enable_shadow()
+            self._model.enable_shadow(self._storage16)
+        # "f16x2": fp32 operands split on the fly into two fp16 planes on per-tensor power-of-two scales (csrc/gemm_split.hip, ADDHIP_PREC_F16X2);
+        # the scales come from maxima the producers track on the device (activations / gradients: NetRunner.amax; parameters: Model.w_amax)
+        self._f16x2 = self._prec == L.PREC_F16X2
+        if self._f16x2:
+            self._model.enable_w_amax()
         mm = self._model
         sgd = self._opt_type == "SGD"
         self._opt_c = L.OptimizerT(L.OPT_SGD if sgd else L.OPT_ADAMW, L.ptr(mm.params), L.ptr(mm.grads), L.ptr(mm.exp_avg), None if sgd else L.ptr(mm.exp_avg_sq),
-                                   mm.count, self._lr, 0.9, 0.999, 1e-8, self._wd, 1, L.ptr(mm.params16) if self._storage16 else None, 1)
+                                   mm.count, self._lr, 0.9, 0.999, 1e-8, self._wd, 1, L.ptr(mm.params16) if self._storage16 else None, 1, self._storage16)
 
         self._build_workspace()
         self._build_plans()
@@ -251,9 +259,10 @@ class ADDAgent(AgentIO):
         self._W = dict(mean=z(rows, 32), d_mean=z(rows, 32), noise=z(N, L.NUM_DOF), explore_u=z(N), u=z(3, N), logits=z(rows), nv=z(1),
                        norm_obs=z(Mb, OS), norm_act=z(Mb, 32), mb_logp=z(Mb), mb_adv=z(Mb), mb_tar=z(Mb), mb_mask=z(Mb), norm_diff=z(rows + 1, DS),
                        dv=z(Mb), dlogit=z(Mb + 1), a2=z(Mb, hd[-1]), a1=z(Mb, hd[0]), g=z(Mb, DS), G=z(Mb, DS), e1=z(Mb, hd[0]), da2=z(Mb, hd[-1]),
-                       stats=z(32), scratch=z(4096, dt=torch.float64), adv_stats=z(2), rstats=z(2), perm_idx=z(Mb, dt=torch.int64))
+                       stats=z(32), scratch=z(4096, dt=torch.float64), adv_stats=z(2), rstats=z(2), perm_idx=z(Mb, dt=torch.int64),
+                       mb_amax=z(2, L.AMAX_SLOTS, dt=torch.int32))  # f16x2: tracked maxima of the gathered norm_obs / norm_diff rows
         if s16:  # bf16 copies of the GEMM operands the fp32 kernels produce
-            b16 = lambda *shape: torch.zeros(*shape, dtype=torch.bfloat16, device=dev)
+            b16 = lambda r, c: torch.zeros(r, s16 * c, dtype=torch.bfloat16, device=dev)  # (plane storage: three bf16 per value)
             self._W.update(norm_obs16=b16(Mb, OS), norm_diff16=b16(Mb + 1, DS), a2_16=b16(Mb, hd[-1]), a1_16=b16(Mb, hd[0]), G16=b16(Mb, DS),
                            e1_16=b16(Mb, hd[0]))
 
@@ -334,7 +343,8 @@ class ADDAgent(AgentIO):
                                    L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), L.ptr(B["a_logp"]), L.ptr(B["adv"]), L.ptr(B["tar_val"]), L.ptr(B["rand_mask"]),
                                    L.ptr(B["disc_obs"]), L.ptr(B["disc_demo"]), DS, tk.disc_dim, L.ptr(Nm["d_abs"]), 1e-4, L.ptr(W["norm_obs"]),
                                    L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_tar"]), L.ptr(W["mb_mask"]), L.ptr(W["norm_diff"]),
-                                   L.ptr(W["norm_obs16"]) if s16 else None, L.ptr(W["norm_diff16"]) if s16 else None)
+                                   L.ptr(W["norm_obs16"]) if s16 else None, L.ptr(W["norm_diff16"]) if s16 else None, s16,
+                                   L.ptr(W["mb_amax"][0]) if self._f16x2 else None, L.ptr(W["mb_amax"][1]) if self._f16x2 else None)
 
     def _loss_descs(self):
         """The update step's two loss sections as parameter blocks of the composite entry points (include/addhip.h:
@@ -345,12 +355,13 @@ class ADDAgent(AgentIO):
         self._mlp_c = {r.net.name: r.c_struct() for r in (self._run_actor, self._run_critic, self._run_disc)}
         import ctypes as C
         ppo = L.PpoLossT(C.pointer(self._mlp_c["actor"]), C.pointer(self._mlp_c["critic"]), Mb, L.ptr(W["norm_obs"]), L.ptr(W["norm_obs16"]) if s16 else None,
-                         L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_tar"]), L.ptr(W["mb_mask"]), m.std32, m.logp_const,
+                         L.ptr(W["mb_amax"][0]) if self._f16x2 else None, L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_tar"]), L.ptr(W["mb_mask"]), m.std32, m.logp_const,
                          self._ppo_clip_ratio, self._action_bound_weight, self._action_reg_weight, self._critic_loss_weight, gs, self._prec_small,
                          L.ptr(W["mean"]), L.ptr(W["d_mean"]), L.ptr(W["dv"]), L.ptr(W["nv"]), L.ptr(W["stats"]))
         o = (lambda k: L.ptr(W[k])) if s16 else (lambda k: None)
         f = (lambda k: None) if s16 else (lambda k: L.ptr(W[k]))
-        disc = L.DiscLossT(C.pointer(self._mlp_c["disc"]), Mb, tk.disc_dim, L.ptr(W["norm_diff"]), o("norm_diff16"), self._disc_loss_weight * gs,
+        disc = L.DiscLossT(C.pointer(self._mlp_c["disc"]), Mb, tk.disc_dim, L.ptr(W["norm_diff"]), o("norm_diff16"), L.ptr(W["mb_amax"][1]) if self._f16x2 else None,
+                           self._disc_loss_weight * gs,
                            self._disc_logit_reg, self._disc_grad_penalty, self._disc_weight_decay, L.ptr(W["dlogit"]), f("a2"), f("a1"), L.ptr(W["g"]), f("G"),
                            f("e1"), L.ptr(W["da2"]), o("a2_16"), o("a1_16"), o("G16"), o("e1_16"), L.ptr(W["stats"]))
         return ppo, disc
@@ -607,7 +618,7 @@ class ADDAgent(AgentIO):
         steps, n_steps = 0, self._update_epochs * num_batches
         main, side = torch.cuda.current_stream(), self._side_streams[0]
         self._next_minibatch_indices()
-        L.call("addhip_gather_minibatch", self._gather_c, st)
+        self._gather(st)
         while steps < n_steps:
             self._run_update_sections(zero_grad=steps == 0)  # later steps find the gradient zeroed by the optimiser launch before them
             steps += 1
@@ -619,7 +630,7 @@ class ADDAgent(AgentIO):
                 joined = torch.cuda.Event()
                 joined.record(main)
                 side.wait_event(joined)
-                L.call("addhip_gather_minibatch", self._gather_c, side.cuda_stream)
+                self._gather(side.cuda_stream)
                 gathered = torch.cuda.Event()
                 gathered.record(side)
             if self._grad_clip > 0.0:
@@ -630,9 +641,16 @@ class ADDAgent(AgentIO):
             o = self._opt_c
             o.step = m.opt_step
             L.call("addhip_optimizer_step", o, st)
+            m.refresh_w_amax(st)  # (f16x2: the new parameters' tracked maximum, the scale of the next step's weight operands)
             if gathered is not None:
                 main.wait_event(gathered)
         return steps
+
+    def _gather(self, stream):
+        """ExperienceBuffer.sample of one minibatch (addhip_gather_minibatch); f16x2: the rows' tracked maxima start from zero."""
+        if self._f16x2:
+            L.call("addhip_fill_zero", L.ptr(self._W["mb_amax"]), 2 * L.AMAX_SLOTS, stream)
+        L.call("addhip_gather_minibatch", self._gather_c, stream)
 
     def _run_update_sections(self, zero_grad=True):
         """The actor, critic and discriminator sections of the update plan are independent until the optimiser: they run on

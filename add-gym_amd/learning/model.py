@@ -81,6 +81,7 @@ class Model:
         self.exp_avg_sq = torch.zeros(off, device=device)
         self.opt_step = 0
         self.params16 = None  # bf16 shadow of params (agent.matmul_precision = bf16), refreshed after every optimiser step
+        self.w_amax = None    # tracked maximum |parameter| (agent.matmul_precision = f16x2: the scale of every weight operand), likewise
         self._init_params(seed)
         # distribution_gaussian_diag.py:24-31, 63-94: fp32 logstd vector -> std and the log-prob constant
         logstd = torch.full((L.NUM_DOF,), float(math.log(self.action_std)), dtype=torch.float32)
@@ -102,12 +103,14 @@ class Model:
     def g(self, net, key):
         return self.p(net, key, self.grads)
 
-    def enable_shadow(self):
-        """bf16 shadows of the parameters: params16 in the flat layout (W[out,in]: what the forward and weight-gradient GEMMs read) and
+    def enable_shadow(self, planes=L.STORE_BF16):
+        """16-bit shadows of the parameters: params16 in the flat layout (W[out,in]: what the forward and weight-gradient GEMMs read) and
         params16t holding W^T[in,out] of every hidden weight past a net's first layer (what the backward dX GEMMs and the gradient-
-        penalty chain read, k-contiguously)."""
-        self.params16 = torch.zeros(self.count, dtype=torch.bfloat16, device=self.device)
-        self.params16t = torch.zeros(self.count, dtype=torch.bfloat16, device=self.device)
+        penalty chain read, k-contiguously).  planes = L.STORE_BF16: one bf16 per value (rounded); L.STORE_BF16X3: plane storage, three
+        bf16 per value whose sum is the fp32 value exactly (include/addhip.h, "plane storage")."""
+        self.shadow_planes = int(planes)
+        self.params16 = torch.zeros(self.shadow_planes * self.count, dtype=torch.bfloat16, device=self.device)
+        self.params16t = torch.zeros(self.shadow_planes * self.count, dtype=torch.bfloat16, device=self.device)
         self._transposed = [(net.name, f"W{i}") for net in self.nets for i in range(len(net.hidden)) if i > 0 or net is self.disc]
         import ctypes as C
         n = len(self._transposed)
@@ -120,28 +123,41 @@ class Model:
             self._net_tables[net.name] = ((C.c_int64 * len(keys))(*o), (C.c_int32 * len(keys))(*(d[0] for d in dm)), (C.c_int32 * len(keys))(*(d[1] for d in dm)), len(keys))
         self.refresh_shadow()
 
+    def enable_w_amax(self):
+        """ADDHIP_PREC_F16X2: ADDHIP_AMAX_SLOTS slots bounding max |parameter| over the flat buffer (one bound for every weight: fp16 spans 2^18
+        above the point where the split starts to lose relative precision, far more than the layers' maxima differ by)."""
+        self.w_amax = torch.zeros(L.AMAX_SLOTS, dtype=torch.int32, device=self.device)
+        self.refresh_shadow()
+
+    def refresh_w_amax(self, stream):
+        if self.w_amax is not None:
+            L.call("addhip_fill_zero", L.ptr(self.w_amax), L.AMAX_SLOTS, stream)
+            L.call("addhip_amax_f32", L.ptr(self.params), self.count, L.ptr(self.w_amax), stream)
+
     def refresh_shadow(self, stream=None):
-        """params16 = bf16(params), round to nearest even, + the transposed copies: one launch."""
+        """Derived parameter state after the parameters changed (optimiser step, load, broadcast): params16 = bf16(params), round to nearest
+        even, + the transposed copies in one launch (storage modes); the tracked maximum (f16x2)."""
+        st = L.current_stream() if stream is None else stream
+        self.refresh_w_amax(st)
         if self.params16 is not None:
-            st = L.current_stream() if stream is None else stream
             offs, rows, cols, n = self._shadow_table
-            L.call("addhip_shadow_refresh", L.ptr(self.params), L.ptr(self.params16), L.ptr(self.params16t), self.count, offs, rows, cols, n, st)
+            L.call("addhip_shadow_refresh", L.ptr(self.params), L.ptr(self.params16), L.ptr(self.params16t), self.count, offs, rows, cols, n, self.shadow_planes, st)
 
     def transposed_refresh_args(self, net):
         """Arguments (without the stream) of the addhip_shadow_refresh call that rewrites only `net`'s transposed weight copies from the
         fp32 parameters (the flat shadow is written by the optimiser step itself)."""
         offs, rows, cols, n = self._net_tables[net]
-        return (L.ptr(self.params), None, L.ptr(self.params16t), self.count, offs, rows, cols, n)
+        return (L.ptr(self.params), None, L.ptr(self.params16t), self.count, offs, rows, cols, n, self.shadow_planes)
 
     def p16(self, net, key):
         off, _ = self.offsets[(net, key)]
-        return self.params16.data_ptr() + 2 * off
+        return self.params16.data_ptr() + 2 * self.shadow_planes * off
 
     def p16t(self, net, key):
         """W^T [in, out] (leading dimension = out)."""
         assert (net, key) in self._transposed
         off, _ = self.offsets[(net, key)]
-        return self.params16t.data_ptr() + 2 * off
+        return self.params16t.data_ptr() + 2 * self.shadow_planes * off
 
     def n_elem(self, net, key):
         return math.prod(self.offsets[(net, key)][1])
@@ -212,6 +228,8 @@ class Model:
                 v[:src.shape[0], :src.shape[1]] = src.to(self.device)
             else:
                 v[:src.shape[0]] = src.to(self.device)
+        if buf is None:
+            self.refresh_shadow()
 
     def num_params(self):
         return sum(math.prod(self._ref_shape(net, key)) for _, net, key in self._key_map())
@@ -343,16 +361,17 @@ class NetRunner:
     """One Mlp's activation / gradient workspace for up to `rows` rows, as the addhip_mlp_t the library's composite entry points take
     (addhip_mlp_forward / _backward, addhip_ppo_loss_fwd_bwd, addhip_disc_loss_fwd_bwd: csrc/learner.hip assembles the launches)."""
 
-    def __init__(self, model, net, rows, device, slabs, precision=L.PREC_F32, storage16=False):
+    def __init__(self, model, net, rows, device, slabs, precision=L.PREC_F32, storage16=0):
         self.m, self.net, self.rows, self.slabs = model, net, rows, slabs
         self.precision = precision  # ADDHIP_PREC_* of every GEMM this runner records (agent.matmul_precision)
         # storage16 (agent.matmul_precision = bf16): hidden activations and pre-activation gradients are kept as bf16 in HBM and
         # the GEMMs read the model's bf16 weight shadow; the last hidden layer and the top gradient also exist in fp32 for the
         # loss-head kernels
-        self.storage16 = bool(storage16)
+        # storage16 = L.STORE_BF16X3 (agent.matmul_precision = bf16x3): the same buffers in plane storage, three bf16 per value (exact)
+        self.storage16 = int(storage16)  # 0 | L.STORE_BF16 | L.STORE_BF16X3
         if self.storage16:
-            self.h16 = [torch.zeros(rows, h, dtype=torch.bfloat16, device=device) for h in net.hidden]
-            self.dz16 = [torch.zeros(rows, h, dtype=torch.bfloat16, device=device) for h in net.hidden]
+            self.h16 = [torch.zeros(rows, self.storage16 * h, dtype=torch.bfloat16, device=device) for h in net.hidden]
+            self.dz16 = [torch.zeros(rows, self.storage16 * h, dtype=torch.bfloat16, device=device) for h in net.hidden]
         self.aux_slabs = None   # (layer, buffer): the top layer's weight-gradient group uses its own split-K scratch, so that it may run on
                                 # another stream than the rest of the backward pass (addhip_mlp_t.slabs_top)
         # ReLU sign bits of the hidden activations (1 bit per element): what the backward GEMMs read as their mask instead of
@@ -363,6 +382,8 @@ class NetRunner:
         # bias-gradient column sums of the dX GEMMs, spread over 16 rows (same-line float atomics of all row tiles serialise otherwise);
         # summed into the gradient and cleared by the split-K combine that follows (addhip_slab_reduce_pair)
         self.bias_rep = torch.zeros(16, max(net.hidden), device=device) if slabs is not None else None
+        # agent.matmul_precision = f16x2: the tracked maxima of this runner's activations / gradients (include/addhip.h: ADDHIP_MLP_AMAX_*)
+        self.amax = torch.zeros(L.MLP_AMAX_TENSORS * L.AMAX_SLOTS, dtype=torch.int32, device=device) if precision == L.PREC_F16X2 else None
 
     def c_struct(self):
         """addhip_mlp_t over this runner's buffers (include/addhip.h, "composite entry points")."""
@@ -370,6 +391,7 @@ class NetRunner:
         n = len(net.hidden)
         c = L.MlpT()
         c.num_hidden, c.in_dim, c.in_ld, c.head_rows, c.precision, c.rows_cap = n, net.in_dim, net.in_ld, net.head_rows, self.precision, self.rows
+        c.storage = self.storage16
         for i, h in enumerate(net.hidden):
             c.hidden[i] = h
             c.W[i], c.b[i], c.gW[i], c.gb[i] = m.p(net.name, f"W{i}"), m.p(net.name, f"b{i}"), m.g(net.name, f"W{i}"), m.g(net.name, f"b{i}")
@@ -386,6 +408,8 @@ class NetRunner:
             c.slabs_top = L.ptr(self.aux_slabs[1])
         if self.bias_rep is not None:
             c.bias_replicas, c.bias_replica_rows = L.ptr(self.bias_rep), self.bias_rep.shape[0]
+        if self.amax is not None:
+            c.amax, c.w_amax = L.ptr(self.amax), L.ptr(m.w_amax)
         if self.storage16:
             offs, rows, cols, cnt = m._net_tables[net.name]
             c.flat_params, c.flat_trans16, c.flat_count = L.ptr(m.params), L.ptr(m.params16t), m.count
@@ -394,9 +418,9 @@ class NetRunner:
         self._c = c
         return c
 
-    def forward(self, plan, x_ptr, rows, a_mean=None, a_std=None, sign_bits=False, x16_ptr=None):
+    def forward(self, plan, x_ptr, rows, a_mean=None, a_std=None, sign_bits=False, x16_ptr=None, x_amax=None):
         """Record this net's forward pass over `rows` rows into `plan` (addhip_mlp_forward: one GEMM with fused bias + ReLU per layer).
         sign_bits: also write the ReLU sign bits (a backward pass follows).  x16_ptr: bf16 copy of the input rows (storage16 runners)."""
         if not hasattr(self, "_c"):
             self.c_struct()
-        return plan.add("addhip_mlp_forward", self._c, x_ptr, x16_ptr, rows, a_mean, a_std, int(bool(sign_bits)))
+        return plan.add("addhip_mlp_forward", self._c, x_ptr, x16_ptr, rows, a_mean, a_std, int(bool(sign_bits)), x_amax)

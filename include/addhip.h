@@ -224,7 +224,28 @@ enum { ADDHIP_EPI_NONE = 0, ADDHIP_EPI_BIAS = 1, ADDHIP_EPI_BIAS_RELU = 2, ADDHI
  * itself runs its matmuls in TF32, main.py:16-18).  ADDHIP_PREC_BF16X2: the two leading chunks only (16 significant bits per operand, three MFMAs per
  * k-step: error bound 2^-15 |a||b|, 64x below TF32).  ADDHIP_PREC_BF16: operands truncated to bf16, fp32 accumulate.
  * The split paths are used for shapes that fill the chip with 128x128 tiles; other shapes always take the fp32 path. */
-enum { ADDHIP_PREC_F32 = 0, ADDHIP_PREC_BF16 = 1, ADDHIP_PREC_BF16X2 = 2, ADDHIP_PREC_BF16X3 = 3 };
+enum { ADDHIP_PREC_F32 = 0, ADDHIP_PREC_BF16 = 1, ADDHIP_PREC_BF16X2 = 2, ADDHIP_PREC_BF16X3 = 3, ADDHIP_PREC_F16X2 = 4 };
+/* ADDHIP_PREC_F16X2: each fp32 operand value, scaled by an exact power of two chosen per TENSOR, is split into two fp16 values
+ * hi = fp16(x s), lo = fp16(x s - hi) (round to nearest: 22 significant bits + sign of the residual) and all FOUR fp16 products are
+ * accumulated in fp32 by v_mfma_f32_32x32x16_f16: operand representation error <= 2^-22 |x| each, i.e. a bound of 2^-21 |a||b| per product
+ * (fp32 MFMA: 0 per product + 2^-24 per accumulation; measured at K = 1024: both 3.3e-7 of sum |a||b|), at 4 instead of 6 matrix
+ * instructions per k-step -- the chip sustains 395-435 TFLOP/s of fp32 products on this pattern against 280-290 on the bf16x3 one
+ * (tools/ubench/mfma_x3_variants.hip).  fp16 has 5 exponent bits, so the scale must put the tensor's largest magnitude just below
+ * 2^15: the descriptor carries, per operand, a device array of ADDHIP_AMAX_SLOTS float bit patterns whose maximum is an upper bound of
+ * max |x| over the operand (a_amax, b_amax), written by the operand's producer -- every kernel of this library that produces a GEMM
+ * operand can track it (addhip_gemm_t.amax_out, the `amax` arguments of the loss-head kernels, addhip_amax_f32 for anything else).
+ * A descriptor with precision F16X2 but without both arrays runs as ADDHIP_PREC_BF16X3.  Values below 2^-18 of the tensor's maximum
+ * keep an ABSOLUTE error of 2^-40 of that maximum. */
+#define ADDHIP_AMAX_SLOTS 64
+/* ---- plane storage.  16-bit storage formats of fp32 values, for GEMM operands kept in HBM (addhip_gemm_t.operands_bf16, .c16_planes and
+ *      the `planes16` argument / field of every producer of such operands):
+ *   ADDHIP_STORE_BF16   (1)  one bf16 per value, rounded to nearest even (agent.matmul_precision = bf16: 8 significant bits);
+ *   ADDHIP_STORE_BF16X3 (3)  three bf16 per value, hi + mid + lo == x EXACTLY (split by truncation), interleaved in groups of 8 values:
+ *                            element c of plane p of a row of ld values (ld % 8 == 0) is the uint16 at (c / 8) * 24 + p * 8 + c % 8, row r
+ *                            starts at uint16 index 3 * r * ld (leading dimensions always count VALUES).  A GEMM on such operands forms the
+ *                            six bf16 products above 2^-24 |a||b| (csrc/gemm_x3.hip): the error bound of ADDHIP_PREC_BF16X3, i.e. of the fp32
+ *                            MFMA, without splitting operands inside the GEMM (agent.matmul_precision = bf16x3, update step). */
+enum { ADDHIP_STORE_BF16 = 1, ADDHIP_STORE_BF16X3 = 3 };
 typedef struct {
   int32_t M, N, K;          /* C[M,N] = sum_k A(m,k) * B(n,k) */
   const float* A; int32_t lda; int32_t a_kcontig; /* 1: A[m*lda+k], 0: A[k*lda+m] */
@@ -254,7 +275,7 @@ typedef struct {
    * conversion anywhere.  Epilogues, sign bits, column sums and split-K slabs (fp32) as for fp32 operands; no fused normalisation.
    * C16 (optional, with fp32 operands too): a second copy of the result rounded to bf16 (nearest even), leading dimension ldc16; with
    * it C may be NULL (not with split-K slabs, which are fp32). */
-  int32_t operands_bf16;
+  int32_t operands_bf16;    /* 0 | ADDHIP_STORE_BF16 | ADDHIP_STORE_BF16X3 (A and B in plane storage; lda / ldb count values, multiples of 8) */
   uint16_t* C16;
   int32_t ldc16;
   /* 0 (always, in product code): the dispatcher picks the kernel configuration from the shape.  ADDHIP_GEMM_HINT_* bits override one
@@ -267,13 +288,24 @@ typedef struct {
    * addhip_slab_reduce_pair.  0 / 1: plain colsum[N]. */
   int32_t colsum_replicas;
   int32_t ldcs;
+  /* format of C16: 0 / ADDHIP_STORE_BF16 = rounded to bf16; ADDHIP_STORE_BF16X3 = the exact three-plane split of the fp32 result (N and
+   * ldc16 multiples of 8), e.g. the hidden activations / pre-activation gradients the next plane-storage GEMM reads */
+  int32_t c16_planes;
+  /* ADDHIP_PREC_F16X2 (above): upper bounds of max |A|, max |B| as ADDHIP_AMAX_SLOTS float bit patterns each (the maximum over the slots
+   * counts; zero slots are fine), read at kernel start; NULL (either): the launch runs as ADDHIP_PREC_BF16X3. */
+  const uint32_t* a_amax; const uint32_t* b_amax;
+  /* optional, any precision: max |C| over this launch's results (after the epilogue), atomically maxed as float bits into slot
+   * (workgroup index % ADDHIP_AMAX_SLOTS) of this array, which the caller zeroes (addhip_fill_zero) before the launch(es) that produce
+   * the tensor; not with split-K slabs */
+  uint32_t* amax_out;
 } addhip_gemm_t;
 enum {
   ADDHIP_GEMM_HINT_BIG_TILE = 1,     /* bf16 operands: the 256x256 ring kernel on eligible shapes (M, N multiples of 256, K of 64) */
   ADDHIP_GEMM_HINT_NO_BIG_TILE = 2,  /* bf16 operands: never the 256x256 kernel */
   ADDHIP_GEMM_HINT_ONE_STAGE = 4,    /* 128x128 tiles: one LDS stage x 3-4 workgroups per CU */
   ADDHIP_GEMM_HINT_TWO_STAGE = 8,    /* 128x128 tiles: two LDS stages x 2 workgroups per CU */
-  ADDHIP_GEMM_HINT_REG_STAGED = 16   /* fp32 operands: the register-staged tile kernel instead of the LDS-DMA one */
+  ADDHIP_GEMM_HINT_REG_STAGED = 16,  /* fp32 operands: the register-staged tile kernel instead of the LDS-DMA one */
+  ADDHIP_GEMM_HINT_WIDE_TILE = 32    /* plane-stored operands: the 256x128 configuration (BIG_TILE: 256x256, NO_BIG_TILE: 128x128) */
 };
 int addhip_gemm_f32(const addhip_gemm_t* g, void* stream);
 /* Up to ADDHIP_GEMM_MAX_GROUP problems of the SAME shape, operand layouts, epilogue kind, split, precision and storage (different
@@ -287,6 +319,8 @@ int addhip_gemm_grouped(const addhip_gemm_t* problems, int32_t count, void* stre
 /* dst[r*ld_dst + c] = bf16(src[r*ld_src + c]), round to nearest even (bf16-storage mode: minibatch inputs, head gradients, the weight
  * shadow after an optimiser step); cols and both leading dimensions multiples of 4 */
 int addhip_to_bf16(const float* src, uint16_t* dst, int64_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream);
+/* the same into plane storage (ADDHIP_STORE_BF16X3): cols and ld_dst multiples of 8, ld_src of 4 */
+int addhip_to_bf16x3(const float* src, uint16_t* dst, int64_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream);
 /* transposing variant: dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) -- the [in,out] copy of a weight matrix [out,in], which lets the
  * backward (dX) GEMMs of the bf16-storage mode read the weights k-contiguously like the forward ones */
 int addhip_to_bf16_t(const float* src, uint16_t* dst, int32_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream);
@@ -296,7 +330,14 @@ int addhip_to_bf16_t(const float* src, uint16_t* dst, int32_t rows, int32_t cols
  * the transposed copies of the listed matrices are refreshed -- e.g. one net's, on that net's stream, between its forward and backward pass) */
 #define ADDHIP_SHADOW_MAX_MATS 8
 int addhip_shadow_refresh(const float* params, uint16_t* flat16, uint16_t* trans16, int64_t count, const int64_t* offset, const int32_t* rows,
-                          const int32_t* cols, int32_t n_mats, void* stream);
+                          const int32_t* cols, int32_t n_mats, int32_t planes16 /* ADDHIP_STORE_*: format of flat16 and trans16; X3: the flat
+                          buffer is split in groups of 8 along its flat index (every tensor offset, row length and count % 8 == 0), the
+                          transposed copies row by row; both buffers hold 3 * count uint16 */, void* stream);
+
+/* slots[block % ADDHIP_AMAX_SLOTS] = max(slots[..], max |x[i]|) as float bit patterns, for i < count (caller zeroes slots): the operand
+ * bound ADDHIP_PREC_F16X2 GEMMs read (a_amax / b_amax) for tensors no kernel of this library produced -- e.g. the flat parameter
+ * buffer after an optimiser step or a checkpoint load */
+int addhip_amax_f32(const float* x, int64_t count, uint32_t* slots, void* stream);
 
 /* out[n] (+)= scale * sum over `slabs` of in[s*slab_stride + n]  (split-K combine, grads) */
 int addhip_slab_reduce(const float* in, int32_t slabs, int64_t slab_stride, float* out, int64_t count,
@@ -381,6 +422,8 @@ typedef struct {
   const float* mean_abs; float min_diff;
   float* norm_obs; float* norm_action; float* o_logp; float* o_adv; float* o_tar_val; float* o_mask; float* norm_diff;
   uint16_t* norm_obs16; uint16_t* norm_diff16; /* optional (NULL = none): bf16 copies of norm_obs / norm_diff, same strides (bf16-storage mode) */
+  int32_t planes16;                            /* ADDHIP_STORE_* format of those two (0 = ADDHIP_STORE_BF16) */
+  uint32_t* obs_amax; uint32_t* diff_amax;     /* optional: max |norm_obs|, max |norm_diff| tracked into ADDHIP_AMAX_SLOTS slots each (caller zeroes; ADDHIP_PREC_F16X2) */
 } addhip_gather_t;
 int addhip_gather_minibatch(const addhip_gather_t* g, void* stream);
 
@@ -413,15 +456,18 @@ int addhip_disc_head(const float* H, int32_t ld, int32_t K, int32_t M, const flo
  * may be NULL).  Replaces outer_mask + weighted_col_sum + 2 x col_sum and three of their four passes over H.  K <= 1024.
  * dZ16 (optional): the same dZ rounded to bf16 (nearest even), what the bf16-storage backward GEMMs read. */
 int addhip_head_backward(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows,
-                         float* dZ, uint16_t* dZ16, float* dW_head, float* db_head, float* db_top, void* stream);
+                         float* dZ, uint16_t* dZ16, int32_t planes16 /* ADDHIP_STORE_* format of dZ16 */, float* dW_head, float* db_head, float* db_top,
+                         uint32_t* amax /* optional: max |dZ| into ADDHIP_AMAX_SLOTS slots (caller zeroes) */, void* stream);
 
 /* out[m,k] = v[m] * w[k] * (H[m,k] > 0)    (back through a 1-wide head into the last hidden layer) */
 int addhip_outer_mask(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows,
                       float* out, void* stream);
 /* out[m,k] = w[k] * (H[m,k] > 0)          (a2 of the gradient-penalty chain); out and/or its bf16 copy out16 */
-int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, uint16_t* out16, void* stream);
+int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* out, uint16_t* out16, int32_t planes16, uint32_t* amax /* as above */,
+                      void* stream);
 /* gradient penalty (add_agent.py:166-178): n=sqrt(|g|^2+1e-8); G = coef*2(n-1)/n * g / M (fp32 G and/or its bf16 copy G16); stats[0] += sum (n-1)^2 */
-int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, uint16_t* G16, float* stats, void* stream);
+int addhip_grad_penalty(const float* g, int32_t ld, int32_t dim, int32_t M, float coef, float* G, uint16_t* G16, int32_t planes16, float* stats,
+                        uint32_t* amax /* as above: max |G| */, void* stream);
 /* out[k] (+)= scale * sum_m v[m]*(mask? (Hmask[m,k]>0):1)*X[m,k]   (dw of 1-wide heads) */
 int addhip_weighted_col_sum(const float* v, const float* X, int32_t ld, int32_t K, int64_t rows, float* out,
                             float scale, int32_t accumulate, void* stream);
@@ -456,6 +502,7 @@ typedef struct {
   int32_t step;            /* 1-based */
   uint16_t* param16;       /* or NULL */
   int32_t zero_grad;
+  int32_t param16_planes;  /* ADDHIP_STORE_* format of param16 (0 = ADDHIP_STORE_BF16); X3: 3 * count uint16, count % 8 == 0 */
 } addhip_optimizer_t;
 int addhip_optimizer_step(const addhip_optimizer_t* o, void* stream);
 
@@ -526,6 +573,9 @@ typedef struct {
   int32_t hidden[ADDHIP_MLP_MAX_HIDDEN];  /* layer widths */
   int32_t head_rows;                      /* rows of the head weight: 32 for the 29-wide action-mean head (zero rows as padding), 1 for a scalar head */
   int32_t precision;                      /* ADDHIP_PREC_* of this net's GEMMs; ADDHIP_PREC_BF16 = bf16 STORAGE (the *16 buffers below) */
+  int32_t storage;                        /* 0: by `precision` (fp32 operands, or ADDHIP_STORE_BF16 when precision == ADDHIP_PREC_BF16);
+                                             ADDHIP_STORE_BF16X3: the *16 buffers below hold plane storage (3 uint16 per value) and every
+                                             hidden GEMM runs on them (csrc/gemm_x3.hip); precision is then ADDHIP_PREC_BF16X3 */
   /* parameters: W[i] [hidden[i], in_ld | hidden[i-1]] row major, b[i] [hidden[i]], Wh [head_rows, hidden[last]], bh; g* = their gradients */
   const float* W[ADDHIP_MLP_MAX_HIDDEN]; const float* b[ADDHIP_MLP_MAX_HIDDEN]; const float* Wh; const float* bh;
   float* gW[ADDHIP_MLP_MAX_HIDDEN]; float* gb[ADDHIP_MLP_MAX_HIDDEN]; float* gWh; float* gbh;
@@ -546,13 +596,21 @@ typedef struct {
    * backward pass, on its own stream.  t_offset / t_rows / t_cols: HOST arrays of t_count entries (copied when recorded). */
   const float* flat_params; uint16_t* flat_trans16; int64_t flat_count;
   const int64_t* t_offset; const int32_t* t_rows; const int32_t* t_cols; int32_t t_count;
+  /* precision = ADDHIP_PREC_F16X2: the tracked operand maxima its GEMMs scale by.  amax: workspace of ADDHIP_MLP_AMAX_TENSORS x
+   * ADDHIP_AMAX_SLOTS uint32 (tensor t at amax + t * ADDHIP_AMAX_SLOTS: h[i] at ADDHIP_MLP_AMAX_H + i, dz[i] at ADDHIP_MLP_AMAX_DZ + i, the
+   * penalty chain's a2 / a1 / G / e1 behind them), zeroed by every forward pass before its GEMMs rewrite it; w_amax: ADDHIP_AMAX_SLOTS
+   * slots bounding every weight the net reads (e.g. addhip_amax_f32 over the flat parameter buffer after each optimiser step).  Either
+   * NULL: the net's GEMMs run as ADDHIP_PREC_BF16X3. */
+  uint32_t* amax; const uint32_t* w_amax;
 } addhip_mlp_t;
+enum { ADDHIP_MLP_AMAX_H = 0, ADDHIP_MLP_AMAX_DZ = 4, ADDHIP_MLP_AMAX_A2 = 8, ADDHIP_MLP_AMAX_A1 = 9, ADDHIP_MLP_AMAX_G = 10, ADDHIP_MLP_AMAX_E1 = 11,
+       ADDHIP_MLP_AMAX_TENSORS = 12 };
 
 /* h[last] = MLP(x) for `rows` rows (<= rows_cap): one GEMM per layer with fused bias + ReLU (+ fused (x - a_mean) / a_std on the first
  * layer's input when a_mean is given: Normalizer.normalize, normalizer.py:107-110; not with bf16 storage, whose input x16 is the
  * already normalised rows rounded to bf16).  sign_bits: also write hbits (a backward pass follows). */
 int addhip_mlp_forward(const addhip_mlp_t* net, const float* x, const uint16_t* x16, int64_t rows, const float* a_mean, const float* a_std,
-                       int32_t sign_bits, void* stream);
+                       int32_t sign_bits, const uint32_t* x_amax /* ADDHIP_PREC_F16X2: bound of max |x| (ADDHIP_AMAX_SLOTS slots) or NULL */, void* stream);
 
 /* Backward pass through the hidden stack.  In: dz[last] (bf16 storage: dz16[last]) = d loss / d pre-activation of the last hidden layer,
  * written by the caller (the loss sections below do).  Out: gW[i], gb[i] for every layer.  Weight gradients are split-K GEMMs combined
@@ -567,6 +625,7 @@ enum {
 };
 typedef struct {                 /* a second product accumulated into a layer's weight gradient: gW += A^T B over `rows` rows */
   const void* A; int32_t lda; const void* B; int32_t ldb; int64_t rows;   /* fp32, or bf16 with bf16 storage; A == NULL: none */
+  const uint32_t* a_amax; const uint32_t* b_amax;                         /* ADDHIP_PREC_F16X2: their tracked maxima (or NULL) */
 } addhip_extra_dw_t;
 typedef struct {                 /* where things are final, as launch counts from this call's first launch (for schedules) */
   int32_t launches;              /* launches issued by the call */
@@ -574,7 +633,7 @@ typedef struct {                 /* where things are final, as launch counts fro
   int32_t dw_first[ADDHIP_MLP_MAX_HIDDEN], dw_last[ADDHIP_MLP_MAX_HIDDEN];  /* launches [first, last) form layer i's weight gradient */
 } addhip_mlp_marks_t;
 int addhip_mlp_backward(const addhip_mlp_t* net, const float* x, const uint16_t* x16, int64_t rows, const addhip_extra_dw_t* extra /* [num_hidden] or NULL */,
-                        int32_t flags, addhip_mlp_marks_t* marks /* or NULL */, void* stream);
+                        int32_t flags, addhip_mlp_marks_t* marks /* or NULL */, const uint32_t* x_amax /* as for addhip_mlp_forward */, void* stream);
 
 /* The actor's and the critic's sections of one optimiser step on a gathered minibatch (addhip_gather_minibatch's outputs): forward,
  * loss heads (addhip_actor_loss; addhip_critic_head), backward.  Needs the flat gradient zeroed (addhip_fill_zero / the zero_grad of
@@ -583,6 +642,7 @@ typedef struct {
   const addhip_mlp_t* actor; const addhip_mlp_t* critic;
   int32_t rows;                                   /* minibatch rows Mb */
   const float* norm_obs; const uint16_t* norm_obs16;   /* [Mb, in_ld] normalised observations (+ bf16 copy with bf16 storage) */
+  const uint32_t* norm_obs_amax;                  /* ADDHIP_PREC_F16X2: their tracked maximum (addhip_gather_t.obs_amax) or NULL */
   const float* norm_action;                       /* [Mb, 32] */
   const float* old_logp; const float* adv; const float* tar_val; const float* rand_mask;   /* [Mb] */
   float action_std, logp_const, ppo_clip_ratio, action_bound_weight, action_reg_weight, critic_loss_weight, grad_scale;
@@ -606,6 +666,7 @@ typedef struct {
   int32_t rows;                                   /* Mb; the net runs Mb + 1 rows (rows_cap >= Mb + 1) */
   int32_t disc_dim;                               /* columns of a difference row that carry data (<= disc->in_ld) */
   const float* norm_diff; const uint16_t* norm_diff16;   /* [Mb + 1, in_ld]; row Mb is all zeros */
+  const uint32_t* norm_diff_amax;                 /* ADDHIP_PREC_F16X2: their tracked maximum (addhip_gather_t.diff_amax) or NULL */
   float loss_scale;                               /* disc_loss_weight * grad_scale */
   float logit_reg, grad_penalty, weight_decay;
   float* dlogit;                                  /* workspace [Mb + 1] */

@@ -45,7 +45,28 @@ def T(x, dtype=None):
     return torch.tensor(np.ascontiguousarray(x), dtype=dtype, device="cuda")
 
 
-PRECISIONS = ["fp32", "bf16x3", "bf16x2"]  # agent.matmul_precision product modes with fp32-class error bounds (include/addhip.h)
+# agent.matmul_precision product modes with fp32-class error bounds (include/addhip.h); "bf16x3" splits fp32 operands inside every GEMM
+# (csrc/gemm_split.hip), "bf16x3_planes" runs the update step on plane-stored operands (csrc/gemm_x3.hip), "f16x2" splits them two ways
+# into fp16 on per-tensor power-of-two scales (four products, 22-bit operands: ADDHIP_PREC_F16X2)
+PRECISIONS = ["fp32", "bf16x3", "bf16x3_planes", "f16x2", "bf16x2"]
+
+
+def sync_minibatch16(ag):
+    """The 16-bit copies of the gathered minibatch rows that addhip_gather_minibatch writes in the storage modes (bf16: rounded to nearest
+    even; bf16x3: plane storage), refreshed from the fp32 rows a test wrote by hand."""
+    import add_gym_amd._lib as L
+
+    W = ag._W
+    if getattr(ag, "_f16x2", False):  # f16x2: the rows' tracked maxima instead (the fp16 split's scales)
+        L.call("addhip_fill_zero", L.ptr(W["mb_amax"]), 2 * L.AMAX_SLOTS, L.current_stream())
+        for i, src in enumerate(("norm_obs", "norm_diff")):
+            L.call("addhip_amax_f32", L.ptr(W[src]), W[src].numel(), L.ptr(W["mb_amax"][i]), L.current_stream())
+    if "norm_obs16" not in W:
+        return
+    x3 = ag._storage16 == L.STORE_BF16X3
+    for src, dst in (("norm_obs", "norm_obs16"), ("norm_diff", "norm_diff16")):
+        rows, cols = W[dst].shape[0], W[src].shape[1]
+        L.call("addhip_to_bf16x3" if x3 else "addhip_to_bf16", L.ptr(W[src]), L.ptr(W[dst]), rows, cols, cols, cols, L.current_stream())
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -83,9 +104,7 @@ def minibatch_loss_gradients_and_adamw(precision="fp32"):
     W["mb_mask"].copy_(T(mb["rand_action_mask"]))
     W["norm_diff"].zero_()
     W["norm_diff"][:M, :114] = T(mb["norm_diff"])
-    if "norm_obs16" in W:  # bf16-storage mode: the gather kernel writes these copies (round to nearest even, as the tensor cast does)
-        W["norm_obs16"].copy_(W["norm_obs"])
-        W["norm_diff16"].copy_(W["norm_diff"][:W["norm_diff16"].shape[0]])
+    sync_minibatch16(ag)
     model = OL.Model(params)
     opt = OL.AdamW(model, 1e-4)
     st = L.current_stream()
@@ -116,6 +135,7 @@ def minibatch_loss_gradients_and_adamw(precision="fp32"):
                     np.testing.assert_allclose(stats[k], float(g["info." + k]), rtol=2e-4, atol=2e-4, err_msg=k)
         m.opt_step += 1
         L.call("addhip_adamw", L.ptr(m.params), L.ptr(m.grads), L.ptr(m.exp_avg), L.ptr(m.exp_avg_sq), m.count, 1e-4, 0.9, 0.999, 1e-8, 0.0, m.opt_step, st)
+        m.refresh_shadow()  # (what the agent's own optimiser step keeps current: the plane-storage shadow, the tracked parameter maximum)
         torch.cuda.synchronize()
         if step in (0, 2):
             ph = {k: v.numpy() for k, v in m.export().items() if k != "_model._action_dist._logstd_net"}

@@ -28,18 +28,31 @@ def T(x):
 
 # per-product error bound relative to sum |a||b|: fp32 MFMA and the exact bf16x3 split share the fp32 bound; plain bf16
 # truncates both operands to 8 significant bits
-TOL = {0: 4e-7, 3: 4e-7, 2: 2.0 ** -14, 1: 2.0 ** -6}
+# (4 = ADDHIP_PREC_F16X2: 22-bit operands on per-tensor scales, all four products: representation error <= 2^-22 per operand, random in
+# sign, next to the same fp32 accumulation -- held to the fp32 tolerance)
+TOL = {0: 4e-7, 3: 4e-7, 4: 4e-7, 2: 2.0 ** -14, 1: 2.0 ** -6}
 
 
-def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, seed=0, precision=0, accumulate=0):
+def amax_slots(t):
+    """ADDHIP_AMAX_SLOTS float bit patterns bounding max |t| (addhip_amax_f32): what an ADDHIP_PREC_F16X2 GEMM scales operand t by."""
+    import torch
+    import add_gym_amd._lib as L
+
+    slots = torch.zeros(L.AMAX_SLOTS, dtype=torch.int32, device="cuda")
+    L.call("addhip_amax_f32", L.ptr(t), t.numel(), L.ptr(slots), L.current_stream())
+    _KEEP.append(slots)
+    return slots
+
+
+def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, seed=0, precision=0, accumulate=0, scale_a=1.0, scale_b=1.0, check_amax=False):
     import torch
     import add_gym_amd._lib as L
     from add_gym_amd.hotpath import gemm
 
     rng = np.random.RandomState(seed)
-    A = rng.uniform(-1, 1, (M, K)).astype(F)
-    B = rng.uniform(-1, 1, (N, K)).astype(F)
-    bias = rng.uniform(-1, 1, N).astype(F)
+    A = (rng.uniform(-1, 1, (M, K)) * scale_a).astype(F)
+    B = (rng.uniform(-1, 1, (N, K)) * scale_b).astype(F)
+    bias = (rng.uniform(-1, 1, N) * scale_a * scale_b).astype(F)
     mask = rng.uniform(-1, 1, (M, N)).astype(F)
     mean = rng.uniform(-1, 1, K).astype(F)
     std = rng.uniform(0.5, 2, K).astype(F)
@@ -54,6 +67,11 @@ def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, 
     g = gemm(M, N, K, L.ptr(dA), lda, a_kc, L.ptr(dB), ldb, b_kc, L.ptr(dC), ldc, epilogue, L.ptr(dbias), L.ptr(dmask), N,
              L.ptr(dmean) if norm else None, L.ptr(dstd) if norm else None, split_k, alpha, L.ptr(dcs) if epilogue == 3 else None, precision,
              accumulate=accumulate)
+    if precision == 4 and not norm:  # the fp16 split scales each operand by its tracked maximum
+        g.a_amax, g.b_amax = L.ptr(amax_slots(dA)), L.ptr(amax_slots(dB))
+    out_amax = torch.zeros(L.AMAX_SLOTS, dtype=torch.int32, device="cuda")
+    if check_amax:
+        g.amax_out = L.ptr(out_amax)
     L.call("addhip_gemm_f32", g, L.current_stream())
     torch.cuda.synchronize()
     A64 = A.astype(np.float64)
@@ -75,7 +93,9 @@ def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, 
     tol = TOL[precision]
     if epilogue == 3 and precision == 1:  # a sign flip of a near-zero masked value is not an error of the product
         pass
-    assert np.all(err <= tol * scale * max(1.0, abs(alpha)) + 1e-6), (M, N, K, a_kc, b_kc, epilogue, split_k, precision, float((err / scale).max()))
+    assert np.all(err <= tol * scale * max(1.0, abs(alpha)) + 1e-6 * scale_a * scale_b), (M, N, K, a_kc, b_kc, epilogue, split_k, precision, float((err / scale).max()))
+    if check_amax:  # the tracked maximum of the result is exactly max |C| over the entries written
+        assert float(out_amax.cpu().numpy().view(np.float32).max()) == float(np.abs(out[0][:, :N]).max())
     if ldc > N:
         assert np.all(out[0][:, N:] == 9.0)  # pad columns are never written
     if epilogue == 3:
@@ -99,6 +119,39 @@ def test_gemm_epilogues(epi):
     run_gemm(515, 1024, 264, 1, 1, epilogue=epi)
     run_gemm(129, 32, 512, 1, 1, epilogue=epi)  # 29/32-wide head shape
     run_gemm(257, 512, 1024, 1, 0, epilogue=epi)
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_f16x2_split(a_kc, b_kc):
+    """ADDHIP_PREC_F16X2 (two-way fp16 split on per-tensor power-of-two scales, four products) at the fp32 tolerance: every layout, ragged
+    edges and K tails, the epilogues, split-K, operands whose magnitudes are far outside fp16's range, the tracked maximum of the result."""
+    run_gemm(4100, 1000, 1024 + 12, a_kc, b_kc, precision=4)
+    run_gemm(16384, 512, 272, a_kc, b_kc, precision=4, check_amax=True)
+    run_gemm(2048, 1024, 512, a_kc, b_kc, precision=4, scale_a=3e-9, scale_b=7e4, check_amax=True)   # gradients x large weights
+    run_gemm(2048, 1024, 512, a_kc, b_kc, precision=4, scale_a=2e7, scale_b=1e-12)
+    if a_kc:
+        for epi in (1, 2, 3):
+            run_gemm(4096, 512, 1024, 1, b_kc, epilogue=epi, precision=4, check_amax=True)
+    if not a_kc and not b_kc:
+        run_gemm(1024, 1024, 16384, 0, 0, split_k=8, precision=4, scale_a=1e-6)
+        run_gemm(1024, 272, 16385 // 4 * 4, 0, 0, split_k=22, precision=4)
+
+
+def test_gemm_f16x2_without_operand_bounds_runs_the_exact_split():
+    """A descriptor that asks for ADDHIP_PREC_F16X2 but carries no tracked maxima (or fused normalisation) runs as ADDHIP_PREC_BF16X3."""
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import gemm
+
+    rng = np.random.RandomState(3)
+    A, B = T(rng.standard_normal((2048, 512)).astype(F) * 1e6), T(rng.standard_normal((1024, 512)).astype(F))
+    outs = []
+    for prec in (L.PREC_F16X2, L.PREC_BF16X3):
+        Cm = torch.zeros(2048, 1024, device="cuda")
+        L.call("addhip_gemm_f32", gemm(2048, 1024, 512, L.ptr(A), 512, 1, L.ptr(B), 512, 1, L.ptr(Cm), 1024, precision=prec), L.current_stream())
+        outs.append(Cm)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
 
 
 @pytest.mark.parametrize("precision", [3, 2, 1])
@@ -404,7 +457,7 @@ def test_shadow_refresh_flat_and_transposed_in_one_launch():
     trans16 = torch.full((count,), 9.0, device="cuda", dtype=torch.bfloat16)
     n = len(mats)
     L.call("addhip_shadow_refresh", L.ptr(params), L.ptr(flat16), L.ptr(trans16), count, (C.c_int64 * n)(*(m[0] for m in mats)),
-           (C.c_int32 * n)(*(m[1] for m in mats)), (C.c_int32 * n)(*(m[2] for m in mats)), n, L.current_stream())
+           (C.c_int32 * n)(*(m[1] for m in mats)), (C.c_int32 * n)(*(m[2] for m in mats)), n, L.STORE_BF16, L.current_stream())
     torch.cuda.synchronize()
     assert torch.equal(flat16, params.to(torch.bfloat16))
     covered = torch.zeros(count, dtype=torch.bool, device="cuda")
@@ -415,7 +468,7 @@ def test_shadow_refresh_flat_and_transposed_in_one_launch():
     assert bool((trans16[~covered] == 9.0).all())
     with pytest.raises(RuntimeError):
         L.call("addhip_shadow_refresh", L.ptr(params), L.ptr(flat16), L.ptr(trans16), count, (C.c_int64 * 1)(count - 10), (C.c_int32 * 1)(8),
-               (C.c_int32 * 1)(8), 1, L.current_stream())
+               (C.c_int32 * 1)(8), 1, L.STORE_BF16, L.current_stream())
 
 
 def _run_with_hint(hint, *a, **k):

@@ -331,22 +331,22 @@ def test_critic_and_disc_heads_and_grad_penalty():
     out2 = torch.full((M + 1, K), 7.0, device="cuda")
     gW, gb, gt_ = torch.full((K,), 0.25, device="cuda"), torch.full((1,), 0.25, device="cuda"), torch.full((K,), 0.25, device="cuda")
     out16 = torch.full((M + 1, K), 7.0, device="cuda", dtype=torch.bfloat16)
-    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, L.ptr(out2), L.ptr(out16), L.ptr(gW), L.ptr(gb), L.ptr(gt_), L.current_stream())
+    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, L.ptr(out2), L.ptr(out16), L.STORE_BF16, L.ptr(gW), L.ptr(gb), L.ptr(gt_), None, L.current_stream())
     torch.cuda.synchronize()
     assert torch.equal(out2, out) and torch.equal(out16, out.to(torch.bfloat16))  # the optional bf16 copy: the same values, rounded to nearest even
     dl64, H64, o64 = dl.cpu().numpy().astype(np.float64), H.astype(np.float64), out.cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(gW.cpu().numpy() - 0.25, dl64 @ H64, rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(gb.cpu().numpy() - 0.25, dl64.sum(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(gt_.cpu().numpy() - 0.25, o64.sum(0), rtol=1e-4, atol=1e-6)
-    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, None, None, None, None, None, L.current_stream())  # every output optional
+    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, None, None, 0, None, None, None, None, L.current_stream())  # every output optional
     # a2 of the gradient-penalty chain: fp32 and / or bf16
     a2, a2_16 = torch.zeros(M, K, device="cuda"), torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
-    L.call("addhip_bcast_mask", L.ptr(dw), L.ptr(dH), K, K, M, L.ptr(a2), L.ptr(a2_16), L.current_stream())
+    L.call("addhip_bcast_mask", L.ptr(dw), L.ptr(dH), K, K, M, L.ptr(a2), L.ptr(a2_16), L.STORE_BF16, None, L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_array_equal(a2.cpu().numpy(), np.where(H[:M] > 0, dw.cpu().numpy()[None, :], 0).astype(F))
     assert torch.equal(a2_16, a2.to(torch.bfloat16))
     a2_16b = torch.zeros_like(a2_16)
-    L.call("addhip_bcast_mask", L.ptr(dw), L.ptr(dH), K, K, M, None, L.ptr(a2_16b), L.current_stream())
+    L.call("addhip_bcast_mask", L.ptr(dw), L.ptr(dH), K, K, M, None, L.ptr(a2_16b), L.STORE_BF16, None, L.current_stream())
     torch.cuda.synchronize()
     assert torch.equal(a2_16b, a2_16)
     # critic head without its dZ pass (dZ = NULL)
@@ -365,7 +365,7 @@ def test_critic_and_disc_heads_and_grad_penalty():
     (20.0 * 0.5 * gp).backward()
     G, st3 = torch.ones(M, 116, device="cuda"), torch.zeros(8, device="cuda")
     G16 = torch.ones(M, 116, device="cuda", dtype=torch.bfloat16)
-    L.call("addhip_grad_penalty", P(T(g)), 116, 114, M, 10.0, L.ptr(G), L.ptr(G16), L.ptr(st3), L.current_stream())
+    L.call("addhip_grad_penalty", P(T(g)), 116, 114, M, 10.0, L.ptr(G), L.ptr(G16), L.STORE_BF16, L.ptr(st3), None, L.current_stream())
     torch.cuda.synchronize()
     assert torch.equal(G16, G.to(torch.bfloat16))
     np.testing.assert_allclose(st3.cpu().numpy()[0] / M, gp.item(), rtol=1e-5)
@@ -532,3 +532,69 @@ def test_optimizer_step_is_the_separate_kernels_in_one_launch(kind):
     L.call("addhip_optimizer_step", o, L.current_stream())
     torch.cuda.synchronize()
     assert torch.equal(g3, g)
+
+
+def test_plane_storage_outputs_of_the_producers():
+    """Plane storage (include/addhip.h: ADDHIP_STORE_BF16X3) written by the kernels that produce GEMM operands in the update step --
+    gather, head backward, a2 of the penalty chain, the penalty gradient, the optimiser's parameter shadow: each is the exact three-way
+    split (tests/util.py: to_planes) of the fp32 value the same launch writes."""
+    import torch
+    import add_gym_amd._lib as L
+    from util import to_planes
+
+    X3 = L.STORE_BF16X3
+    rng = np.random.RandomState(16)
+    i16 = lambda r, c: torch.full((r, 3 * c), 5, dtype=torch.int16, device="cuda")
+    pl = lambda t: t.cpu().numpy().view(np.uint16)
+    # gather: obs rows of stride 272 (264 used), difference rows of stride 128 (114 used)
+    R, Mb = 2000, 555
+    obs, do, dd = np.zeros((R, 272), F), np.zeros((R, 128), F), np.zeros((R, 128), F)
+    obs[:, :264], do[:, :114], dd[:, :114] = rng.standard_normal((R, 264)), rng.standard_normal((R, 114)), rng.standard_normal((R, 114))
+    act = np.zeros((R, 32), F)
+    sc = {k: rng.standard_normal(R).astype(F) for k in ("logp", "adv", "tar", "mask")}
+    om, os_ = np.zeros(272, F), np.ones(272, F)
+    om[:264], os_[:264] = rng.standard_normal(264), rng.rand(264) + 0.5
+    am, as_ = np.zeros(32, F), np.ones(32, F)
+    ma = (rng.rand(128) * 0.3 + 0.01).astype(F)
+    idx = rng.randint(0, R, Mb).astype(np.int64)
+    d = {k: T(v) for k, v in dict(obs=obs, act=act, do=do, dd=dd, om=om, os=os_, am=am, as_=as_, ma=ma, idx=idx, **sc).items()}
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    o = dict(no=z(Mb, 272), na=z(Mb, 32), lp=z(Mb), ad=z(Mb), tv=z(Mb), mk=z(Mb), nd=z(Mb, 128), no16=i16(Mb, 272), nd16=i16(Mb, 128))
+    g = L.GatherT(L.ptr(d["idx"]), Mb, L.ptr(d["obs"]), 272, 264, L.ptr(d["om"]), L.ptr(d["os"]), L.ptr(d["act"]), L.ptr(d["am"]), L.ptr(d["as_"]),
+                  L.ptr(d["logp"]), L.ptr(d["adv"]), L.ptr(d["tar"]), L.ptr(d["mask"]), L.ptr(d["do"]), L.ptr(d["dd"]), 128, 114, L.ptr(d["ma"]), 1e-4,
+                  L.ptr(o["no"]), L.ptr(o["na"]), L.ptr(o["lp"]), L.ptr(o["ad"]), L.ptr(o["tv"]), L.ptr(o["mk"]), L.ptr(o["nd"]), L.ptr(o["no16"]), L.ptr(o["nd16"]), X3)
+    am = torch.zeros(5, L.AMAX_SLOTS, dtype=torch.int32, device="cuda")  # tracked maxima (ADDHIP_PREC_F16X2): obs, diff, dZ, a2, G
+    amax = lambda i: float(am[i].cpu().numpy().view(np.float32).max())
+    g.obs_amax, g.diff_amax = L.ptr(am[0]), L.ptr(am[1])
+    L.call("addhip_gather_minibatch", g, L.current_stream())
+    torch.cuda.synchronize()
+    assert amax(0) == float(o["no"].abs().max()) and amax(1) == float(o["nd"].abs().max())
+    assert np.array_equal(pl(o["no16"]), to_planes(o["no"].cpu().numpy())) and np.array_equal(pl(o["nd16"]), to_planes(o["nd"].cpu().numpy()))
+    assert float(o["no"].abs().max()) > 1.0 and float(o["nd"].abs().max()) > 1.0
+    # head backward, a2, penalty gradient
+    M, K = 999, 512
+    H = T(np.maximum(rng.standard_normal((M, K)), 0).astype(F))
+    w, v = T((rng.standard_normal(K) * 0.1).astype(F)), T((rng.standard_normal(M) * 1e-3).astype(F))
+    dZ, dZ16 = z(M, K), i16(M, K)
+    L.call("addhip_head_backward", L.ptr(v), L.ptr(w), L.ptr(H), K, K, M, L.ptr(dZ), L.ptr(dZ16), X3, None, None, None, L.ptr(am[2]), L.current_stream())
+    a2, a2_16 = z(M, K), i16(M, K)
+    L.call("addhip_bcast_mask", L.ptr(w), L.ptr(H), K, K, M, L.ptr(a2), L.ptr(a2_16), X3, L.ptr(am[3]), L.current_stream())
+    gsrc = np.zeros((M, 128), F)
+    gsrc[:, :114] = rng.standard_normal((M, 114)) * 0.1
+    G, G16, st = z(M, 128), i16(M, 128), z(8)
+    L.call("addhip_grad_penalty", P(T(gsrc)), 128, 114, M, 10.0, L.ptr(G), L.ptr(G16), X3, L.ptr(st), L.ptr(am[4]), L.current_stream())
+    torch.cuda.synchronize()
+    for i, (fp, p16) in enumerate(((dZ, dZ16), (a2, a2_16), (G, G16))):
+        assert np.array_equal(pl(p16), to_planes(fp.cpu().numpy())) and float(fp.abs().max()) > 0.0
+        assert amax(2 + i) == float(fp.abs().max())
+    with pytest.raises(RuntimeError):  # plane storage needs rows of whole 8-value groups
+        L.call("addhip_grad_penalty", P(T(gsrc[:, :116].copy())), 116, 114, M, 10.0, L.ptr(G), L.ptr(G16), X3, L.ptr(st), None, L.current_stream())
+    # the optimiser's shadow of the new parameters
+    n = 8 * 30001
+    p = T(rng.standard_normal(n).astype(F))
+    gr, m1, m2 = T((rng.standard_normal(n) * 0.1).astype(F)), z(n), z(n)
+    p16 = torch.full((3 * n,), 5, dtype=torch.int16, device="cuda")
+    oc = L.OptimizerT(L.OPT_ADAMW, L.ptr(p), L.ptr(gr), L.ptr(m1), L.ptr(m2), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 1, L.ptr(p16), 1, X3)
+    L.call("addhip_optimizer_step", oc, L.current_stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(pl(p16), to_planes(p.cpu().numpy().reshape(1, -1)).reshape(-1)) and float(gr.abs().max()) == 0.0

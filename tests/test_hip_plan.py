@@ -140,7 +140,7 @@ def test_mlp_forward_backward_launch_directly_and_match_torch():
         c.h[i], c.dz[i], c.hbits[i] = L.ptr(h[i]), L.ptr(dz[i]), L.ptr(hb[i])
     c.slabs, c.slab_floats = L.ptr(slabs), slabs.numel()
     st = torch.cuda.current_stream().cuda_stream
-    L.call("addhip_mlp_forward", c, L.ptr(x), None, rows, None, None, 1, st)
+    L.call("addhip_mlp_forward", c, L.ptr(x), None, rows, None, None, 1, None, st)
     xt = x.clone().requires_grad_(False)
     Wt = [w.clone().requires_grad_(True) for w in Ws]
     bt = [b.clone().requires_grad_(True) for b in bs]
@@ -152,7 +152,7 @@ def test_mlp_forward_backward_launch_directly_and_match_torch():
     (h1 * top).sum().backward()
     dz[1].copy_(top * (h1 > 0))  # the caller's part: d loss / d pre-activation of the last hidden layer
     marks = L.MlpMarksT()
-    L.call("addhip_mlp_backward", c, L.ptr(x), None, rows, None, L.BWD_SIGN_BITS, C.byref(marks), st)
+    L.call("addhip_mlp_backward", c, L.ptr(x), None, rows, None, L.BWD_SIGN_BITS, C.byref(marks), None, st)
     torch.cuda.synchronize()
     for i in range(2):
         assert torch.allclose(gW[i], Wt[i].grad, atol=2e-3, rtol=1e-3), i
@@ -160,4 +160,4 @@ def test_mlp_forward_backward_launch_directly_and_match_torch():
     # layer 1: dW GEMM + combine, top bias column sum, zero of gb[0], dX GEMM; layer 0: dW GEMM + combine
     assert marks.launches == 7 and (marks.dw_first[1], marks.dw_last[1], marks.early) == (0, 2, 2) and (marks.dw_first[0], marks.dw_last[0]) == (5, 7)
     # rows beyond the workspace are refused
-    assert L.load().addhip_mlp_forward(C.byref(c), L.ptr(x), None, rows + 1, None, None, 0, st) != 0
+    assert L.load().addhip_mlp_forward(C.byref(c), L.ptr(x), None, rows + 1, None, None, 0, None, st) != 0

@@ -107,12 +107,12 @@ def test_composite_entry_points_record_their_launches():
         c.hidden[i] = h
         c.W[i], c.b[i], c.h[i], c.dz[i], c.hbits[i] = 0x100000 * (i + 1), 0x900000 + 0x1000 * i, 0x2000000 * (i + 1), 0x6000000 * (i + 1), 0xA000000 + 0x100000 * i
     p = Plan()
-    p.add("addhip_mlp_forward", c, 0x50000000, None, 1025, None, None, 1)
+    p.add("addhip_mlp_forward", c, 0x50000000, None, 1025, None, None, 1, None)
     shapes = [(n, [(x.M, x.N, x.K, x.epilogue, bool(x.relu_bits)) for x in gs]) for n, gs in p.launches()]
     assert shapes == [("addhip_gemm_f32", [(1024, 256, 128, L.EPI_BIAS_RELU, True)]), ("addhip_gemm_f32", [(1, 256, 128, L.EPI_BIAS_RELU, False)]),
                       ("addhip_gemm_f32", [(1024, 128, 256, L.EPI_BIAS_RELU, True)]), ("addhip_gemm_f32", [(1, 128, 256, L.EPI_BIAS_RELU, False)])]
     with pytest.raises(L.AddhipError):  # more rows than the workspace holds
-        p.add("addhip_mlp_forward", c, 0x50000000, None, 1026, None, None, 0)
+        p.add("addhip_mlp_forward", c, 0x50000000, None, 1026, None, None, 0, None)
     pm, dm = L.PpoMarksT(60, 30, 20, 50), L.DiscMarksT(40, 10, 12, 20, 21, 24)
     secs = (L.SectionT * 10)()
     assert lib.addhip_update_schedule(5, C.byref(pm), C.byref(dm), secs, 10) == 10

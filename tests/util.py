@@ -90,3 +90,39 @@ class HipMotion:
         self.lengths = lengths
         self.c = L.MotionT(L.ptr(self.pose), L.ptr(self.vel), L.ptr(self.start), L.ptr(self.steps), L.ptr(self.len), L.ptr(self.loop),
                            len(lengths), int(self.pose.shape[0]), int(reference_compat), 100.0)
+
+
+# ---------------------------------------------------------------- plane storage (include/addhip.h: ADDHIP_STORE_BF16X3; csrc/planes.h)
+def split3(x):
+    """fp32 array -> (hi, mid, lo) fp32 arrays that are bf16 values (low 16 bits zero) with hi + mid + lo == x exactly: the
+    truncation split of csrc/planes.h, restated with numpy bit operations."""
+    x = np.ascontiguousarray(x, np.float32)
+    hi = (x.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    r1 = (x - hi).astype(np.float32)
+    mid = (r1.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    lo = (r1 - mid).astype(np.float32)
+    return hi, mid, lo
+
+
+def to_planes(x, ld=None):
+    """[rows, cols] fp32 -> [rows, 3 * ld] uint16 in plane storage (groups of 8 values: hi x 8 | mid x 8 | lo x 8); pad columns 0."""
+    x = np.asarray(x, np.float32)
+    rows, cols = x.shape
+    ld = cols if ld is None else ld
+    assert ld % 8 == 0 and ld >= cols
+    full = np.zeros((rows, ld), np.float32)
+    full[:, :cols] = x
+    planes = np.stack([(p.view(np.uint32) >> 16).astype(np.uint16) for p in split3(full)], 0)  # [3, rows, ld]
+    return np.ascontiguousarray(planes.reshape(3, rows, ld // 8, 8).transpose(1, 2, 0, 3)).reshape(rows, 3 * ld)
+
+
+def from_planes(u16, cols=None):
+    """[rows, 3 * ld] uint16 plane storage -> ([rows, ld] fp32 sum of the planes, [3, rows, ld] fp32 planes)."""
+    u16 = np.asarray(u16, np.uint16)
+    rows, w = u16.shape
+    ld = w // 3
+    planes = (u16.reshape(rows, ld // 8, 3, 8).transpose(2, 0, 1, 3).reshape(3, rows, ld).astype(np.uint32) << 16).view(np.float32)
+    val = ((planes[0].astype(np.float64) + planes[1]) + planes[2]).astype(np.float32)  # exact: the three parts do not overlap
+    if cols is not None:
+        val, planes = val[:, :cols], planes[:, :, :cols]
+    return val, planes

@@ -12,6 +12,10 @@ for w in ag._W.values():
     if w.dtype == torch.float32: w.normal_()
 for r in (ag._run_actor, ag._run_critic, ag._run_disc):
     for t in r.h + r.dz: t.normal_()
+    if r.storage16:  # (random bf16 values in every plane: zero operands would flatter the clock)
+        for t in r.h16 + r.dz16: t.copy_(torch.randn(t.shape, device=t.device))
+for w in ag._W.values():
+    if w.dtype == torch.bfloat16: w.copy_(torch.randn(w.shape, device=w.device))
 st = torch.cuda.current_stream()
 # the clocks of an idle chip ramp over the first milliseconds of load: bring it to its loaded state before the first timed launch
 _w = torch.randn(8192, 8192, device="cuda")
