@@ -136,7 +136,7 @@ class DiscMarksT(C.Structure):
     _fields_ = [("launches", C.c_int32), ("head", C.c_int32), ("chain", C.c_int32), ("backward", C.c_int32), ("top_dw_first", C.c_int32), ("top_dw_last", C.c_int32)]
 
 
-BWD_GRADS_ZEROED, BWD_TOP_BIAS_DONE, BWD_ACCUMULATE_DW, BWD_TOP_CAST_DONE, BWD_SIGN_BITS = 1, 2, 4, 8, 16
+BWD_GRADS_ZEROED, BWD_TOP_BIAS_DONE, BWD_ACCUMULATE_DW, BWD_TOP_CAST_DONE, BWD_SIGN_BITS, BWD_TOP_BIAS_REPLICAS = 1, 2, 4, 8, 16, 32
 BUCKET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_void_p)  # addhip_bucket_fn(user, bucket, stream)
 MAX_STREAMS = 8
 OPT_ADAMW, OPT_SGD = 0, 1

@@ -6,8 +6,19 @@
 // heads), PPOAgent._compute_actor_loss / _compute_critic_loss with their autograd backward (learning/ppo_agent.py:194-275,
 // base_agent.py:522-546) and ADDAgent._compute_disc_loss (learning/add/add_agent.py:141-202, amp_agent.py:177-192) as explicit launches.
 #include "common.h"
+#include "record.h"
 
 namespace {
+
+// A composite entry point that fails after some of its launches were recorded (a check that sits between launches) leaves the plan as it
+// found it: the plan's size at entry is restored on every non-zero return.
+struct PlanGuard {
+  int size = addhip::record_size();
+  int done(int rc) const {
+    if (rc != 0 && addhip::recording()) addhip::record_truncate(size);
+    return rc;
+  }
+};
 
 addhip_gemm_t gemm(int M, int N, int K, const void* A, int lda, int akc, const void* B, int ldb, int bkc, float* C, int ldc, int epilogue = ADDHIP_EPI_NONE,
                    const float* bias = nullptr) {
@@ -193,13 +204,14 @@ int backward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64
     else
       LAUNCH(addhip_slab_reduce(slabs, total, slab, net.gW[i], slab, 1.0f, (flags & ADDHIP_BWD_ACCUMULATE_DW) ? 1 : 0, stream));
     if (marks) marks->dw_last[i] = launches - base;
-    // every gradient of this net except W[0] / b[0] is final here (b[1] came with the dX GEMM of layer 2, the head's with the loss
-    // kernels): an early bucket for the data-parallel exchange
-    if (marks && i == 1) marks->early = launches - base;
     if (i == n - 1 && !(flags & ADDHIP_BWD_TOP_BIAS_DONE)) {
       ADDHIP_REQUIRE(net.dz[i], "mlp_backward: the top bias gradient is summed from the fp32 dz[last]");
       LAUNCH(addhip_col_sum(net.dz[i], (int)rows, out_d, out_d, net.gb[i], 1.0f, zeroed ? 1 : 0, stream));
     }
+    // every gradient of this net except W[0] / b[0] is final here (b[1] came with the dX GEMM of layer 2 -- or, for a two-layer net
+    // whose caller left the top bias to this pass, with the column sum just above; the head's with the loss kernels): an early bucket
+    // for the data-parallel exchange
+    if (marks && i == 1) marks->early = launches - base;
     if (i > 0) {
       const int prev_d = net.hidden[i - 1];
       if (!zeroed) LAUNCH(addhip_fill_zero(net.gb[i - 1], prev_d, stream));
@@ -241,7 +253,8 @@ extern "C" int addhip_mlp_forward(const addhip_mlp_t* net, const float* x, const
   ADDHIP_REQUIRE(storage16(*net) ? (x16 && !a_mean) : (x != nullptr), "mlp_forward: bf16 storage takes x16 (already normalised), the other modes x");
   ADDHIP_REQUIRE((a_mean == nullptr) == (a_std == nullptr), "mlp_forward: a_mean and a_std come together");
   int launches = 0;
-  return forward(*net, x, x16, rows, a_mean, a_std, sign_bits != 0, launches, stream, x_amax);
+  const PlanGuard guard;
+  return guard.done(forward(*net, x, x16, rows, a_mean, a_std, sign_bits != 0, launches, stream, x_amax));
 }
 
 extern "C" int addhip_mlp_backward(const addhip_mlp_t* net, const float* x, const uint16_t* x16, int64_t rows, const addhip_extra_dw_t* extra, int32_t flags,
@@ -253,10 +266,11 @@ extern "C" int addhip_mlp_backward(const addhip_mlp_t* net, const float* x, cons
   for (int i = 0; i < net->num_hidden; ++i) ADDHIP_REQUIRE(net->gW[i] && net->gb[i], "mlp_backward: gradient of layer %d missing", i);
   if (marks) memset(marks, 0, sizeof(*marks));
   int launches = 0;
-  return backward(*net, x, x16, rows, extra, flags, marks, launches, stream, x_amax);
+  const PlanGuard guard;
+  return guard.done(backward(*net, x, x16, rows, extra, flags, marks, launches, stream, x_amax));
 }
 
-extern "C" int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, void* stream) {
+static int ppo_loss_impl(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, void* stream) {
   ADDHIP_REQUIRE(d && d->actor && d->critic, "ppo_loss_fwd_bwd: null argument");
   const addhip_mlp_t &A = *d->actor, &Cn = *d->critic;
   const int Mb = d->rows;
@@ -327,7 +341,7 @@ extern "C" int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_ma
   return 0;
 }
 
-extern "C" int addhip_disc_loss_fwd_bwd(const addhip_disc_loss_t* d, addhip_disc_marks_t* marks, void* stream) {
+static int disc_loss_impl(const addhip_disc_loss_t* d, addhip_disc_marks_t* marks, void* stream) {
   ADDHIP_REQUIRE(d && d->disc, "disc_loss_fwd_bwd: null argument");
   const addhip_mlp_t& D = *d->disc;
   const int Mb = d->rows, Md = Mb + 1;
@@ -395,6 +409,15 @@ extern "C" int addhip_disc_loss_fwd_bwd(const addhip_disc_loss_t* d, addhip_disc
     return rc;
   if (marks) *marks = addhip_disc_marks_t{launches, m_head, m_chain, m_bwd, m_bwd + mk.dw_first[1], m_bwd + mk.dw_last[1]};
   return 0;
+}
+
+extern "C" int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, void* stream) {
+  const PlanGuard guard;  // (a call refused between two of its launches leaves a plan being recorded unchanged)
+  return guard.done(ppo_loss_impl(d, marks, stream));
+}
+extern "C" int addhip_disc_loss_fwd_bwd(const addhip_disc_loss_t* d, addhip_disc_marks_t* marks, void* stream) {
+  const PlanGuard guard;
+  return guard.done(disc_loss_impl(d, marks, stream));
 }
 
 extern "C" int addhip_update_schedule(int32_t base, const addhip_ppo_marks_t* ppo, const addhip_disc_marks_t* disc, addhip_section_t* out, int32_t capacity) {

@@ -13,10 +13,11 @@ struct addhip_plan {
     std::vector<addhip_gemm_t> gemms;  // GEMM launches only: their problem descriptors, for introspection (roofline accounting)
   };
   std::vector<Call> calls;
+  int schedules = 0;  // schedules created over this plan and not yet destroyed: addhip_plan_destroy refuses while any is alive
 };
 
 struct addhip_schedule {
-  const addhip_plan* plan;
+  addhip_plan* plan;
   std::vector<addhip_section_t> sections;
   int num_streams;
   hipEvent_t fork;
@@ -36,6 +37,11 @@ int record_push(const char* name, std::function<int(void*)> fn, const addhip_gem
   g_recording->calls.push_back(std::move(c));
   return 0;
 }
+// composite entry points (learner.hip): a call refused half way through its launches leaves the plan as it found it
+int record_size() { return g_recording ? (int)g_recording->calls.size() : 0; }
+void record_truncate(int size) {
+  if (g_recording && size >= 0 && (size_t)size < g_recording->calls.size()) g_recording->calls.resize((size_t)size);
+}
 }  // namespace addhip
 
 extern "C" int addhip_plan_create(addhip_plan_t** out) {
@@ -45,6 +51,7 @@ extern "C" int addhip_plan_create(addhip_plan_t** out) {
 }
 
 extern "C" int addhip_plan_destroy(addhip_plan_t* plan) {
+  ADDHIP_REQUIRE(!plan || plan->schedules == 0, "plan_destroy: %d schedule(s) still refer to this plan (destroy them first)", plan ? plan->schedules : 0);
   if (plan && plan == g_recording) g_recording = nullptr;
   delete plan;
   return 0;
@@ -108,7 +115,8 @@ extern "C" int addhip_schedule_create(const addhip_plan_t* plan, const addhip_se
     if (s.wait_after >= 0) waited[s.wait_after] = 1;
   }
   auto* sc = new addhip_schedule();
-  sc->plan = plan;
+  sc->plan = const_cast<addhip_plan*>(plan);
+  sc->plan->schedules += 1;
   sc->sections.assign(sections, sections + count);
   sc->num_streams = num_streams;
   sc->fork = nullptr;
@@ -129,6 +137,7 @@ extern "C" int addhip_schedule_create(const addhip_plan_t* plan, const addhip_se
 
 extern "C" int addhip_schedule_destroy(addhip_schedule_t* sc) {
   if (!sc) return 0;
+  if (sc->plan) sc->plan->schedules -= 1;
   if (sc->fork) (void)hipEventDestroy(sc->fork);
   for (hipEvent_t e : sc->done)
     if (e) (void)hipEventDestroy(e);
@@ -145,20 +154,23 @@ extern "C" int addhip_schedule_run(addhip_schedule_t* sc, void* const* streams, 
   // fork: the side streams start behind everything already enqueued on streams[0]
   ADDHIP_HIP(hipEventRecord(sc->fork, st(0)));
   for (int i = 1; i < sc->num_streams; ++i) ADDHIP_HIP(hipStreamWaitEvent(st(i), sc->fork, 0));
-  for (size_t k = 0; k < sc->sections.size(); ++k) {
+  int rc = 0;
+  for (size_t k = 0; k < sc->sections.size() && rc == 0; ++k) {
     const addhip_section_t& s = sc->sections[k];
     if (s.wait_before >= 0) ADDHIP_HIP(hipStreamWaitEvent(st(s.stream), sc->done[s.wait_before], 0));
-    if (int rc = addhip_plan_run(sc->plan, s.first, s.last, streams[s.stream])) return rc;
+    rc = addhip_plan_run(sc->plan, s.first, s.last, streams[s.stream]);
+    if (rc) break;  // (the join below still runs: the side streams were forked and may hold queued work)
     if (s.wait_after >= 0) ADDHIP_HIP(hipStreamWaitEvent(st(s.stream), sc->done[s.wait_after], 0));
     if (sc->done[k]) ADDHIP_HIP(hipEventRecord(sc->done[k], st(s.stream)));
     // the exchange step of this section's result (a gradient bucket's all-reduce) is the host's: it is told where in the issue order
     // and on which stream the data is final
     if (s.bucket >= 0 && on_bucket) on_bucket(user, s.bucket, streams[s.stream]);
   }
-  // join: streams[0] continues behind every side stream
+  // join: streams[0] continues behind every side stream -- also when a section failed, so that the caller's next work on streams[0]
+  // cannot race with what the side streams already hold
   for (int i = 1; i < sc->num_streams; ++i) {
     ADDHIP_HIP(hipEventRecord(sc->join[i - 1], st(i)));
     ADDHIP_HIP(hipStreamWaitEvent(st(0), sc->join[i - 1], 0));
   }
-  return 0;
+  return rc;
 }

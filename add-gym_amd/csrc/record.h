@@ -17,6 +17,8 @@ namespace addhip {
 // (plan.hip)
 bool recording();
 int record_push(const char* name, std::function<int(void*)> fn, const addhip_gemm_t* gemms, int n_gemms);
+int record_size();               // calls in the plan being recorded on this thread (0 when not recording)
+void record_truncate(int size);  // drop the calls recorded behind `size` (a composite entry point refused half way)
 
 // how an argument is kept inside a recorded call: by value, except pointers to the ABI's parameter blocks, which are copied
 template <class T> struct Held {

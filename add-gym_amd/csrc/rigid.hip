@@ -20,6 +20,7 @@
 // with coalesced loads/stores.  Per-lane LDS: pose 36 + velocity 36 + target 32 + sin/cos 64 + U 192 + 1/D, u 64 +
 // 4 branch accumulators x 27 floats = 532 floats (133 KB per workgroup) + 11 KB of model constants staged once per workgroup;
 // body velocities / up-vectors live in private (scratch) arrays that stay in L2.
+#include <mutex>
 #include "common.h"
 #include "record.h"
 #include "philox.h"
@@ -976,6 +977,32 @@ extern "C" int addhip_rigid_randomize(const addhip_rigid_dr_t* dr, float* env_sc
   return addhip::check_launch("rigid_dr_kernel");
 }
 
+// Per-device set-up done once (a control step is launch-latency scale at 4096 envs: no runtime queries on its path): the CU count that picks
+// the kernel form, and the dynamic-LDS limits of the three kernels.  One slot per device ordinal, guarded by a mutex.
+namespace {
+struct DeviceSetup { bool done = false; int cus = 256; };
+DeviceSetup* device_setup() {
+  static std::mutex mu;
+  static DeviceSetup slots[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  DeviceSetup& d = slots[dev];
+  if (!d.done) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) d.cus = cus;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * l4_lds_floats(MAXP, false))) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * l4_lds_floats(MAXP, true))) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * LDS_FLOATS)) != hipSuccess)
+      return nullptr;
+    d.done = true;
+  }
+  return &d;
+}
+}  // namespace
+
 extern "C" int addhip_rigid_step(const addhip_rigid_model_t* m, float* sim_pose, float* sim_vel, const float* target, int32_t target_stride,
                                  int32_t num_envs, uint8_t* contact_flag, uint32_t* contact_bits, void* stream) {
   ADDHIP_REQUIRE(m && sim_pose && sim_vel && target, "rigid_step: null argument");
@@ -987,29 +1014,17 @@ extern "C" int addhip_rigid_step(const addhip_rigid_model_t* m, float* sim_pose,
   ADDHIP_RECORDABLE(addhip_rigid_step, m, sim_pose, sim_vel, target, target_stride, num_envs, contact_flag, contact_bits);
   if (m->chains) {  // four lanes per environment
     // two waves per CU (the all-LDS form) serve up to 2 x 16 envs per CU; beyond that the register form runs four
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    const bool regs = num_envs > 2 * L4_ENVS * cus;
-    static bool attr4_set = false;
-    if (!attr4_set) {
-      ADDHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(sizeof(float) * l4_lds_floats(MAXP, false))));
-      ADDHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(sizeof(float) * l4_lds_floats(MAXP, true))));
-      attr4_set = true;
-    }
+    DeviceSetup* ds = device_setup();
+    ADDHIP_REQUIRE(ds, "rigid_step: device set-up failed (hipFuncSetAttribute)");
+    const bool regs = num_envs > 2 * L4_ENVS * ds->cus;
     const size_t shmem4 = sizeof(float) * l4_lds_floats(m->num_points, regs);  // G1 (301 points): 69 KB / 38.7 KB
     const dim3 grid4((num_envs + L4_ENVS - 1) / L4_ENVS);
     if (regs) hipLaunchKernelGGL(rigid_step4_kernel<true>, grid4, dim3(64), shmem4, (hipStream_t)stream, *m, sim_pose, sim_vel, target, target_stride, num_envs, contact_flag, contact_bits);
     else hipLaunchKernelGGL(rigid_step4_kernel<false>, grid4, dim3(64), shmem4, (hipStream_t)stream, *m, sim_pose, sim_vel, target, target_stride, num_envs, contact_flag, contact_bits);
     return addhip::check_launch("rigid_step4_kernel");
   }
-  static bool attr_set = false;
   const size_t shmem = sizeof(float) * LDS_FLOATS;
-  if (!attr_set) {
-    ADDHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rigid_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set = true;
-  }
+  ADDHIP_REQUIRE(device_setup(), "rigid_step: device set-up failed (hipFuncSetAttribute)");
   hipLaunchKernelGGL(rigid_step_kernel, dim3((num_envs + WG - 1) / WG), dim3(WG), shmem, (hipStream_t)stream, *m, sim_pose, sim_vel, target,
                      target_stride, num_envs, contact_flag, contact_bits);
   return addhip::check_launch("rigid_step_kernel");

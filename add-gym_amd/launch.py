@@ -65,7 +65,8 @@ def _pump(src, dst):
 def spawn_ranks(script_argv, world, timeout=None, extra_env=None):
     """Start `world` fresh children of `python script_argv...`, one per rank, on 127.0.0.1; rank 0's stdout is forwarded to ours
     (it carries the result line), every other stream goes to stderr.  Returns 0 when all ranks exit 0; on the first failure the
-    remaining ranks (exactly the PIDs started here) are terminated and that rank's exit code is returned."""
+    remaining ranks (exactly the PIDs started here) are terminated and that rank's exit code is returned.  The same clean-up runs on
+    every other way out: timeout (124), SIGTERM / SIGINT delivered to the launcher (128 + signal), an exception in the wait loop."""
     env0 = dict(os.environ)
     env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver
     env0.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world)})
@@ -75,38 +76,60 @@ def spawn_ranks(script_argv, world, timeout=None, extra_env=None):
     procs, pumps = [], []
     out = getattr(sys.stdout, "buffer", sys.stdout)
     err = getattr(sys.stderr, "buffer", sys.stderr)
-    for rank in range(world):
-        env = dict(env0, RANK=str(rank), LOCAL_RANK=str(rank))
-        p = subprocess.Popen([sys.executable] + list(script_argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        procs.append(p)
-        for src, dst in ((p.stdout, out if rank == 0 else err), (p.stderr, err)):
-            t = threading.Thread(target=_pump, args=(src, dst), daemon=True)
-            t.start()
-            pumps.append(t)
+    import signal
     import time
 
-    t0, rc, alive = time.monotonic(), 0, set(range(world))
-    while alive and rc == 0:
-        for r in sorted(alive):
-            code = procs[r].poll()
-            if code is not None:
-                alive.discard(r)
-                if code != 0:
-                    rc = code if code > 0 else 1
-                    print(f"[launch] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
-                    break
-        if timeout is not None and time.monotonic() - t0 > timeout:
-            rc = 124
-            print(f"[launch] ranks still running after {timeout} s: stopping them", file=sys.stderr, flush=True)
-        time.sleep(0.05)
-    for r in alive:  # only on failure / timeout
-        procs[r].terminate()
-    for r in alive:
-        try:
-            procs[r].wait(timeout=20)
-        except subprocess.TimeoutExpired:
-            procs[r].kill()
-            procs[r].wait()
-    for t in pumps:
-        t.join(timeout=5)
+    class _Stop(Exception):
+        pass
+
+    def _on_signal(signum, frame):  # a launcher told to stop (driver timeout, SIGTERM, ^C) takes its ranks with it: the finally below
+        raise _Stop(signum)
+
+    # (signal handlers can only be installed from the main thread; elsewhere the finally still covers exceptions and normal exits)
+    in_main = threading.current_thread() is threading.main_thread()
+    old_handlers = {sig: signal.signal(sig, _on_signal) for sig in (signal.SIGTERM, signal.SIGINT)} if in_main else {}
+    rc, alive = 0, set()
+    try:
+        for rank in range(world):
+            env = dict(env0, RANK=str(rank), LOCAL_RANK=str(rank))
+            p = subprocess.Popen([sys.executable] + list(script_argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            procs.append(p)
+            alive.add(rank)
+            for src, dst in ((p.stdout, out if rank == 0 else err), (p.stderr, err)):
+                t = threading.Thread(target=_pump, args=(src, dst), daemon=True)
+                t.start()
+                pumps.append(t)
+        t0 = time.monotonic()
+        while alive and rc == 0:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is not None:
+                    alive.discard(r)
+                    if code != 0:
+                        rc = code if code > 0 else 1
+                        print(f"[launch] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
+                        break
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                rc = 124
+                print(f"[launch] ranks still running after {timeout} s: stopping them", file=sys.stderr, flush=True)
+            time.sleep(0.05)
+    except _Stop as stop:
+        rc = 128 + int(stop.args[0])
+        print(f"[launch] signal {int(stop.args[0])}: stopping the ranks", file=sys.stderr, flush=True)
+    finally:
+        # every exit path -- failure, timeout, signal, an exception in the loop above -- stops exactly the PIDs started here: a rank left
+        # behind would sit in its rendezvous or a collective and keep its GPU
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
+        left = [p for p in procs if p.poll() is None]
+        for p in left:
+            p.terminate()
+        for p in left:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        for t in pumps:
+            t.join(timeout=5)
     return rc

@@ -528,6 +528,7 @@ int addhip_return_tracker_fold(const float* ep_stats, int32_t T, float* state, v
  * is hipGraph-capturable like the calls themselves.  Plans are not thread-safe: record and run a plan from one thread at a time. ---- */
 typedef struct addhip_plan addhip_plan_t;
 int addhip_plan_create(addhip_plan_t** out);
+/* (refused, plan left alive, while a schedule created over the plan has not been destroyed: destroy schedules first) */
 int addhip_plan_destroy(addhip_plan_t* plan);
 int addhip_plan_record_begin(addhip_plan_t* plan);
 int addhip_plan_record_end(addhip_plan_t* plan);

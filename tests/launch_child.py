@@ -10,6 +10,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "fail":
     if os.environ["RANK"] == "1":
         sys.exit(7)
     time.sleep(600)
+if len(sys.argv) > 2 and sys.argv[1] == "hang":  # every rank records its PID and sleeps: the launcher is then signalled by the test
+    with open(os.path.join(sys.argv[2], "pid.%s" % os.environ["RANK"]), "w") as f:
+        f.write(str(os.getpid()))
+    time.sleep(600)
 import torch
 import torch.distributed as dist
 

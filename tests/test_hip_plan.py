@@ -161,3 +161,27 @@ def test_mlp_forward_backward_launch_directly_and_match_torch():
     assert marks.launches == 7 and (marks.dw_first[1], marks.dw_last[1], marks.early) == (0, 2, 2) and (marks.dw_first[0], marks.dw_last[0]) == (5, 7)
     # rows beyond the workspace are refused
     assert L.load().addhip_mlp_forward(C.byref(c), L.ptr(x), None, rows + 1, None, None, 0, None, st) != 0
+
+
+def test_plan_destroy_is_refused_while_a_schedule_refers_to_the_plan():
+    """A schedule keeps a pointer to its plan: destroying the plan first would leave it dangling, so the library refuses (destroy order:
+    schedules, then the plan) -- and a failing section still joins the side streams back into streams[0]."""
+    import torch
+    import add_gym_amd._lib as L
+
+    lib = L.load()
+    h, sc = C.c_void_p(), C.c_void_p()
+    assert lib.addhip_plan_create(C.byref(h)) == 0
+    buf = torch.ones(64, device="cuda")
+    lib.addhip_plan_record_begin(h)
+    assert lib.addhip_fill_zero(L.ptr(buf), 64, None) == 0
+    lib.addhip_plan_record_end(h)
+    secs = (L.SectionT * 1)(L.SectionT(1, 0, 1, -1, -1, -1))
+    assert lib.addhip_schedule_create(h, secs, 1, 2, C.byref(sc)) == 0
+    assert lib.addhip_plan_destroy(h) != 0 and b"schedule" in lib.addhip_last_error()
+    side = torch.cuda.Stream()
+    streams = (C.c_void_p * 2)(torch.cuda.current_stream().cuda_stream, side.cuda_stream)
+    assert lib.addhip_schedule_run(sc, streams, C.cast(None, L.BUCKET_FN), None) == 0
+    torch.cuda.synchronize()
+    assert float(buf.abs().max()) == 0.0
+    assert lib.addhip_schedule_destroy(sc) == 0 and lib.addhip_plan_destroy(h) == 0

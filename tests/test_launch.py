@@ -34,6 +34,34 @@ def test_a_failing_rank_stops_the_others_and_its_code_is_returned():
     assert "rank 1 exited with 7" in r.stderr
 
 
+@pytest.mark.timeout(120)
+def test_a_signalled_launcher_takes_its_ranks_with_it(tmp_path):
+    """SIGTERM to the launcher (a driver timeout, a killed job) must not leave ranks behind holding their GPUs."""
+    import signal
+    import time
+
+    p = subprocess.Popen([sys.executable, "-c", DRIVER % (CHILD, 2), "hang", str(tmp_path)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        deadline = time.monotonic() + 60
+        while time.monotonic() < deadline and not all((tmp_path / f"pid.{r}").exists() and (tmp_path / f"pid.{r}").read_text() for r in range(2)):
+            time.sleep(0.1)
+        pids = [int((tmp_path / f"pid.{r}").read_text()) for r in range(2)]
+        p.send_signal(signal.SIGTERM)
+        _, err = p.communicate(timeout=60)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err[-2000:])
+    assert "stopping the ranks" in err
+    for pid in pids:  # both children are gone (reaped by the launcher: the PID no longer exists, or at least is not our child's program)
+        alive = True
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            alive = False
+        assert not alive, pid
+
+
 def test_more_ranks_than_devices_is_refused_unless_rehearsing():
     import add_gym_amd  # noqa: F401
     from add_gym_amd import launch

@@ -120,3 +120,48 @@ def test_composite_entry_points_record_their_launches():
     assert got == [(0, 5, 25, -1, -1, 0), (1, 35, 55, -1, -1, 1), (2, 65, 75, -1, -1, -1), (3, 75, 77, 2, -1, -1), (2, 77, 85, -1, -1, -1),
                    (3, 85, 86, -1, -1, -1), (3, 86, 89, 4, -1, -1), (2, 89, 105, 5, 6, 2), (0, 25, 35, -1, -1, -1), (1, 55, 65, -1, -1, -1)]
     assert lib.addhip_update_schedule(5, C.byref(pm), C.byref(dm), secs, 9) != 0
+
+
+def _two_layer_net(L, slab_floats):
+    c = L.MlpT()
+    c.num_hidden, c.in_dim, c.in_ld, c.head_rows, c.precision, c.rows_cap = 2, 500, 512, 1, L.PREC_F32, 1024
+    for i, h in enumerate((256, 128)):
+        c.hidden[i] = h
+        c.W[i], c.b[i], c.h[i], c.dz[i], c.hbits[i] = 0x100000 * (i + 1), 0x900000 + 0x1000 * i, 0x2000000 * (i + 1), 0x6000000 * (i + 1), 0xA000000 + 0x100000 * i
+        c.gW[i], c.gb[i] = 0x1100000 * (i + 1), 0x1900000 + 0x1000 * i
+    c.slabs, c.slab_floats = 0x70000000, slab_floats
+    return c
+
+
+def test_a_composite_call_refused_between_its_launches_leaves_the_plan_unchanged():
+    """addhip_mlp_backward checks each layer's split-K scratch when it reaches that layer: refused there, the launches it had already
+    recorded for the layers above are dropped again (csrc/learner.hip: PlanGuard)."""
+    L, lib = _lib()
+    from add_gym_amd.learning.model import Plan, split_k_for
+
+    top = split_k_for(128, 256, 1024) * 128 * 256       # the top layer's need: the first check passes ...
+    low = split_k_for(256, 512, 1024) * 256 * 512
+    assert low > top                                      # ... the lower layer's does not
+    p = Plan()
+    p.add("addhip_fill_zero", 0x40000, 64)
+    with pytest.raises(L.AddhipError, match="split-K scratch"):
+        p.add("addhip_mlp_backward", _two_layer_net(L, top), 0x50000000, None, 1024, None, L.BWD_TOP_BIAS_DONE, None, None)
+    assert len(p) == 1
+    n = p.add("addhip_mlp_backward", _two_layer_net(L, low), 0x50000000, None, 1024, None, L.BWD_TOP_BIAS_DONE, None, None)
+    assert n == 1 and len(p) > 1
+
+
+def test_early_mark_of_a_two_layer_net_comes_after_its_top_bias_sum():
+    """With two hidden layers and the top bias gradient left to addhip_mlp_backward (flags without TOP_BIAS_DONE), `early` -- "every gradient
+    but W[0] / b[0] is final" -- must lie behind the column sum that writes gb[1]."""
+    L, lib = _lib()
+    from add_gym_amd.learning.model import Plan, split_k_for
+
+    c = _two_layer_net(L, 2 * split_k_for(256, 512, 1024) * 256 * 512)
+    marks = L.MlpMarksT()
+    p = Plan()
+    p.add("addhip_mlp_backward", c, 0x50000000, None, 1024, None, 0, C.byref(marks), None)
+    names = [n for n, _ in p.launches()]
+    assert "addhip_col_sum" in names
+    assert marks.early == names.index("addhip_col_sum") + 1 and marks.early > marks.dw_last[1]
+    assert marks.launches == len(names)
