@@ -103,7 +103,7 @@ class MlpT(C.Structure):
                 ("dz16", f32p * _H), ("slabs", f32p), ("slab_floats", C.c_int64), ("slabs_top", f32p), ("bias_replicas", f32p), ("bias_replica_rows", C.c_int32),
                 ("flat_params", f32p), ("flat_trans16", f32p),
                 ("flat_count", C.c_int64), ("t_offset", C.POINTER(C.c_int64)), ("t_rows", C.POINTER(C.c_int32)), ("t_cols", C.POINTER(C.c_int32)), ("t_count", C.c_int32),
-                ("amax", f32p), ("w_amax", f32p)]
+                ("amax", f32p), ("w_amax", f32p), ("deterministic", C.c_int32), ("ordered_scratch", f32p)]
 
 
 class ExtraDwT(C.Structure):
@@ -143,6 +143,7 @@ OPT_ADAMW, OPT_SGD = 0, 1
 RIGID_BODY_W, RIGID_TOPO_W = 32, 8
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
 PREC_F32, PREC_BF16, PREC_BF16X2, PREC_BF16X3, PREC_F16X2 = 0, 1, 2, 3, 4
+ORDERED_BLOCKS, HEAD_BWD_BLOCKS = 64, 256  # fixed-order reductions (agent.deterministic)
 AMAX_SLOTS, MLP_AMAX_TENSORS = 64, 12  # tracked operand maxima of PREC_F16X2 (include/addhip.h)
 STORE_BF16, STORE_BF16X3 = 1, 3  # 16-bit storage formats of GEMM operands (include/addhip.h, "plane storage")
 GEMM_HINT_BIG_TILE, GEMM_HINT_NO_BIG_TILE, GEMM_HINT_ONE_STAGE, GEMM_HINT_TWO_STAGE, GEMM_HINT_REG_STAGED, GEMM_HINT_WIDE_TILE = 1, 2, 4, 8, 16, 32
@@ -169,6 +170,7 @@ SIGNATURES = {
     "addhip_slab_reduce": [vp, i32, i64, vp, i64, f32, i32, vp],
     "addhip_slab_reduce_pair": [vp, i32, i64, vp, i64, f32, i32, vp, i32, i32, vp, i32, i32, i32, vp],
     "addhip_col_sum": [vp, i32, i32, i32, vp, f32, i32, vp],
+    "addhip_col_sum_ordered": [vp, i32, i32, i32, vp, f32, i32, vp, vp],
     "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp],
     "addhip_fill_normal": [vp, i64, u64, u64, vp],
     "addhip_fill_uniform": [vp, i64, u64, u64, vp],
@@ -188,7 +190,7 @@ SIGNATURES = {
     "addhip_count_mask": [vp, i32, vp, vp],
     "addhip_critic_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
     "addhip_disc_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
-    "addhip_head_backward": [vp, vp, vp, i32, i32, i64, vp, vp, i32, vp, vp, vp, vp, vp],
+    "addhip_head_backward": [vp, vp, vp, i32, i32, i64, vp, vp, i32, vp, vp, vp, vp, vp, vp],
     "addhip_outer_mask": [vp, vp, vp, i32, i32, i64, vp, vp],
     "addhip_bcast_mask": [vp, vp, i32, i32, i64, vp, vp, i32, vp, vp],
     "addhip_grad_penalty": [vp, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp],

@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(addhip_gemm_t g, 
 
   // epilogue (gemm_epilogue.h): every wave's block leaves through its private slice of the (now idle) stage buffers
   // (the loop's last barrier is behind every read of them)
-  addhip_epi::gemm_epilogue<FM, FN, EPI>(g, acc, reinterpret_cast<char*>(lds) + wave * addhip_epi::EpiBuf<FN>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z);
+  // (the 4-workgroups-per-CU form has no register to spare for the maximum: the dispatcher gives descriptors with amax_out the two-stage form)
+  addhip_epi::gemm_epilogue<FM, FN, EPI, false, !SB>(g, acc, reinterpret_cast<char*>(lds) + wave * addhip_epi::EpiBuf<FN>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z,
+                                                      g.alpha);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, bool SB = false>
@@ -399,6 +401,30 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* X, int M, int
   }
 }
 
+// fixed-order column sums (addhip_col_sum_ordered): slice blockIdx.y of the rows -> scratch[blockIdx.y][n] (the four waves of a workgroup
+// are combined in wave order), then one thread per column adds the slices in slice order
+__global__ __launch_bounds__(256) void col_sum_slices_kernel(const float* X, int M, int N, int ld, float* scratch, int rows_per_block) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < N)
+    for (int r = r0 + w; r < r1; r += 4) s += X[(size_t)r * ld + c];
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < N) scratch[(size_t)blockIdx.y * N + c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void col_sum_combine_kernel(const float* scratch, int slices, int N, float* out, float scale, int accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < slices; ++k) s += scratch[(size_t)k * N + n];
+  s *= scale;
+  out[n] = accumulate ? out[n] + s : s;
+}
+
 }  // namespace
 
 namespace addhip {
@@ -428,24 +454,25 @@ int validate(addhip_gemm_t& g) {
   if (g.accumulate) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_NONE && !g.colsum, "gemm: accumulate takes no epilogue");
   if (g.a_mean || g.a_std) ADDHIP_REQUIRE(g.a_kcontig && g.a_mean && g.a_std, "gemm: fused normalisation needs a k-contiguous A and both mean/std");
   if (g.colsum) ADDHIP_REQUIRE(g.epilogue == ADDHIP_EPI_MASK && g.split_k <= 1, "gemm: colsum needs the MASK epilogue");
-  if (g.colsum_replicas > 1) ADDHIP_REQUIRE(g.colsum && g.ldcs >= g.N && g.colsum_replicas <= 64, "gemm: colsum_replicas (2..64) need colsum and ldcs >= N");
+  if (g.colsum_replicas > 1) ADDHIP_REQUIRE(g.colsum && g.ldcs >= g.N && g.colsum_replicas <= 65536, "gemm: colsum_replicas (2..65536) need colsum and ldcs >= N");
   ADDHIP_REQUIRE(g.precision == ADDHIP_PREC_F32 || g.precision == ADDHIP_PREC_BF16 || g.precision == ADDHIP_PREC_BF16X2 ||
                      g.precision == ADDHIP_PREC_BF16X3 || g.precision == ADDHIP_PREC_F16X2, "gemm: bad precision");
-  if (g.amax_out) ADDHIP_REQUIRE(g.split_k <= 1 && !g.accumulate, "gemm: amax_out tracks final results, not split-K slabs");
+  if (g.amax_out) ADDHIP_REQUIRE(g.split_k <= 1 && !g.accumulate && !g.operands_bf16, "gemm: amax_out tracks final results of fp32-operand GEMMs (not split-K slabs, not stored 16-bit operands)");
   ADDHIP_REQUIRE(g.C || g.split_k <= 1, "gemm: split-K slabs are fp32 (C)");
   if (g.operands_bf16) ADDHIP_REQUIRE(!g.accumulate, "gemm: accumulate is not built for bf16-stored operands");
   ADDHIP_REQUIRE(g.operands_bf16 == 0 || g.operands_bf16 == ADDHIP_STORE_BF16 || g.operands_bf16 == ADDHIP_STORE_BF16X3, "gemm: operands_bf16 is 0 or an ADDHIP_STORE_* format");
   ADDHIP_REQUIRE(g.c16_planes == 0 || g.c16_planes == ADDHIP_STORE_BF16 || g.c16_planes == ADDHIP_STORE_BF16X3, "gemm: c16_planes is 0 or an ADDHIP_STORE_* format");
   if (g.C16 && g.c16_planes == ADDHIP_STORE_BF16X3)
-    ADDHIP_REQUIRE(g.N % 8 == 0 && g.ldc16 % 8 == 0 && aligned16(g.C16), "gemm: a plane-storage C16 needs N and ldc16 multiples of 8 and a 16-byte aligned buffer");
+    ADDHIP_REQUIRE(g.operands_bf16 == ADDHIP_STORE_BF16X3 && g.N % 8 == 0 && g.ldc16 % 8 == 0 && aligned16(g.C16),
+                   "gemm: a plane-storage C16 is written by GEMMs on plane-stored operands only (others: addhip_to_bf16x3 of the fp32 result); N and ldc16 multiples of 8, 16-byte aligned buffer");
   if (g.alpha == 0.0f) g.alpha = 1.0f;
   return 0;
 }
 
 // fp32 operands, 128x128 tiles, whole chip: the LDS-DMA kernel (gemm_dma.h).  Not for the fused input normalisation (the DMA
 // cannot transform in flight: those launches -- first layers of the rollout / evaluation passes -- stay on gemm_kernel).
-bool takes_dma_f32(const addhip_gemm_t& g, long long tiles128) {
-  return g.precision == ADDHIP_PREC_F32 && !g.a_mean && tiles128 > 256 && !(g.hint & ADDHIP_GEMM_HINT_REG_STAGED);
+bool takes_dma_f32(const addhip_gemm_t& g, long long tiles128) {  // (amax_out: honoured by the register-staged and split kernels only)
+  return g.precision == ADDHIP_PREC_F32 && !g.a_mean && tiles128 > 256 && !(g.hint & ADDHIP_GEMM_HINT_REG_STAGED) && !g.amax_out;
 }
 int launch_dma_f32(const addhip_dma::GemmGroup& grp, int count, hipStream_t st) {
   const addhip_gemm_t& g = grp.g[0];
@@ -490,7 +517,7 @@ int dispatch_f32(const addhip_gemm_t& g, hipStream_t st) {
   }
   // register-staged 128x128 tiles (fused normalisation; ADDHIP_GEMM_HINT_REG_STAGED): launches with enough workgroups for 4 per CU
   // run one LDS stage (37 KB) x 4 workgroups per CU instead of two stages x 2
-  const bool one_stage = (g.hint & ADDHIP_GEMM_HINT_ONE_STAGE) ? true : (g.hint & ADDHIP_GEMM_HINT_TWO_STAGE) ? false : tiles128 >= 512;
+  const bool one_stage = g.amax_out ? false : (g.hint & ADDHIP_GEMM_HINT_ONE_STAGE) ? true : (g.hint & ADDHIP_GEMM_HINT_TWO_STAGE) ? false : tiles128 >= 512;
   if (one_stage) return launch_cfg<128, 128, 2, 2, 32, true>(g, st);
   return launch_cfg<128, 128, 2, 2, 32>(g, st);
 }
@@ -568,7 +595,7 @@ extern "C" int addhip_slab_reduce_pair(const float* in, int32_t slabs, int64_t s
                                        float* in2, int32_t rows2, int32_t ld2, float* out2, int32_t count2, int32_t accumulate2, int32_t clear2, void* stream) {
   ADDHIP_REQUIRE(in && out && slabs > 0 && count > 0, "slab_reduce_pair: bad arguments");
   ADDHIP_REQUIRE(count % 4 == 0 && slab_stride % 4 == 0 && aligned16(in) && aligned16(out), "slab_reduce_pair: the slab reduction takes 16-byte aligned buffers, count and stride %% 4 == 0");
-  ADDHIP_REQUIRE(in2 && out2 && rows2 > 0 && rows2 <= 64 && count2 > 0 && ld2 >= count2, "slab_reduce_pair: bad second reduction");
+  ADDHIP_REQUIRE(in2 && out2 && rows2 > 0 && rows2 <= 65536 && count2 > 0 && ld2 >= count2, "slab_reduce_pair: bad second reduction");
   ADDHIP_RECORDABLE(addhip_slab_reduce_pair, in, slabs, slab_stride, out, count, scale, accumulate, in2, rows2, ld2, out2, count2, accumulate2, clear2);
   long long b4 = (count / 4 + 255) / 256;
   if (b4 > 2048) b4 = 2048;
@@ -585,6 +612,16 @@ extern "C" int addhip_fill_zero(float* p, int64_t count, void* stream) {
   ADDHIP_RECORDABLE(addhip_fill_zero, p, count);
   ADDHIP_HIP(hipMemsetAsync(p, 0, sizeof(float) * (size_t)count, (hipStream_t)stream));
   return 0;
+}
+
+extern "C" int addhip_col_sum_ordered(const float* X, int32_t M, int32_t N, int32_t ld, float* out, float scale, int32_t accumulate, float* scratch, void* stream) {
+  ADDHIP_REQUIRE(X && out && scratch && M > 0 && N > 0 && ld >= N, "col_sum_ordered: bad arguments");
+  ADDHIP_RECORDABLE(addhip_col_sum_ordered, X, M, N, ld, out, scale, accumulate, scratch);
+  hipStream_t st = (hipStream_t)stream;
+  const int rows_per_block = (M + ADDHIP_ORDERED_BLOCKS - 1) / ADDHIP_ORDERED_BLOCKS;
+  hipLaunchKernelGGL(col_sum_slices_kernel, dim3((N + 63) / 64, ADDHIP_ORDERED_BLOCKS), dim3(256), 0, st, X, M, N, ld, scratch, rows_per_block);
+  hipLaunchKernelGGL(col_sum_combine_kernel, dim3((N + 255) / 256), dim3(256), 0, st, scratch, ADDHIP_ORDERED_BLOCKS, N, out, scale, accumulate);
+  return addhip::check_launch("col_sum_ordered");
 }
 
 extern "C" int addhip_col_sum(const float* X, int32_t M, int32_t N, int32_t ld, float* out, float scale, int32_t accumulate, void* stream) {

@@ -52,7 +52,11 @@ __device__ __forceinline__ void epi_amax(const addhip_gemm_t& g, float amx) {
   if ((threadIdx.x & 63) == 0) atomicMax(&g.amax_out[(blockIdx.x + blockIdx.y * gridDim.x) % ADDHIP_AMAX_SLOTS], __float_as_uint(amx));
 }
 
-template <int MT, int NT, int EPI>
+// X3OUT: the kernel may be asked for a plane-storage C16 (addhip_gemm_t.c16_planes = ADDHIP_STORE_BF16X3).  Only gemm_x3.hip instantiates it:
+// the split of 8 values into three planes needs ~30 more registers, which the 4-workgroups-per-CU kernels (128 VGPRs) do not have.
+// AMAX: the kernel honours addhip_gemm_t.amax_out (the register-staged and split kernels: gemm.hip's gemm_kernel, gemm_split.hip; the
+// dispatcher sends descriptors that carry amax_out to those).
+template <int MT, int NT, int EPI, bool X3OUT = false, bool AMAX = false>
 __device__ __forceinline__ void gemm_epilogue_full(const addhip_gemm_t& g, f32x16 (&acc)[MT][NT], char* ebuf, int lane, int row0, int col0, float* C,
                                                    unsigned short* C16, float alpha) {
   constexpr int ERS = EpiBuf<NT>::ERS;
@@ -93,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue_full(const addhip_gemm_t& g, f32x1
           v = __uint_as_float(__float_as_uint(v) & (unsigned)keep);
           cs += v;
         }
-        amx = fmaxf(amx, fabsf(v));
+        if (AMAX) amx = fmaxf(amx, fabsf(v));
         *reinterpret_cast<float*>(ebuf + rloc * ERS + (b * 32 + li) * 4) = v;
       }
       if (want_bits && lane < 32) g.relu_bits[(size_t)(rtile + lane) * g.ldbits + (cgroup >> 5)] = rword;
@@ -117,7 +121,7 @@ __device__ __forceinline__ void gemm_epilogue_full(const addhip_gemm_t& g, f32x1
         const int idx = lane + 64 * i, rloc = idx / CPR, c8 = (idx % CPR) * 8;
         const float4 lo = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4);
         const float4 hi = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4 + 16);
-        if (g.c16_planes == ADDHIP_STORE_BF16X3)  // plane storage: the exact 3-way split, 48 contiguous bytes per 8 columns
+        if (X3OUT && g.c16_planes == ADDHIP_STORE_BF16X3)  // plane storage: the exact 3-way split, 48 contiguous bytes per 8 columns
           addhip_planes::store8(C16 + 3 * (size_t)(rtile + rloc) * g.ldc16, col0 + c8, lo, hi);
         else
           *reinterpret_cast<uint4*>(C16 + (size_t)(rtile + rloc) * g.ldc16 + col0 + c8) =
@@ -125,11 +129,11 @@ __device__ __forceinline__ void gemm_epilogue_full(const addhip_gemm_t& g, f32x1
       }
     }
   }
-  if (g.amax_out) epi_amax(g, amx);
+  if (AMAX && g.amax_out) epi_amax(g, amx);
 }
 
 // alpha: the factor applied to the accumulators (g.alpha; the F16X2 kernel folds the inverse of its operand scales in)
-template <int MT, int NT, int EPI>
+template <int MT, int NT, int EPI, bool X3OUT = false, bool AMAX = false>
 __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&acc)[MT][NT], char* ebuf, int lane, int row0, int col0, int zslab, float alpha) {
   constexpr int ERS = EpiBuf<NT>::ERS;
   typedef unsigned short u16;
@@ -142,7 +146,7 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
   const bool c16_vec = C16 && (reinterpret_cast<uintptr_t>(C16) & 15) == 0 && (g.ldc16 & 7) == 0;
   // (wave-uniform) the straight-line form for blocks wholly inside C with aligned rows
   if (row0 + MT * 32 <= g.M && col0 + NT * 32 <= g.N && !accum && (!C || c_vec) && (!C16 || c16_vec) && (epi != ADDHIP_EPI_MASK || g.mask_bits)) {
-    gemm_epilogue_full<MT, NT, EPI>(g, acc, ebuf, lane, row0, col0, C, C16, alpha);
+    gemm_epilogue_full<MT, NT, EPI, X3OUT, AMAX>(g, acc, ebuf, lane, row0, col0, C, C16, alpha);
     return;
   }
   float amx = 0.f;
@@ -175,7 +179,7 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
           }
           if (ok) cs += v;
         }
-        if (ok) amx = fmaxf(amx, fabsf(v));
+        if (AMAX && ok) amx = fmaxf(amx, fabsf(v));
         if (epi == ADDHIP_EPI_BIAS_RELU && g.relu_bits) {
           const unsigned long long pos = __ballot(ok && v > 0.f);
           rword = lane == r0 ? (unsigned)pos : lane == r0 + 4 ? (unsigned)(pos >> 32) : rword;
@@ -218,7 +222,7 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
         const int idx = lane + 64 * i, rloc = idx / CPR, c8 = (idx % CPR) * 8, row = rtile + rloc, col = col0 + c8;
         const float4 lo = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4);
         const float4 hi = *reinterpret_cast<const float4*>(ebuf + rloc * ERS + c8 * 4 + 16);
-        if (row < g.M && g.c16_planes == ADDHIP_STORE_BF16X3) {  // (N % 8 == 0: a group of 8 columns is in or out as a whole)
+        if (X3OUT && row < g.M && g.c16_planes == ADDHIP_STORE_BF16X3) {  // (N % 8 == 0: a group of 8 columns is in or out as a whole)
           if (col < g.N) addhip_planes::store8(C16 + 3 * (size_t)row * g.ldc16, col, lo, hi);
         } else if (row < g.M) {
           u16* dst = C16 + (size_t)row * g.ldc16 + col;
@@ -235,11 +239,11 @@ __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&a
       }
     }
   }
-  if (g.amax_out) epi_amax(g, amx);
+  if (AMAX && g.amax_out) epi_amax(g, amx);
 }
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const addhip_gemm_t& g, f32x16 (&acc)[MT][NT], char* ebuf, int lane, int row0, int col0, int zslab) {
-  gemm_epilogue<MT, NT, EPI>(g, acc, ebuf, lane, row0, col0, zslab, g.alpha);
+  gemm_epilogue<MT, NT, EPI, false, false>(g, acc, ebuf, lane, row0, col0, zslab, g.alpha);
 }
 
 }  // namespace addhip_epi

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
   // epilogue (gemm_epilogue.h): every wave's block leaves through its private slice of the stage buffers, once every wave is done
   // reading them
   __syncthreads();
-  addhip_epi::gemm_epilogue<2, 2, EPI>(g, acc, lds + wave * addhip_epi::EpiBuf<2>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z, alpha);
+  addhip_epi::gemm_epilogue<2, 2, EPI, false, true>(g, acc, lds + wave * addhip_epi::EpiBuf<2>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z, alpha);
 }
 
 template <int PLANES, bool F16 = false>

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(Q::THREADS, Q::WPE) void gemm_x3_kernel(addhip_gemm
   }
 
   __syncthreads();  // every wave is done with the last stage (and no DMA is in flight): LDS becomes the waves' private epilogue buffers
-  gemm_epilogue<MT, NT, EPI>(g, acc, lds + wave * EpiBuf<NT>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z);
+  gemm_epilogue<MT, NT, EPI, true>(g, acc, lds + wave * EpiBuf<NT>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z, g.alpha);
 }
 
 typedef Cfg3<2, 4, 4, 2, 3, 1> CfgBig;   // 256x256, 8 waves of 128x64, ring of three, one workgroup per CU

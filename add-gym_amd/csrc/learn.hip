@@ -507,7 +507,7 @@ __global__ void outer_mask_kernel(const float* v, const float* w, const float* H
 // A lane owns the same columns for every row its wave visits, so the column sums are per-lane registers; the four waves
 // of a workgroup are combined in LDS and each workgroup issues one atomic per column.  K <= 1024.
 __global__ __launch_bounds__(256) void head_backward_kernel(const float* v, const float* w, const float* H, int ld, int K, long long rows, float* dZ,
-                                                            unsigned short* dZ16, int planes16, float* dW, float* db, float* dbt, unsigned* amax) {
+                                                            unsigned short* dZ16, int planes16, float* dW, float* db, float* dbt, unsigned* amax, float* ordered) {
   __shared__ float red[4][1024];
   __shared__ float sh[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -536,6 +536,9 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* v, cons
       }
     }
   }
+  // ordered != NULL: this workgroup's partial sums go to ordered[blockIdx.x][0..K) (dW), [K..2K) (dbt), [2K] (db) instead of being added by
+  // atomics; head_backward_combine_kernel adds the workgroups in index order
+  float* mine = ordered ? ordered + (size_t)blockIdx.x * (2 * K + 4) : nullptr;
   for (int pass = 0; pass < 2; ++pass) {
     float* out = pass == 0 ? dW : dbt;
     if (!out) continue;  // uniform
@@ -545,12 +548,29 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* v, cons
       if (k < K) *reinterpret_cast<float4*>(&red[wave][k]) = pass == 0 ? gw[j] : gb[j];
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += 256) atomicAdd(&out[k], red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+    for (int k = threadIdx.x; k < K; k += 256) {
+      const float t4 = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+      if (mine) mine[pass * K + k] = t4;
+      else atomicAdd(&out[k], t4);
+    }
     __syncthreads();
   }
   const float t = block_sum(sv, sh);
-  if (threadIdx.x == 0 && db) atomicAdd(db, t);
+  if (threadIdx.x == 0 && db) {
+    if (mine) mine[2 * K] = t;
+    else atomicAdd(db, t);
+  }
   if (amax) amax_commit(amax, amx);
+}
+
+__global__ __launch_bounds__(256) void head_backward_combine_kernel(const float* ordered, int blocks, int K, float* dW, float* db, float* dbt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // 0..K) dW, K..2K) dbt, 2K db
+  if (i > 2 * K) return;
+  float* out = i < K ? (dW ? dW + i : nullptr) : i < 2 * K ? (dbt ? dbt + (i - K) : nullptr) : db;
+  if (!out) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += ordered[(size_t)b * (2 * K + 4) + i];
+  *out += s;  // (the outputs are accumulated into, as the atomics form does)
 }
 
 __global__ __launch_bounds__(256) void grad_penalty_kernel(const float* g, int ld, int dim, int M, float coef, float* G, unsigned short* G16, int planes16, float* stats, unsigned* amax) {
@@ -934,12 +954,14 @@ extern "C" int addhip_bcast_mask(const float* w, const float* H, int32_t ld, int
 }
 
 extern "C" int addhip_head_backward(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows, float* dZ, uint16_t* dZ16,
-                                    int32_t planes16, float* dW_head, float* db_head, float* db_top, uint32_t* amax, void* stream) {
+                                    int32_t planes16, float* dW_head, float* db_head, float* db_top, uint32_t* amax, float* ordered_scratch, void* stream) {
   ADDHIP_REQUIRE(v && w && H && rows > 0 && K > 0 && K <= 1024 && K % 4 == 0 && ld % 4 == 0 && ld >= K, "head_backward: bad arguments (K <= 1024)");
   ADDHIP_CHECK_PLANES16("head_backward", dZ16, ld);
-  ADDHIP_RECORDABLE(addhip_head_backward, v, w, H, ld, K, rows, dZ, dZ16, planes16, dW_head, db_head, db_top, amax);
+  ADDHIP_RECORDABLE(addhip_head_backward, v, w, H, ld, K, rows, dZ, dZ16, planes16, dW_head, db_head, db_top, amax, ordered_scratch);
   const int grid = row_grid(rows) < 256 ? row_grid(rows) : 256;
-  hipLaunchKernelGGL(head_backward_kernel, dim3(grid), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, dZ, dZ16, planes16, dW_head, db_head, db_top, amax);
+  hipLaunchKernelGGL(head_backward_kernel, dim3(grid), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, dZ, dZ16, planes16, dW_head, db_head, db_top, amax,
+                     ordered_scratch);
+  if (ordered_scratch) hipLaunchKernelGGL(head_backward_combine_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, ST, ordered_scratch, grid, K, dW_head, db_head, db_top);
   return addhip::check_launch("head_backward_kernel");
 }
 

@@ -89,6 +89,13 @@ void set_mask(addhip_gemm_t& g, const addhip_mlp_t& net, int layer, int64_t r0, 
   }
 }
 
+// column sums behind a gradient: by float atomics, or (net.deterministic) in a fixed order through the net's scratch
+int col_sum(const addhip_mlp_t& net, const float* X, int M, int N, int ld, float* out, float scale, int accumulate, void* stream) {
+  if (net.deterministic) return addhip_col_sum_ordered(X, M, N, ld, out, scale, accumulate, net.ordered_scratch, stream);
+  return addhip_col_sum(X, M, N, ld, out, scale, accumulate, stream);
+}
+float* ordered_of(const addhip_mlp_t& net) { return net.deterministic ? net.ordered_scratch : nullptr; }
+
 int check_net(const addhip_mlp_t* net, int64_t rows, const char* who) {
   ADDHIP_REQUIRE(net, "%s: null net", who);
   ADDHIP_REQUIRE(net->num_hidden >= 1 && net->num_hidden <= ADDHIP_MLP_MAX_HIDDEN, "%s: 1..%d hidden layers", who, ADDHIP_MLP_MAX_HIDDEN);
@@ -102,6 +109,10 @@ int check_net(const addhip_mlp_t* net, int64_t rows, const char* who) {
     else ADDHIP_REQUIRE(net->h[i] && net->dz[i], "%s: layer %d lacks its fp32 buffers", who, i);
   }
   ADDHIP_REQUIRE(!storage16(*net) || net->h[net->num_hidden - 1], "%s: the last hidden layer is kept in fp32 too (loss heads)", who);
+  if (net->deterministic)
+    ADDHIP_REQUIRE(net->ordered_scratch && (!net->slabs || (net->bias_replicas && (int64_t)net->bias_replica_rows * 32 >= rows)),
+                   "%s: deterministic reductions need ordered_scratch and one bias replica row per 32-row block (%d rows hold %lld)", who,
+                   net->bias_replica_rows, (long long)rows);
   return 0;
 }
 
@@ -206,7 +217,7 @@ int backward(const addhip_mlp_t& net, const float* x, const uint16_t* x16, int64
     if (marks) marks->dw_last[i] = launches - base;
     if (i == n - 1 && !(flags & ADDHIP_BWD_TOP_BIAS_DONE)) {
       ADDHIP_REQUIRE(net.dz[i], "mlp_backward: the top bias gradient is summed from the fp32 dz[last]");
-      LAUNCH(addhip_col_sum(net.dz[i], (int)rows, out_d, out_d, net.gb[i], 1.0f, zeroed ? 1 : 0, stream));
+      LAUNCH(col_sum(net, net.dz[i], (int)rows, out_d, out_d, net.gb[i], 1.0f, zeroed ? 1 : 0, stream));
     }
     // every gradient of this net except W[0] / b[0] is final here (b[1] came with the dX GEMM of layer 2 -- or, for a two-layer net
     // whose caller left the top bias to this pass, with the column sum just above; the head's with the loss kernels): an early bucket
@@ -307,9 +318,11 @@ static int ppo_loss_impl(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, 
     LAUNCH(addhip_gemm_f32(&g, stream));
   }
   LAUNCH(addhip_slab_reduce(A.slabs, 32, 32LL * hA, A.gWh, 32LL * hA, 1.0f, 0, stream));
-  LAUNCH(addhip_col_sum(d->d_mean, Mb, 32, 32, A.gbh, 1.0f, 1, stream));
+  LAUNCH(col_sum(A, d->d_mean, Mb, 32, 32, A.gbh, 1.0f, 1, stream));
+  // (plane storage: an fp32-operand GEMM cannot write planes -- it leaves the fp32 dz and the backward pass splits it first)
+  const bool planes = store_fmt(A) == ADDHIP_STORE_BF16X3;
   {  // dz[last] = (d_mean Wh) * relu'(h[last]); bf16 storage: written as bf16 directly
-    addhip_gemm_t g = gemm(Mb, hA, 32, d->d_mean, 32, 1, A.Wh, hA, 0, s16 ? nullptr : A.dz[nA - 1], hA, ADDHIP_EPI_MASK);
+    addhip_gemm_t g = gemm(Mb, hA, 32, d->d_mean, 32, 1, A.Wh, hA, 0, s16 && !planes ? nullptr : A.dz[nA - 1], hA, ADDHIP_EPI_MASK);
     g.colsum = A.gb[nA - 1];
     if (top_reps) {  // spread over the replica rows like the dX GEMMs' sums; the top layer's combine folds them into gb[last]
       g.colsum = A.bias_replicas;
@@ -317,24 +330,25 @@ static int ppo_loss_impl(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, 
       g.ldcs = hA;
     }
     g.precision = d->head_precision;
-    if (s16) {
+    if (s16 && !planes) {
       g.C16 = A.dz16[nA - 1];
       g.ldc16 = hA;
-      g.c16_planes = store_fmt(A);
     }
     set_mask(g, A, nA - 1, 0, Mb, true);
     g.amax_out = amax_of(A, AMAX_DZ + nA - 1);  // (d_mean's own maximum is not tracked: this launch runs the exact bf16 split or the fp32 MFMA)
     LAUNCH(addhip_gemm_f32(&g, stream));
   }
   int at = launches;
-  if (int rc = backward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, bwd | (top_reps ? ADDHIP_BWD_TOP_BIAS_REPLICAS : 0), &mk, launches, stream, d->norm_obs_amax)) return rc;
+  if (int rc = backward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, (planes ? bwd & ~ADDHIP_BWD_TOP_CAST_DONE : bwd) | (top_reps ? ADDHIP_BWD_TOP_BIAS_REPLICAS : 0), &mk,
+                        launches, stream, d->norm_obs_amax))
+    return rc;
   const int actor_early = at + mk.early, actor_end = launches;
   // ---- critic (ppo_agent.py:234-245, base_agent.py:522-546)
   if (int rc = forward(Cn, d->norm_obs, d->norm_obs16, Mb, nullptr, nullptr, true, launches, stream, d->norm_obs_amax)) return rc;
   if (int rc = refresh_transposed(Cn, launches, stream)) return rc;
   LAUNCH(addhip_critic_head(Cn.h[nC - 1], hC, hC, Mb, Cn.Wh, Cn.bh, d->tar_val, d->critic_loss_weight * d->grad_scale, nullptr, d->dv, d->stats + 8, stream));
   LAUNCH(addhip_head_backward(d->dv, Cn.Wh, Cn.h[nC - 1], hC, hC, Mb, s16 ? nullptr : Cn.dz[nC - 1], s16 ? Cn.dz16[nC - 1] : nullptr, store_fmt(Cn), Cn.gWh,
-                              Cn.gbh, Cn.gb[nC - 1], amax_of(Cn, AMAX_DZ + nC - 1), stream));
+                              Cn.gbh, Cn.gb[nC - 1], amax_of(Cn, AMAX_DZ + nC - 1), ordered_of(Cn), stream));
   at = launches;
   if (int rc = backward(Cn, d->norm_obs, d->norm_obs16, Mb, nullptr, bwd, &mk, launches, stream, d->norm_obs_amax)) return rc;
   if (marks) *marks = addhip_ppo_marks_t{launches, actor_end, actor_early, at + mk.early};
@@ -366,7 +380,7 @@ static int disc_loss_impl(const addhip_disc_loss_t* d, addhip_disc_marks_t* mark
   const int m_head = launches;
   // logit loss on Mb agent rows (negative) and the demo... rows of h[last]: row Mb = the zero-difference sample (positive)
   LAUNCH(addhip_disc_head(D.h[1], d2, d2, Mb, D.h[1] + (size_t)Mb * d2, D.Wh, D.bh, ls, d->dlogit, d->dlogit + Mb, d->stats + 12, stream));
-  LAUNCH(addhip_head_backward(d->dlogit, D.Wh, D.h[1], d2, d2, Md, s16 ? nullptr : D.dz[1], s16 ? D.dz16[1] : nullptr, store_fmt(D), D.gWh, D.gbh, D.gb[1], amax_of(D, AMAX_DZ + 1), stream));
+  LAUNCH(addhip_head_backward(d->dlogit, D.Wh, D.h[1], d2, d2, Md, s16 ? nullptr : D.dz[1], s16 ? D.dz16[1] : nullptr, store_fmt(D), D.gWh, D.gbh, D.gb[1], amax_of(D, AMAX_DZ + 1), ordered_of(D), stream));
   const int m_chain = launches;
   // gradient penalty (hand-derived double backward of add_agent.py:166-178):  g = ((w3 * m2) W2 * m1) W1 ;  penalty = mean |g|^2 ;
   // second-order terms  G = d penalty / d g ;  e1 = (G W1^T) * m1 ;  da2 = (e1 W2^T) * m2
@@ -400,7 +414,7 @@ static int disc_loss_impl(const addhip_disc_loss_t* d, addhip_disc_marks_t* mark
     extra[0] = {d->a1, d1, d->G, DS, Mb, amax_of(D, AMAX_A1), amax_of(D, AMAX_G)};
     extra[1] = {d->a2, d2, d->e1, d1, Mb, amax_of(D, AMAX_A2), amax_of(D, AMAX_E1)};
   }
-  LAUNCH(addhip_col_sum(d->da2, Mb, d2, d2, D.gWh, 1.0f, 1, stream));
+  LAUNCH(col_sum(D, d->da2, Mb, d2, d2, D.gWh, 1.0f, 1, stream));
   const int m_bwd = launches;
   addhip_mlp_marks_t mk;
   if (int rc = backward(D, d->norm_diff, d->norm_diff16, Md, extra,

@@ -168,6 +168,9 @@ class ADDAgent(AgentIO):
             self._model.enable_shadow(self._storage16)
         # "f16x2": fp32 operands split on the fly into two fp16 planes on per-tensor power-of-two scales (csrc/gemm_split.hip, ADDHIP_PREC_F16X2);
         # the scales come from maxima the producers track on the device (activations / gradients: NetRunner.amax; parameters: Model.w_amax)
+        # agent.deterministic: every reduction behind a gradient in a fixed order (no float atomics): two runs from the same state give
+        # bit-identical gradients and parameters, as the reference's CPU path does under a seed (mp_optimizer.py:14-23)
+        self._deterministic = bool(cfg.get("deterministic", False))
         self._f16x2 = self._prec == L.PREC_F16X2
         if self._f16x2:
             self._model.enable_w_amax()
@@ -242,9 +245,10 @@ class ADDAgent(AgentIO):
         self._slabs_all = z(4, need)  # [3]: the discriminator's top-layer weight gradient, which runs beside the rest of its backward pass
         self._slabs = self._slabs_all[0]
         s16 = self._storage16
-        self._run_actor = NetRunner(m, m.actor, Mb + 1 if s16 else rows, dev, self._slabs_all[0], self._prec, s16)
-        self._run_critic = NetRunner(m, m.critic, Mb + 1 if s16 else rows, dev, self._slabs_all[1], self._prec, s16)
-        self._run_disc = NetRunner(m, m.disc, Mb + 1 if s16 else rows, dev, self._slabs_all[2], self._prec, s16)
+        det = self._deterministic
+        self._run_actor = NetRunner(m, m.actor, Mb + 1 if s16 else rows, dev, self._slabs_all[0], self._prec, s16, det)
+        self._run_critic = NetRunner(m, m.critic, Mb + 1 if s16 else rows, dev, self._slabs_all[1], self._prec, s16, det)
+        self._run_disc = NetRunner(m, m.disc, Mb + 1 if s16 else rows, dev, self._slabs_all[2], self._prec, s16, det)
         self._run_disc.aux_slabs = (len(m.disc.hidden) - 1, self._slabs_all[3])
         # rollout / evaluation passes: the same runners, except in bf16-storage mode (fp32 operands, bf16x2 products)
         if s16:

@@ -361,7 +361,7 @@ class NetRunner:
     """One Mlp's activation / gradient workspace for up to `rows` rows, as the addhip_mlp_t the library's composite entry points take
     (addhip_mlp_forward / _backward, addhip_ppo_loss_fwd_bwd, addhip_disc_loss_fwd_bwd: csrc/learner.hip assembles the launches)."""
 
-    def __init__(self, model, net, rows, device, slabs, precision=L.PREC_F32, storage16=0):
+    def __init__(self, model, net, rows, device, slabs, precision=L.PREC_F32, storage16=0, deterministic=False):
         self.m, self.net, self.rows, self.slabs = model, net, rows, slabs
         self.precision = precision  # ADDHIP_PREC_* of every GEMM this runner records (agent.matmul_precision)
         # storage16 (agent.matmul_precision = bf16): hidden activations and pre-activation gradients are kept as bf16 in HBM and
@@ -381,7 +381,12 @@ class NetRunner:
         self.dz = [torch.zeros(rows, h, device=device) for h in net.hidden]
         # bias-gradient column sums of the dX GEMMs, spread over 16 rows (same-line float atomics of all row tiles serialise otherwise);
         # summed into the gradient and cleared by the split-K combine that follows (addhip_slab_reduce_pair)
-        self.bias_rep = torch.zeros(16, max(net.hidden), device=device) if slabs is not None else None
+        # agent.deterministic: one replica row per 32-row block instead (every slot then receives ONE add, and the combine sums the rows in
+        # order) and a scratch for the fixed-order column sums of the loss heads -- no float atomics behind any gradient
+        self.deterministic = bool(deterministic)
+        rep_rows = (rows + 31) // 32 if self.deterministic else 16
+        self.bias_rep = torch.zeros(rep_rows, max(net.hidden), device=device) if slabs is not None else None
+        self.ordered = torch.zeros(L.HEAD_BWD_BLOCKS * (2 * max(net.hidden) + 4), device=device) if self.deterministic else None
         # agent.matmul_precision = f16x2: the tracked maxima of this runner's activations / gradients (include/addhip.h: ADDHIP_MLP_AMAX_*)
         self.amax = torch.zeros(L.MLP_AMAX_TENSORS * L.AMAX_SLOTS, dtype=torch.int32, device=device) if precision == L.PREC_F16X2 else None
 
@@ -410,6 +415,8 @@ class NetRunner:
             c.bias_replicas, c.bias_replica_rows = L.ptr(self.bias_rep), self.bias_rep.shape[0]
         if self.amax is not None:
             c.amax, c.w_amax = L.ptr(self.amax), L.ptr(m.w_amax)
+        if self.deterministic:
+            c.deterministic, c.ordered_scratch = 1, L.ptr(self.ordered)
         if self.storage16:
             offs, rows, cols, cnt = m._net_tables[net.name]
             c.flat_params, c.flat_trans16, c.flat_count = L.ptr(m.params), L.ptr(m.params16t), m.count

@@ -99,10 +99,11 @@ def gemm_roofline(agent, precision, with_traffic=True):
         peak, kern = MFMA_F32_PEAK_TFLOPS, "gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all GEMM launches of one optimiser step)"
         tr, tr_src = traffic("gemm_fp32_step") if with_traffic else (None, None)
     else:
-        products = {"bf16x3": 6, "bf16x2": 3, "bf16": 1}[precision]
-        peak = MFMA_BF16_PEAK_TFLOPS / products
-        kern = ("gemm_bf16_kernel (bf16 operands in HBM, " if precision == "bf16" else "gemm_split_kernel (") + \
-               "v_mfma_f32_32x32x16_bf16 x %d per k-step; small shapes stay on gemm_kernel); all GEMM launches of one optimiser step" % products
+        products = {"bf16x3": 6, "bf16x3_planes": 6, "f16x2": 4, "bf16x2": 3, "bf16": 1}[precision]
+        peak = MFMA_BF16_PEAK_TFLOPS / products  # (fp16 MFMAs run at the bf16 rate)
+        kern = {"bf16": "gemm_dma_kernel<bf16> (bf16 operands in HBM, ", "bf16x3_planes": "gemm_x3_kernel (operands stored as three exact bf16 planes, LDS-DMA ring, ",
+                "f16x2": "gemm_split_kernel<f16> (fp32 operands split two ways into fp16 on tracked per-tensor scales, "}.get(precision, "gemm_split_kernel (") + \
+               "v_mfma_f32_32x32x16_%s x %d per k-step; small shapes stay on gemm_kernel); all GEMM launches of one optimiser step" % ("f16" if precision == "f16x2" else "bf16", products)
         tr, tr_src = traffic("gemm_bf16_step") if precision == "bf16" and with_traffic else (None, None)  # (counters were taken at 4096 envs)
     return {"bound": "mfma", "kernel": kern, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": tr, "traffic_source": tr_src,
             "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"],
@@ -309,10 +310,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_agent(precision, engine="kinematic", envs=None, motion="synthetic:1x3600", extra=()):
+    def make_agent(precision, engine="kinematic", envs=None, motion="synthetic:1x3600", extra=(), dist_on=None):
         cfg = load_config("train", [f"engine={engine}", f"engine.num_envs={envs or a.envs}", f"task.motion_file={motion}", f"seed={1 + rank}",
                                     f"agent.matmul_precision={precision}"] + list(extra))
-        ag = ADDAgent(cfg, distributed=distributed)
+        ag = ADDAgent(cfg, distributed=distributed if dist_on is None else dist_on)
         ag.reset_all_envs()
         ag._init_train()
         gc.collect()
@@ -382,6 +383,10 @@ def main():
         del agent
         alts = []
         for prec, what in (("bf16x3", "6 bf16 MFMAs on an exact 3-way split (fp32-level error)"),
+                           ("f16x2", "4 fp16 MFMAs on a two-way fp16 split (22 bits + sign per operand) scaled by exact per-tensor powers of two from "
+                                     "device-tracked maxima: fp32-class error, 2^-21 |a||b| per product"),
+                           ("bf16x3_planes", "6 bf16 MFMAs on operands STORED as three exact bf16 planes (update step: csrc/gemm_x3.hip, LDS-DMA ring; "
+                                             "the error of bf16x3)"),
                            ("bf16x2", "3 bf16 MFMAs on the two leading chunks (16 significant bits per operand; TF32-class, 64x less error than TF32)"),
                            ("bf16", "bf16 STORAGE: activations, gradients and a weight shadow kept as bf16 in HBM (update step), 1 bf16 MFMA per k-step, "
                                     "fp32 accumulate and master weights; rollout / evaluation passes on bf16x2")):
@@ -415,6 +420,37 @@ def main():
                                  "value": agent4.T * agent4.N * world * a.steps / dt4, "unit": "env-steps/s", "ms_per_step": 1000.0 * dt4 / a.steps,
                                  "minibatch_rows": agent4.Mb, "roofline": gemm_roofline(agent4, "bf16", with_traffic=False)}
         del agent4
+    if world == 1 and not distributed and not a.no_alt:
+        # N > 1 pre-flight that one GPU can give: the SAME workload with the exchange machinery on -- a 1-rank RCCL group, so every optimiser
+        # step issues its four asynchronous gradient buckets from the schedule's call-backs on their streams, the normaliser statistics and
+        # the logged scalars are all-reduced -- next to the plain run above.  The collectives are identities; what is measured is their issue
+        # and synchronisation cost on the path an N-rank job takes.
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            dist.init_process_group(backend=launch.backend())
+            agent5 = make_agent(a.precision, dist_on=True)
+            for _ in range(a.warmup):
+                agent5._train_iter()
+                agent5._iter += 1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                agent5._train_iter()
+                agent5._iter += 1
+            torch.cuda.synchronize()
+            dt5 = time.perf_counter() - t0
+            br = agent5._model.bucket_ranges
+            out["dist_overhead_1rank"] = {"backend": dist.get_backend(), "ms_per_step": 1000.0 * dt5 / a.steps, "plain_ms_per_step": out["ms_per_step"],
+                                          "vs_plain": (dt5 / a.steps) / (dt / a.steps), "optimiser_steps_per_iter": agent5._update_epochs * ((agent5.T * agent5.N + agent5.Mb - 1) // agent5.Mb),
+                                          "buckets_per_optimiser_step": [{"bucket": k, "bytes": 4 * (v[1] - v[0])} for k, v in br.items()],
+                                          "note": "1-rank RCCL group: collectives are identities; the figure is the cost of issuing / joining them on the N-rank code path"}
+            del agent5
+            dist.destroy_process_group()
+        except Exception as e:  # (never let the pre-flight take the headline line down)
+            out["dist_overhead_1rank"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # last: the oracle's 16 torch-CPU threads keep spinning after their parallel regions, and the launch-bound GPU runs above
         # (the bf16 modes enqueue ~90 kernels per 1.1 ms optimiser step) slow down when they share the host cores with them

@@ -350,6 +350,10 @@ int addhip_slab_reduce_pair(const float* in, int32_t slabs, int64_t slab_stride,
 /* out[n] (+)= scale * sum_m X[m*ld+n]   (bias gradients) */
 int addhip_col_sum(const float* X, int32_t M, int32_t N, int32_t ld, float* out, float scale,
                    int32_t accumulate, void* stream);
+/* The same with a FIXED summation order (no float atomics: the result is bit-identical from run to run): ADDHIP_ORDERED_BLOCKS row slices
+ * are summed into scratch[slice][n] (scratch: >= ADDHIP_ORDERED_BLOCKS * N floats), then added slice by slice.  Two launches. */
+#define ADDHIP_ORDERED_BLOCKS 64
+int addhip_col_sum_ordered(const float* X, int32_t M, int32_t N, int32_t ld, float* out, float scale, int32_t accumulate, float* scratch, void* stream);
 
 /* ---- rollout actor head: DistributionGaussianDiag.sample/log_prob (distribution_gaussian_diag.py:84-94)
  *      + Normalizer.unnormalize (normalizer.py:112-114) + exp-buffer record (ppo_agent.py:72-109).
@@ -457,7 +461,11 @@ int addhip_disc_head(const float* H, int32_t ld, int32_t K, int32_t M, const flo
  * dZ16 (optional): the same dZ rounded to bf16 (nearest even), what the bf16-storage backward GEMMs read. */
 int addhip_head_backward(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows,
                          float* dZ, uint16_t* dZ16, int32_t planes16 /* ADDHIP_STORE_* format of dZ16 */, float* dW_head, float* db_head, float* db_top,
-                         uint32_t* amax /* optional: max |dZ| into ADDHIP_AMAX_SLOTS slots (caller zeroes) */, void* stream);
+                         uint32_t* amax /* optional: max |dZ| into ADDHIP_AMAX_SLOTS slots (caller zeroes) */,
+                         float* ordered_scratch /* optional: >= ADDHIP_HEAD_BWD_BLOCKS * (2 K + 4) floats; the three sums are then formed in a
+                         fixed order (per-workgroup partials, added workgroup by workgroup by a second launch) instead of by float atomics:
+                         bit-identical from run to run */, void* stream);
+#define ADDHIP_HEAD_BWD_BLOCKS 256
 
 /* out[m,k] = v[m] * w[k] * (H[m,k] > 0)    (back through a 1-wide head into the last hidden layer) */
 int addhip_outer_mask(const float* v, const float* w, const float* H, int32_t ld, int32_t K, int64_t rows,
@@ -603,6 +611,12 @@ typedef struct {
    * slots bounding every weight the net reads (e.g. addhip_amax_f32 over the flat parameter buffer after each optimiser step).  Either
    * NULL: the net's GEMMs run as ADDHIP_PREC_BF16X3. */
   uint32_t* amax; const uint32_t* w_amax;
+  /* deterministic != 0: every reduction behind this net's gradients runs in a fixed order (agent.deterministic) -- the reference's CPU
+   * path is reproducible under a seed (learning/mp_optimizer.py:14-23 on torch-CPU).  Needs bias_replica_rows >= ceil(rows_cap / 32) (each
+   * 32-row block of a dX GEMM then owns its replica row: one add per slot, summed in row order by the combine) and ordered_scratch:
+   * >= ADDHIP_HEAD_BWD_BLOCKS * (2 * max(hidden) + 4) floats (addhip_head_backward, addhip_col_sum_ordered).  Loss diagnostics (stats) are
+   * still accumulated by atomics: logged scalars may differ in their last bits, gradients and parameters do not. */
+  int32_t deterministic; float* ordered_scratch;
 } addhip_mlp_t;
 enum { ADDHIP_MLP_AMAX_H = 0, ADDHIP_MLP_AMAX_DZ = 4, ADDHIP_MLP_AMAX_A2 = 8, ADDHIP_MLP_AMAX_A1 = 9, ADDHIP_MLP_AMAX_G = 10, ADDHIP_MLP_AMAX_E1 = 11,
        ADDHIP_MLP_AMAX_TENSORS = 12 };

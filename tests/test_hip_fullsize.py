@@ -343,3 +343,35 @@ def test_bf16_storage_mode_tracks_fp32_training():
             assert np.isfinite(y) and abs(x - y) <= 0.10 * max(abs(x), abs(y)) + 2e-3, (it, k, x, y)
     for k, v in a[2].items():  # 240 optimiser steps at lr 1e-4: nobody moved further than 0.024 from the start
         assert float((v - b[2][k]).abs().max()) <= 3e-2, k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_deterministic_update_step_repeats_bit_for_bit(precision):
+    """agent.deterministic: the 16 384-row update step (all three nets on their streams) run twice from the same buffers gives bit-identical
+    gradients -- all 22 tensors, padding included -- where the default (float atomics behind bias gradients and loss-head sums) differs in
+    the last bits from run to run; and the deterministic gradients are the default ones to fp32 accuracy."""
+    import torch
+    import add_gym_amd.learning.add_agent as A
+
+    grads = {}
+    for det in (True, False):
+        cfg = make_cfg(4096, steps_per_iter=32, matmul_precision=precision)
+        cfg["task"]["motion_file"] = "synthetic:1x300"
+        cfg["agent"]["deterministic"] = det
+        ag = A.ADDAgent(cfg)
+        assert ag._deterministic == det and ag.Mb == 16384
+        params = OL.synth_params(11)
+        ag._model.load({k: torch.tensor(v) for k, v in params.items()})
+        _fill_minibatch(ag, OL.Model(params), 5)
+        runs = []
+        for _ in range(3 if det else 1):
+            ag._W["stats"].zero_()
+            ag._run_update_sections()
+            torch.cuda.synchronize()
+            runs.append(ag._model.grads.clone())
+        grads[det] = runs
+        del ag
+    assert torch.equal(grads[True][0], grads[True][1]) and torch.equal(grads[True][0], grads[True][2])
+    assert float(grads[True][0].abs().max()) > 0.0
+    d = (grads[True][0] - grads[False][0]).abs().max() / grads[False][0].abs().max()
+    assert float(d) < (2e-2 if precision == "bf16" else 1e-4), float(d)

@@ -331,14 +331,14 @@ def test_critic_and_disc_heads_and_grad_penalty():
     out2 = torch.full((M + 1, K), 7.0, device="cuda")
     gW, gb, gt_ = torch.full((K,), 0.25, device="cuda"), torch.full((1,), 0.25, device="cuda"), torch.full((K,), 0.25, device="cuda")
     out16 = torch.full((M + 1, K), 7.0, device="cuda", dtype=torch.bfloat16)
-    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, L.ptr(out2), L.ptr(out16), L.STORE_BF16, L.ptr(gW), L.ptr(gb), L.ptr(gt_), None, L.current_stream())
+    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, L.ptr(out2), L.ptr(out16), L.STORE_BF16, L.ptr(gW), L.ptr(gb), L.ptr(gt_), None, None, L.current_stream())
     torch.cuda.synchronize()
     assert torch.equal(out2, out) and torch.equal(out16, out.to(torch.bfloat16))  # the optional bf16 copy: the same values, rounded to nearest even
     dl64, H64, o64 = dl.cpu().numpy().astype(np.float64), H.astype(np.float64), out.cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(gW.cpu().numpy() - 0.25, dl64 @ H64, rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(gb.cpu().numpy() - 0.25, dl64.sum(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(gt_.cpu().numpy() - 0.25, o64.sum(0), rtol=1e-4, atol=1e-6)
-    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, None, None, 0, None, None, None, None, L.current_stream())  # every output optional
+    L.call("addhip_head_backward", L.ptr(dl), L.ptr(dw), L.ptr(dH), K, K, M + 1, None, None, 0, None, None, None, None, None, L.current_stream())  # every output optional
     # a2 of the gradient-penalty chain: fp32 and / or bf16
     a2, a2_16 = torch.zeros(M, K, device="cuda"), torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
     L.call("addhip_bcast_mask", L.ptr(dw), L.ptr(dH), K, K, M, L.ptr(a2), L.ptr(a2_16), L.STORE_BF16, None, L.current_stream())
@@ -576,7 +576,7 @@ def test_plane_storage_outputs_of_the_producers():
     H = T(np.maximum(rng.standard_normal((M, K)), 0).astype(F))
     w, v = T((rng.standard_normal(K) * 0.1).astype(F)), T((rng.standard_normal(M) * 1e-3).astype(F))
     dZ, dZ16 = z(M, K), i16(M, K)
-    L.call("addhip_head_backward", L.ptr(v), L.ptr(w), L.ptr(H), K, K, M, L.ptr(dZ), L.ptr(dZ16), X3, None, None, None, L.ptr(am[2]), L.current_stream())
+    L.call("addhip_head_backward", L.ptr(v), L.ptr(w), L.ptr(H), K, K, M, L.ptr(dZ), L.ptr(dZ16), X3, None, None, None, L.ptr(am[2]), None, L.current_stream())
     a2, a2_16 = z(M, K), i16(M, K)
     L.call("addhip_bcast_mask", L.ptr(w), L.ptr(H), K, K, M, L.ptr(a2), L.ptr(a2_16), X3, L.ptr(am[3]), L.current_stream())
     gsrc = np.zeros((M, 128), F)
@@ -598,3 +598,41 @@ def test_plane_storage_outputs_of_the_producers():
     L.call("addhip_optimizer_step", oc, L.current_stream())
     torch.cuda.synchronize()
     assert np.array_equal(pl(p16), to_planes(p.cpu().numpy().reshape(1, -1)).reshape(-1)) and float(gr.abs().max()) == 0.0
+
+
+def test_fixed_order_reductions_repeat_bit_for_bit():
+    """addhip_col_sum_ordered and addhip_head_backward with its ordered scratch (agent.deterministic): the same sums as the atomics forms to
+    fp32 accuracy, and bit-identical from launch to launch."""
+    import torch
+    import add_gym_amd._lib as L
+
+    rng = np.random.RandomState(21)
+    M, K = 16385, 512
+    X = T((rng.standard_normal((M, K)) * 10.0 ** rng.uniform(-3, 3, (M, 1))).astype(F))
+    scratch = torch.zeros(L.HEAD_BWD_BLOCKS * (2 * K + 4), device="cuda")
+    outs = []
+    for _ in range(3):
+        o = torch.full((K,), 0.5, device="cuda")
+        L.call("addhip_col_sum_ordered", L.ptr(X), M, K, K, L.ptr(o), 2.0, 1, L.ptr(scratch), L.current_stream())
+        outs.append(o)
+    ref = torch.full((K,), 0.5, device="cuda")
+    L.call("addhip_col_sum", L.ptr(X), M, K, K, L.ptr(ref), 2.0, 1, L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    x64 = X.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(outs[0].cpu().numpy(), 0.5 + 2.0 * x64.sum(0), rtol=1e-5, atol=1e-3 * np.abs(x64).sum(0).max() * 1e-4)
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-2)
+    H = T(np.maximum(rng.standard_normal((M, K)), 0).astype(F))
+    w, v = T((rng.standard_normal(K) * 0.1).astype(F)), T(rng.standard_normal(M).astype(F))
+    res = []
+    for ordered in (scratch, scratch, None):
+        gW, gb, gt_ = torch.full((K,), 0.25, device="cuda"), torch.full((1,), 0.25, device="cuda"), torch.full((K,), 0.25, device="cuda")
+        dZ = torch.zeros(M, K, device="cuda")
+        L.call("addhip_head_backward", L.ptr(v), L.ptr(w), L.ptr(H), K, K, M, L.ptr(dZ), None, 0, L.ptr(gW), L.ptr(gb), L.ptr(gt_), None,
+               None if ordered is None else L.ptr(ordered), L.current_stream())
+        res.append((gW, gb, gt_, dZ))
+    torch.cuda.synchronize()
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0], res[2]):  # the atomics form: the same sums in another order
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-3)

@@ -157,8 +157,9 @@ def test_mlp_forward_backward_launch_directly_and_match_torch():
     for i in range(2):
         assert torch.allclose(gW[i], Wt[i].grad, atol=2e-3, rtol=1e-3), i
         assert torch.allclose(gb[i], bt[i].grad, atol=2e-3, rtol=1e-3), i
-    # layer 1: dW GEMM + combine, top bias column sum, zero of gb[0], dX GEMM; layer 0: dW GEMM + combine
-    assert marks.launches == 7 and (marks.dw_first[1], marks.dw_last[1], marks.early) == (0, 2, 2) and (marks.dw_first[0], marks.dw_last[0]) == (5, 7)
+    # layer 1: dW GEMM + combine, top bias column sum, zero of gb[0], dX GEMM; layer 0: dW GEMM + combine.  `early` (every gradient but
+    # W[0] / b[0] is final) lies behind the column sum that writes gb[1]
+    assert marks.launches == 7 and (marks.dw_first[1], marks.dw_last[1], marks.early) == (0, 2, 3) and (marks.dw_first[0], marks.dw_last[0]) == (5, 7)
     # rows beyond the workspace are refused
     assert L.load().addhip_mlp_forward(C.byref(c), L.ptr(x), None, rows + 1, None, None, 0, None, st) != 0
 
