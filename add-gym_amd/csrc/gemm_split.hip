@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
     stash_part(std::false_type{}, 3, kt + 1, a_next, b_next);
     if (PLANES >= 2) {
       // pin the interleave: the split's VALU work spread evenly over the MFMAs, a DS write after every second (third) one
+      // (F16: 4 / 6 / 8 vector instructions per MFMA and no pinning at all time within 1 % of each other: profiles/r04_split_pmc.json)
       constexpr int NM = F16 ? 16 : PLANES == 3 ? 24 : 12, PER = F16 ? 6 : PLANES == 3 ? 5 : 8;
 #pragma unroll
       for (int i = 0; i < NM; ++i) {
