@@ -132,6 +132,13 @@ class DiscLossT(C.Structure):
                 ("G", f32p), ("e1", f32p), ("da2", f32p), ("a2_16", f32p), ("a1_16", f32p), ("G16", f32p), ("e1_16", f32p), ("stats", f32p)]
 
 
+class ActorHeadT(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("hidden", C.c_int32), ("H", f32p), ("Wh", f32p), ("bh", f32p), ("norm_action", f32p), ("old_logp", f32p), ("adv", f32p),
+                ("rand_mask", f32p), ("n_valid", f32p), ("action_std", C.c_float), ("logp_const", C.c_float), ("clip_ratio", C.c_float),
+                ("bound_weight", C.c_float), ("reg_weight", C.c_float), ("loss_scale", C.c_float), ("dz", f32p), ("dz16", f32p), ("planes16", C.c_int32),
+                ("slabs", f32p), ("num_slabs", C.c_int32), ("gb_top", f32p), ("gb_replicas", C.c_int32), ("ld_gb", C.c_int32), ("stats", f32p), ("amax", f32p)]
+
+
 class DiscMarksT(C.Structure):
     _fields_ = [("launches", C.c_int32), ("head", C.c_int32), ("chain", C.c_int32), ("backward", C.c_int32), ("top_dw_first", C.c_int32), ("top_dw_last", C.c_int32)]
 
@@ -188,6 +195,8 @@ SIGNATURES = {
     "addhip_gather_minibatch": [P(GatherT), vp],
     "addhip_actor_loss": [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
     "addhip_count_mask": [vp, i32, vp, vp],
+    "addhip_actor_head_slabs": [i32],     # returns the slab count
+    "addhip_actor_head": [P(ActorHeadT), vp],
     "addhip_critic_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
     "addhip_disc_head": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
     "addhip_head_backward": [vp, vp, vp, i32, i32, i64, vp, vp, i32, vp, vp, vp, vp, vp, vp],
@@ -241,7 +250,7 @@ def load():
     lib.addhip_version.restype = C.c_int
     lib.addhip_abi_sizes.argtypes, lib.addhip_abi_sizes.restype = [C.POINTER(C.c_int32), C.c_int32], C.c_int
     structs = (MotionT, TaskT, EnvT, StepOutT, SamplerT, GemmT, GatherT, RigidModelT, RigidDrT, OptimizerT, SectionT, MlpT, ExtraDwT, MlpMarksT, PpoLossT,
-               PpoMarksT, DiscLossT, DiscMarksT)
+               PpoMarksT, DiscLossT, DiscMarksT, ActorHeadT)
     sizes = (C.c_int32 * len(structs))()
     mine = [C.sizeof(t) for t in structs]
     if lib.addhip_abi_sizes(sizes, len(structs)) != len(structs) or list(sizes) != mine:

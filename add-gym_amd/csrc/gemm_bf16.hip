@@ -301,6 +301,10 @@ int gemm_bf16_dispatch(const addhip_dma::GemmGroup& grp, int count, hipStream_t 
   const long long t256 = (long long)(g.M / 256) * (g.N / 256);
   const bool eligible = count == 1 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 64 == 0;
   bool big = eligible && t256 * split >= 192 && g.K / split >= 2048;
+  // (round 4, re-measured: alone on the chip and on random operands the forward launches -- both operands k-contiguous, bias + ReLU -- run
+  //  8-13 % faster on the 256x256 tiles (16384x1024x1024: 40.8 vs 45.7 us; 65536 rows: 161 vs 182; profiles/r04_bf16_tile_sweep.log), the dX
+  //  and weight-gradient launches do not; given to the step it was again SLOWER end to end -- 2.58 M vs 2.67 M env-steps/s at 4096 envs,
+  //  3.15 M vs 3.21 M at 16 384 -- for the reason above, so the rule stays as it was)
   if (g.hint & ADDHIP_GEMM_HINT_BIG_TILE) big = eligible;
   if (g.hint & ADDHIP_GEMM_HINT_NO_BIG_TILE) big = false;
   const int BM = big ? 256 : 128, BN = BM;

@@ -303,43 +303,71 @@ static int ppo_loss_impl(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, 
   // ---- actor (ppo_agent.py:194-232, 247-275)
   if (int rc = forward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, nullptr, true, launches, stream, d->norm_obs_amax)) return rc;
   if (int rc = refresh_transposed(A, launches, stream)) return rc;  // beside the other nets' GEMMs (the optimiser step wrote the flat shadow)
-  {
-    addhip_gemm_t g = gemm(Mb, 32, hA, A.h[nA - 1], hA, 1, A.Wh, hA, 1, d->mean, 32, ADDHIP_EPI_BIAS, A.bh);
-    g.precision = d->head_precision;
-    LAUNCH(addhip_gemm_f32(&g, stream));
-  }
-  LAUNCH(addhip_count_mask(d->rand_mask, Mb, d->num_valid, stream));
-  LAUNCH(addhip_actor_loss(d->mean, d->norm_action, d->old_logp, d->adv, d->rand_mask, Mb, d->action_std, d->logp_const, d->ppo_clip_ratio,
-                           d->action_bound_weight, d->action_reg_weight, d->grad_scale, d->num_valid, d->d_mean, d->stats, stream));
-  {  // head weight gradient: d_mean^T h over Mb rows, 32 K slices
-    addhip_gemm_t g = gemm(32, hA, Mb, d->d_mean, 32, 0, A.h[nA - 1], hA, 0, A.slabs, hA);
-    g.split_k = 32;
-    g.precision = d->head_precision;
-    LAUNCH(addhip_gemm_f32(&g, stream));
-  }
-  LAUNCH(addhip_slab_reduce(A.slabs, 32, 32LL * hA, A.gWh, 32LL * hA, 1.0f, 0, stream));
-  LAUNCH(col_sum(A, d->d_mean, Mb, 32, 32, A.gbh, 1.0f, 1, stream));
-  // (plane storage: an fp32-operand GEMM cannot write planes -- it leaves the fp32 dz and the backward pass splits it first)
+  // The head section: one launch (csrc/actor_head.hip: head forward, loss, gradient, backward step into the last hidden layer) where the
+  // last hidden layer is 128 / 256 / 512 wide; the three 32-wide GEMMs + loss + column sums otherwise.
+  const int head_slabs = addhip_actor_head_slabs(Mb);
+  const bool fused = (hA == 128 || hA == 256 || hA == 512) && (int64_t)head_slabs * (32 * hA + 32) <= A.slab_floats;
   const bool planes = store_fmt(A) == ADDHIP_STORE_BF16X3;
-  {  // dz[last] = (d_mean Wh) * relu'(h[last]); bf16 storage: written as bf16 directly
-    addhip_gemm_t g = gemm(Mb, hA, 32, d->d_mean, 32, 1, A.Wh, hA, 0, s16 && !planes ? nullptr : A.dz[nA - 1], hA, ADDHIP_EPI_MASK);
-    g.colsum = A.gb[nA - 1];
-    if (top_reps) {  // spread over the replica rows like the dX GEMMs' sums; the top layer's combine folds them into gb[last]
-      g.colsum = A.bias_replicas;
-      g.colsum_replicas = A.bias_replica_rows;
-      g.ldcs = hA;
+  LAUNCH(addhip_count_mask(d->rand_mask, Mb, d->num_valid, stream));
+  if (fused) {
+    addhip_actor_head_t h;
+    memset(&h, 0, sizeof(h));
+    h.rows = Mb; h.hidden = hA;
+    h.H = A.h[nA - 1]; h.Wh = A.Wh; h.bh = A.bh;
+    h.norm_action = d->norm_action; h.old_logp = d->old_logp; h.adv = d->adv; h.rand_mask = d->rand_mask; h.n_valid = d->num_valid;
+    h.action_std = d->action_std; h.logp_const = d->logp_const; h.clip_ratio = d->ppo_clip_ratio; h.bound_weight = d->action_bound_weight;
+    h.reg_weight = d->action_reg_weight; h.loss_scale = d->grad_scale;
+    h.dz = s16 ? nullptr : A.dz[nA - 1]; h.dz16 = s16 ? A.dz16[nA - 1] : nullptr; h.planes16 = store_fmt(A);
+    h.slabs = A.slabs; h.num_slabs = head_slabs;
+    h.gb_top = top_reps ? A.bias_replicas : A.gb[nA - 1]; h.gb_replicas = top_reps ? A.bias_replica_rows : 1; h.ld_gb = hA;
+    h.stats = d->stats;
+    h.amax = amax_of(A, AMAX_DZ + nA - 1);
+    LAUNCH(addhip_actor_head(&h, stream));
+    const int64_t stride = 32LL * hA + 32;
+    if (A.gbh == A.gWh + 32LL * hA) {  // (the flat layout places a head's bias behind its weight)
+      LAUNCH(addhip_slab_reduce(A.slabs, head_slabs, stride, A.gWh, stride, 1.0f, 0, stream));
+    } else {
+      LAUNCH(addhip_slab_reduce(A.slabs, head_slabs, stride, A.gWh, 32LL * hA, 1.0f, 0, stream));
+      LAUNCH(addhip_slab_reduce(A.slabs + 32LL * hA, head_slabs, stride, A.gbh, 32, 1.0f, 0, stream));
     }
-    g.precision = d->head_precision;
-    if (s16 && !planes) {
-      g.C16 = A.dz16[nA - 1];
-      g.ldc16 = hA;
+  } else {
+    {
+      addhip_gemm_t g = gemm(Mb, 32, hA, A.h[nA - 1], hA, 1, A.Wh, hA, 1, d->mean, 32, ADDHIP_EPI_BIAS, A.bh);
+      g.precision = d->head_precision;
+      LAUNCH(addhip_gemm_f32(&g, stream));
     }
-    set_mask(g, A, nA - 1, 0, Mb, true);
-    g.amax_out = amax_of(A, AMAX_DZ + nA - 1);  // (d_mean's own maximum is not tracked: this launch runs the exact bf16 split or the fp32 MFMA)
-    LAUNCH(addhip_gemm_f32(&g, stream));
+    LAUNCH(addhip_actor_loss(d->mean, d->norm_action, d->old_logp, d->adv, d->rand_mask, Mb, d->action_std, d->logp_const, d->ppo_clip_ratio,
+                             d->action_bound_weight, d->action_reg_weight, d->grad_scale, d->num_valid, d->d_mean, d->stats, stream));
+    {  // head weight gradient: d_mean^T h over Mb rows, 32 K slices
+      addhip_gemm_t g = gemm(32, hA, Mb, d->d_mean, 32, 0, A.h[nA - 1], hA, 0, A.slabs, hA);
+      g.split_k = 32;
+      g.precision = d->head_precision;
+      LAUNCH(addhip_gemm_f32(&g, stream));
+    }
+    LAUNCH(addhip_slab_reduce(A.slabs, 32, 32LL * hA, A.gWh, 32LL * hA, 1.0f, 0, stream));
+    LAUNCH(col_sum(A, d->d_mean, Mb, 32, 32, A.gbh, 1.0f, 1, stream));
+    {  // dz[last] = (d_mean Wh) * relu'(h[last]); bf16 storage: written as bf16 directly
+      // (plane storage: an fp32-operand GEMM cannot write planes -- it leaves the fp32 dz and the backward pass splits it first)
+      addhip_gemm_t g = gemm(Mb, hA, 32, d->d_mean, 32, 1, A.Wh, hA, 0, s16 && !planes ? nullptr : A.dz[nA - 1], hA, ADDHIP_EPI_MASK);
+      g.colsum = A.gb[nA - 1];
+      if (top_reps) {  // spread over the replica rows like the dX GEMMs' sums; the top layer's combine folds them into gb[last]
+        g.colsum = A.bias_replicas;
+        g.colsum_replicas = A.bias_replica_rows;
+        g.ldcs = hA;
+      }
+      g.precision = d->head_precision;
+      if (s16 && !planes) {
+        g.C16 = A.dz16[nA - 1];
+        g.ldc16 = hA;
+      }
+      set_mask(g, A, nA - 1, 0, Mb, true);
+      g.amax_out = amax_of(A, AMAX_DZ + nA - 1);  // (d_mean's own maximum is not tracked: this launch runs the exact bf16 split or the fp32 MFMA)
+      LAUNCH(addhip_gemm_f32(&g, stream));
+    }
   }
+  const bool cast_top = planes && !fused;  // (the unfused path leaves fp32 dz in plane-storage mode: the backward pass splits it)
   int at = launches;
-  if (int rc = backward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, (planes ? bwd & ~ADDHIP_BWD_TOP_CAST_DONE : bwd) | (top_reps ? ADDHIP_BWD_TOP_BIAS_REPLICAS : 0), &mk,
+  if (int rc = backward(A, d->norm_obs, d->norm_obs16, Mb, nullptr, (cast_top ? bwd & ~ADDHIP_BWD_TOP_CAST_DONE : bwd) | (top_reps ? ADDHIP_BWD_TOP_BIAS_REPLICAS : 0), &mk,
                         launches, stream, d->norm_obs_amax))
     return rc;
   const int actor_early = at + mk.early, actor_end = launches;

@@ -44,6 +44,7 @@ ADDHIP_HELD_BLOCK(addhip_gather_t);
 ADDHIP_HELD_BLOCK(addhip_rigid_model_t);
 ADDHIP_HELD_BLOCK(addhip_rigid_dr_t);
 ADDHIP_HELD_BLOCK(addhip_optimizer_t);
+ADDHIP_HELD_BLOCK(addhip_actor_head_t);
 #undef ADDHIP_HELD_BLOCK
 
 // Q... = the entry point's parameter types (the trailing void* stream included), A... = the arguments but the stream

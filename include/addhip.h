@@ -37,7 +37,7 @@ enum { ADDHIP_DONE_NULL = 0, ADDHIP_DONE_FAIL = 1, ADDHIP_DONE_SUCC = 2, ADDHIP_
 const char* addhip_last_error(void);
 int addhip_version(void);
 /* sizeof() of addhip_motion_t, task_t, env_t, step_out_t, sampler_t, gemm_t, gather_t, rigid_model_t, rigid_dr_t, optimizer_t, section_t, mlp_t,
- * extra_dw_t, mlp_marks_t, ppo_loss_t, ppo_marks_t, disc_loss_t, disc_marks_t (in that order) -> out[0..17]; returns the number written (18) or -1
+ * extra_dw_t, mlp_marks_t, ppo_loss_t, ppo_marks_t, disc_loss_t, disc_marks_t, actor_head_t (in that order) -> out[0..18]; returns the number written (19) or -1
  * (count too small).  For bindings to verify their struct layouts against the library they loaded. */
 int addhip_abi_sizes(int32_t* out, int32_t count);
 
@@ -441,6 +441,28 @@ int addhip_actor_loss(const float* mean, const float* norm_action, const float* 
                       const float* rand_mask, int32_t M, float std, float logp_const, float clip_ratio,
                       float bound_weight, float reg_weight, float loss_scale, const float* n_valid /*device [1]*/, float* d_mean,
                       float* stats, void* stream);
+/* The actor's head section as ONE launch: mean = H Wh^T + bh (DistributionGaussianDiagBuilder.forward, distribution_gaussian_diag.py:47-58),
+ * addhip_actor_loss on it (same arguments, same stats slots), and the backward step through the head into the last hidden layer:
+ *   dz = (d_mean Wh) * (H > 0)   -> dz [rows, hidden] fp32 and / or dz16 (ADDHIP_STORE_* format planes16),
+ *   db_top[k] += sum_rows dz     -> added to row (workgroup % gb_replicas) of gb_top [gb_replicas, ld_gb] (gb_replicas = 1: plain atomics on one row),
+ *   (dWh | dbh) partial sums     -> slabs [num_slabs][32 * hidden + 32], one per workgroup, to be combined by
+ *                                   addhip_slab_reduce(slabs, num_slabs, 32 * hidden + 32, gWh, 32 * hidden + 32, 1, 0) when the head's
+ *                                   bias gradient directly follows its weight gradient in memory (or by two calls).
+ * Replaces three 32-wide GEMM launches + addhip_actor_loss + addhip_col_sum of the step (csrc/actor_head.hip).  hidden: 128, 256 or 512;
+ * Wh [32, hidden] with zero rows past ADDHIP_NUM_DOF; num_slabs = addhip_actor_head_slabs(rows). */
+typedef struct {
+  int32_t rows, hidden;
+  const float* H; const float* Wh; const float* bh;
+  const float* norm_action; const float* old_logp; const float* adv; const float* rand_mask; const float* n_valid;
+  float action_std, logp_const, clip_ratio, bound_weight, reg_weight, loss_scale;
+  float* dz; uint16_t* dz16; int32_t planes16;
+  float* slabs; int32_t num_slabs;
+  float* gb_top; int32_t gb_replicas, ld_gb;
+  float* stats;
+  uint32_t* amax;           /* optional: max |dz| into ADDHIP_AMAX_SLOTS slots (caller zeroes) */
+} addhip_actor_head_t;
+int addhip_actor_head_slabs(int32_t rows);
+int addhip_actor_head(const addhip_actor_head_t* p, void* stream);
 /* count of rand_mask == 1 -> out[0] */
 int addhip_count_mask(const float* rand_mask, int32_t M, float* out, void* stream);
 /* PPOAgent._compute_critic_loss (ppo_agent.py:209-219): v = H.w+b; dv = scale*2(v-tar)/M;

@@ -30,8 +30,10 @@ def test_c_host_records_the_optimiser_step(tmp_path):
                   r"first=(\w+) last=(\w+)", out)
     assert m, out
     version, launches, gemms, gflop, sections, actor_end, early, critic_end, disc_end = (float(x) if "." in x else int(x) for x in m.groups()[:9])
-    assert version >= 4 and sections == 10
-    assert launches == 55 and gemms == 33 and abs(gflop - 471.9) < 0.1, out
+    assert version >= 5 and sections == 10
+    # (round 4: the actor's three 32-wide head GEMMs + loss + column sum are one launch, addhip_actor_head: 55 -> 52 launches, 33 -> 30 GEMMs;
+    #  its 1.6 GFLOP are no longer GEMM descriptors of the plan)
+    assert launches == 52 and gemms == 30 and abs(gflop - 470.3) < 0.1, out
     assert 0 < early < actor_end < critic_end < disc_end == launches
     assert m.group(10) == "addhip_gemm_f32" and m.group(11) in ("addhip_slab_reduce", "addhip_slab_reduce_pair")
     assert "refused=1" in out and "workspace holds" in out

@@ -636,3 +636,62 @@ def test_fixed_order_reductions_repeat_bit_for_bit():
         assert torch.equal(a, b)
     for a, b in zip(res[0], res[2]):  # the atomics form: the same sums in another order
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("hidden,rows", [(512, 4000), (256, 129), (128, 32)])
+def test_fused_actor_head_equals_the_unfused_sequence(hidden, rows):
+    """addhip_actor_head (csrc/actor_head.hip) against the launches it replaces -- head GEMM, addhip_actor_loss, weight-gradient GEMM + slab
+    reduce, column sums, dz GEMM with the ReLU mask -- on the same inputs: dz, d loss / d Wh, d bh, the top layer's bias gradient and the
+    loss diagnostics; ragged row counts, masked-out samples, action-bound violations."""
+    import torch
+    import add_gym_amd._lib as L
+    from add_gym_amd.hotpath import gemm
+
+    rng = np.random.RandomState(31 + hidden)
+    M, K = rows, hidden
+    H = T(np.maximum(rng.standard_normal((M, K)), 0).astype(F))
+    Wh = np.zeros((32, K), F)
+    Wh[:29] = rng.standard_normal((29, K)) * 0.05
+    bh = np.zeros(32, F)
+    bh[:29] = rng.standard_normal(29) * 0.3
+    na = np.zeros((M, 32), F)
+    na[:, :29] = rng.standard_normal((M, 29))
+    old_logp = (rng.standard_normal(M) * 0.3 - 30).astype(F)
+    adv = rng.standard_normal(M).astype(F)
+    mask = (rng.rand(M) < 0.9).astype(F)
+    dWh, dbh, dna, dol, dadv, dmask = T(Wh), T(bh), T(na), T(old_logp), T(adv), T(mask)
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    st = L.current_stream()
+    nv = z(1)
+    L.call("addhip_count_mask", L.ptr(dmask), M, L.ptr(nv), st)
+    std, logp_const, clip, bw, rw, ls = 0.05, float(-0.5 * 29 * np.log(2 * np.pi) - 29 * np.log(0.05)), 0.2, 10.0, 0.01, 0.5
+    # --- the unfused sequence
+    mean, d_mean, stats_a = z(M, 32), z(M, 32), z(8)
+    L.call("addhip_gemm_f32", gemm(M, 32, K, L.ptr(H), K, 1, L.ptr(dWh), K, 1, L.ptr(mean), 32, L.EPI_BIAS, L.ptr(dbh)), st)
+    L.call("addhip_actor_loss", L.ptr(mean), L.ptr(dna), L.ptr(dol), L.ptr(dadv), L.ptr(dmask), M, std, logp_const, clip, bw, rw, ls, L.ptr(nv), L.ptr(d_mean), L.ptr(stats_a), st)
+    torch.cuda.synchronize()
+    dm64, H64 = d_mean.cpu().numpy().astype(np.float64), H.cpu().numpy().astype(np.float64)
+    want_gW, want_gb = dm64.T @ H64, dm64.sum(0)
+    want_dz = (dm64 @ Wh.astype(np.float64)) * (H64 > 0)
+    # --- one launch
+    ns = L.load().addhip_actor_head_slabs(M)
+    dz, dz16 = z(M, K), torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    slabs, gb_top, stats_b = torch.full((ns, 32 * K + 32), 7.0, device="cuda"), z(4, K), z(8)
+    amax = torch.zeros(L.AMAX_SLOTS, dtype=torch.int32, device="cuda")
+    h = L.ActorHeadT(M, K, L.ptr(H), L.ptr(dWh), L.ptr(dbh), L.ptr(dna), L.ptr(dol), L.ptr(dadv), L.ptr(dmask), L.ptr(nv), std, logp_const, clip, bw, rw, ls,
+                     L.ptr(dz), L.ptr(dz16), L.STORE_BF16, L.ptr(slabs), ns, L.ptr(gb_top), 4, K, L.ptr(stats_b), L.ptr(amax))
+    L.call("addhip_actor_head", h, st)
+    out = z(32 * K + 32)
+    L.call("addhip_slab_reduce", L.ptr(slabs), ns, 32 * K + 32, L.ptr(out), 32 * K + 32, 1.0, 0, st)
+    torch.cuda.synchronize()
+    scale = np.abs(want_dz).max()
+    assert scale > 0
+    np.testing.assert_allclose(dz.cpu().numpy(), want_dz, rtol=1e-4, atol=2e-5 * scale)
+    assert torch.equal(dz16, dz.to(torch.bfloat16))
+    assert float(amax.cpu().numpy().view(np.float32).max()) == float(dz.abs().max())
+    gW = out[:32 * K].view(32, K).cpu().numpy()
+    np.testing.assert_allclose(gW, want_gW, rtol=1e-4, atol=2e-5 * np.abs(want_gW).max())
+    np.testing.assert_allclose(out[32 * K:].cpu().numpy(), want_gb, rtol=1e-4, atol=2e-5 * np.abs(want_gb).max())
+    np.testing.assert_allclose(gb_top.sum(0).cpu().numpy(), want_dz.sum(0), rtol=1e-3, atol=1e-4 * np.abs(want_dz).sum(0).max())
+    np.testing.assert_allclose(stats_b.cpu().numpy(), stats_a.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    assert float(gW[29:].max()) == 0.0 and float(np.abs(gW[29:]).max()) == 0.0  # padding rows of the head receive no gradient

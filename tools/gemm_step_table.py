@@ -22,9 +22,20 @@ _w = torch.randn(8192, 8192, device="cuda")
 for _ in range(60): _w @ _w
 torch.cuda.synchronize()
 plan = ag._update_plan   # the recorded optimiser step (addhip_plan_t): launches are listed and replayed one by one through the C ABI
-calls = [(i, gemms) for i, (name, gemms) in enumerate(plan.launches()) if gemms]
+calls = [(i, gemms) for i, (name, gemms) in enumerate(plan.launches()) if gemms or name == "addhip_actor_head"]
 tot_ms, tot_fl = 0.0, 0.0
 for n, (i, gemms) in enumerate(calls):
+    if not gemms:  # addhip_actor_head: the head's three 32-wide products + loss in one launch
+        ts = []
+        for rep in range(8):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st); plan.run(st.cuda_stream, i, i + 1); e1.record(st); e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ms = sorted(ts[1:])[3]
+        fl = 3 * 2.0 * ag.Mb * 32 * ag._model.actor.hidden[-1]
+        tot_ms += ms; tot_fl += fl
+        print(f"{n:2d} addhip_actor_head (head forward + loss + dWh + dz, one launch)                {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF  {fl/1e9:6.1f} GF", flush=True)
+        continue
     cnt, g = len(gemms), gemms[0]   # grouped launch: several equal-shaped problems
     ts = []
     for rep in range(8):
