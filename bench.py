@@ -108,7 +108,9 @@ def gemm_roofline(agent, precision, with_traffic=True):
         kern = {"bf16": "gemm_dma_kernel<bf16> (bf16 operands in HBM, ", "bf16x3_planes": "gemm_x3_kernel (operands stored as three exact bf16 planes, LDS-DMA ring, ",
                 "f16x2": "gemm_split_kernel<f16> (fp32 operands split two ways into fp16 on tracked per-tensor scales, "}.get(precision, "gemm_split_kernel (") + \
                "v_mfma_f32_32x32x16_%s x %d per k-step; small shapes stay on gemm_kernel); all GEMM launches of one optimiser step" % ("f16" if precision == "f16x2" else "bf16", products)
-        tr, tr_src = traffic("gemm_bf16_step") if precision == "bf16" and with_traffic else (None, None)  # (counters were taken at 4096 envs)
+        # (counters: profiles/traffic.json -- taken at 4096 envs, and for bf16 storage at the 16 384 envs of BASELINE configs[2] as well)
+        key = {"bf16": "gemm_bf16_step_16384" if agent.N == 16384 else "gemm_bf16_step", "f16x2": "gemm_f16x2_step"}.get(precision)
+        tr, tr_src = traffic(key) if key and (with_traffic or agent.N == 16384) else (None, None)
     return {"bound": "mfma", "kernel": kern, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": tr, "traffic_source": tr_src,
             "launches_per_step": g["launches"], "gflop_per_step": g["flops"] / 1e9, "ms_per_step": g["ms"],
             "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS}
