@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CSRC = os.path.join(ROOT, "add-gym_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 BASE = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wno-unused-function"]
-OTHERS = [os.path.join(CSRC, f) for f in ("capi.o", "plan.o", "learner.o", "env_step.o", "gemm.o", "gemm_split.o", "gemm_bf16.o", "learn.o")]
+OTHERS = [os.path.join(CSRC, f) for f in ("capi.o", "plan.o", "learner.o", "env_step.o", "gemm.o", "gemm_split.o", "gemm_bf16.o", "gemm_x3.o", "learn.o", "actor_head.o")]
 
 # Stage 2: the default -O3 build (SLP on: wrong) with ONE region of rigid_step4_kernel fenced off from the vectorizer -- an empty
 # `asm volatile` on the values that leave the region makes them opaque, so no SLP tree can span it.  (text anchor in rigid.hip,
@@ -41,7 +41,23 @@ STAGES = {
           ("slp, O2", ["-O2"]),
           ] + [(f"slp-threshold={t}", ["-mllvm", f"-slp-threshold={t}"]) for t in (1, 2, 3, 5, 8, 16, 24, 40, 60)],
     "2": [("slp (control)", [])] + [("slp, fence: " + k, ["@fence", k]) for k in FENCES],
+    # Stage 3 (round 4): is the VECTORIZED IR wrong, or its lowering to packed instructions?  With the packed-fp32 target feature off the
+    # cost model rejects the trees, so the vectorizer is forced (negative threshold) and the <2 x float> operations are scalarised by
+    # instruction selection: same IR-level decisions, no v_pk_*_f32.  `vec2` = <2 x float> arithmetic operations in the device IR of rigid.hip.
+    "3": [("slp (control)", [])] +
+         [(f"slp forced (threshold {t}), packed fp32 off", ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-mllvm", f"-slp-threshold={t}"]) for t in (-4, -20)] +
+         [(f"slp forced (threshold {t}), packed fp32 on", ["-mllvm", f"-slp-threshold={t}"]) for t in (-4, -20)],
 }
+
+
+def ir_vec2(flags, tmp, tag):
+    """<2 x float> fadd / fmul / fma / fsub operations in the device IR (how much the SLP vectorizer formed)."""
+    ll = os.path.join(tmp, f"rigid_{tag}.ll")
+    r = subprocess.run([HIPCC] + BASE + flags + ["--cuda-device-only", "-emit-llvm", "-S", os.path.join(CSRC, "rigid.hip"), "-o", ll], capture_output=True, text=True)
+    if r.returncode != 0:
+        return None
+    txt = open(ll).read()
+    return len(re.findall(r"= (?:f(?:add|mul|sub)[^\n]*<2 x float>|[^\n]*@llvm\.fma\.v2f32|[^\n]*@llvm\.fmuladd\.v2f32)", txt))
 
 
 def patched_source(key, tmp):
@@ -93,6 +109,9 @@ def main():
             continue
         subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950"] + OTHERS + [obj, "-o", so], check=True)
         st = None
+        if stage == "3":
+            ks, _ = kernel_stats(flags, tmp, str(i))
+            st = dict(vec2_ir_ops=ir_vec2(flags, tmp, str(i)), **(ks or {}))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "slp_repro", "gpu_case.py"), so], capture_output=True, text=True, timeout=600)
         cases = [l for l in r.stdout.splitlines() if l.startswith("CASE")]
         say(f"[{name}] flags {flags}: four-lane kernel {st}")
