@@ -329,6 +329,270 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(addhip_gemm_t g, int ti
   addhip_epi::gemm_epilogue<2, 2, EPI, false, true>(g, acc, lds + wave * addhip_epi::EpiBuf<2>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z, alpha);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel on 256-row tiles, 8 wavefronts (round 4).  Why: the split is vector-ALU work per STAGED element, the products are MFMA work
+// per TILE element.  PMC of the 128x128 kernel (profiles/r04_split_pmc.json): matrix pipe busy 62 % (bf16x3), 47 % (f16x2), 43 % (bf16x2) --
+// exactly what SIMD issue arithmetic predicts: a wave's stream needs 8 (MFMA) + 4 x (5..8 vector instructions) = 28..40 issue cycles per 32-cycle
+// MFMA, and two waves share a SIMD.  A 256x256 tile stages the same 16 values per thread and stage but multiplies them twice as often
+// (8 accumulators of 32x32 per wave instead of 4): 2.3-3.7 vector instructions per MFMA.  256x128 (8 waves of 64x64) for shapes that do not
+// fill the chip with 256x256 tiles.  No fused normalisation here (those launches keep the 128x128 kernel).
+template <int WM_, int WN_, int MT_, int NT_>
+struct BigCfg {
+  static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_;
+  static constexpr int NW = WM * WN, THREADS = 64 * NW, BM = WM * MT * 32, BN = WN * NT * 32;
+};
+
+// k-contiguous operand of ROWS rows: LPT float4 (4 k of one row) per thread and stage
+template <int THREADS, int ROWS>
+struct KcMove {
+  static constexpr int LPT = ROWS * 4 / THREADS;
+  static_assert(LPT * THREADS == ROWS * 4 && LPT >= 1 && LPT <= 2, "whole float4 per thread");
+  static __device__ __forceinline__ void load(float4* reg, const float* __restrict__ P, int ld, int r0, int k0, int R, int kend) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int f = threadIdx.x + THREADS * i;
+      const int row = f >> 2, kq = (f & 3) * 4;
+      reg[i] = *reinterpret_cast<const float4*>(P + (size_t)min(r0 + row, R - 1) * ld + min(k0 + kq, kend - 4));
+    }
+  }
+  template <int PLANES, bool GUARD, bool F16>
+  static __device__ __forceinline__ void store(char* lds, const float4* reg, int i, int k0, int kend, float sc) {
+    if (i >= LPT) return;
+    const int f = threadIdx.x + THREADS * i;
+    const int row = f >> 2, kq = (f & 3) * 4;
+    float4 v = reg[i];
+    if (GUARD) {
+      const bool in = k0 + kq < kend;
+      v = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+    }
+    char* dst = lds + row * Img<PLANES>::RS + kq * 2;
+    if (F16) {
+      unsigned h0, l0, h1, l1;
+      split2h(v.x * sc, v.y * sc, h0, l0);
+      split2h(v.z * sc, v.w * sc, h1, l1);
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(dst + 32) = make_uint2(l0, l1);
+      return;
+    }
+    unsigned h[4], m[4], l[4];
+    split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]); split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+    if (PLANES >= 2) *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pack2(m[0], m[1]), pack2(m[2], m[3]));
+    if (PLANES == 3) *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+  }
+};
+// m/n-contiguous operand of ROWS rows: thread (kk2, rq) moves rows rq..rq+3 of two consecutive k; THREADS / 2 rows are covered, threads
+// beyond ROWS idle (wave-uniform: ROWS / 4 is a multiple of 64 threads' worth of rows)
+template <int THREADS, int ROWS>
+struct McMove {
+  static_assert(THREADS / 2 >= ROWS, "the workgroup covers the tile's rows");
+  static __device__ __forceinline__ bool mine() { return (int)(threadIdx.x >> 3) * 4 < ROWS; }
+  static __device__ __forceinline__ void load(float4* reg, const float* __restrict__ P, int ld, int r0, int k0, int R, int kend) {
+    const int kk2 = threadIdx.x & 7, rq = min((int)(threadIdx.x >> 3) * 4, ROWS - 4);
+    const int r = min(r0 + rq, R - 4), k = k0 + 2 * kk2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) reg[i] = *reinterpret_cast<const float4*>(P + (size_t)min(k + i, kend - 1) * ld + r);
+  }
+  template <int PLANES, bool GUARD, bool F16>
+  static __device__ __forceinline__ void store(char* lds, const float4* reg, int i, int k0, int kend, float sc) {
+    if (!mine()) return;
+    const int kk2 = threadIdx.x & 7, rq = (threadIdx.x >> 3) * 4;
+    const int k = k0 + 2 * kk2;
+    const bool in0 = !GUARD || k < kend, in1 = !GUARD || k + 1 < kend;
+    const float a[2] = {i == 0 ? reg[0].x : reg[0].z, i == 0 ? reg[0].y : reg[0].w};  // k even
+    const float b[2] = {i == 0 ? reg[1].x : reg[1].z, i == 0 ? reg[1].y : reg[1].w};  // k odd
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      char* dst = lds + (rq + 2 * i + j) * Img<PLANES>::RS + kk2 * 4;
+      if (F16) {
+        unsigned h, l;
+        split2h(in0 ? a[j] * sc : 0.f, in1 ? b[j] * sc : 0.f, h, l);
+        *reinterpret_cast<unsigned*>(dst) = h;
+        *reinterpret_cast<unsigned*>(dst + 32) = l;
+        continue;
+      }
+      unsigned ha, ma, la, hb, mb, lb;
+      split3(in0 ? a[j] : 0.f, ha, ma, la);
+      split3(in1 ? b[j] : 0.f, hb, mb, lb);
+      *reinterpret_cast<unsigned*>(dst) = pack2(ha, hb);
+      if (PLANES >= 2) *reinterpret_cast<unsigned*>(dst + 32) = pack2(ma, mb);
+      if (PLANES == 3) *reinterpret_cast<unsigned*>(dst + 64) = pack2(la, lb);
+    }
+  }
+};
+
+template <typename Q, bool AKC, bool BKC, int EPI, int PLANES, bool F16>
+__global__ __launch_bounds__(Q::THREADS, Q::NW / 4) void gemm_split_big_kernel(addhip_gemm_t g, int tiles_m, int tiles_n) {
+  static_assert(PLANES >= 2 && (!F16 || PLANES == 2), "exact / two-chunk bf16 split, or the two-way fp16 split");
+  using I = Img<PLANES>;
+  constexpr int MT = Q::MT, NT = Q::NT, TH = Q::THREADS;
+  constexpr int SIZE_A = Q::BM * I::RS, SIZE_B = Q::BN * I::RS, STAGE = SIZE_A + SIZE_B;
+  constexpr int EPI_BYTES = Q::NW * addhip_epi::EpiBuf<NT>::WAVE_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES];
+  typedef KcMove<TH, Q::BM> KA;
+  typedef KcMove<TH, Q::BN> KB;
+  typedef McMove<TH, Q::BM> MA;
+  typedef McMove<TH, Q::BN> MB;
+  constexpr int PA = AKC ? KA::LPT : 2, PB = BKC ? KB::LPT : 2;  // float4 registers (= stash parts) per operand and stage
+
+  const int total = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q = total >> 3, r = total & 7, xcd = orig & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+  const int m0 = tm * Q::BM, n0 = tn * Q::BN;
+
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  const int kchunk = ((g.K + split - 1) / split + BK - 1) / BK * BK;
+  const int kbeg = blockIdx.z * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  const int nkf = kend > kbeg ? (kend - kbeg) / BK : 0;  // whole stages
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm0 = (wave / Q::WN) * (MT * 32), wn0 = (wave % Q::WN) * (NT * 32);
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
+  const float sc_a = F16 ? scale_from_amax(g.a_amax) : 1.f, sc_b = F16 ? scale_from_amax(g.b_amax) : 1.f;
+  const float alpha = F16 ? g.alpha / sc_a / sc_b : g.alpha;
+
+  constexpr int DEPTH = 2;  // register ring: a stage is MT*NT*products MFMAs (1024-1536 cycles per wave, two waves per SIMD): two stages ahead cover a load round trip
+  float4 ra[DEPTH][2], rb[DEPTH][2];
+  auto fetch = [&](int kt, float4* a_reg, float4* b_reg) {
+    const int k0 = kbeg + min(kt, nk - 1) * BK;  // past the end: a redundant reload of the last stage, never consumed
+    if (AKC) KA::load(a_reg, g.A, g.lda, m0, k0, g.M, kend);
+    else MA::load(a_reg, g.A, g.lda, m0, k0, g.M, kend);
+    if (BKC) KB::load(b_reg, g.B, g.ldb, n0, k0, g.N, kend);
+    else MB::load(b_reg, g.B, g.ldb, n0, k0, g.N, kend);
+  };
+  // part p (0 .. PA+PB-1) of: registers of stage kt -> LDS buffer kt & 1
+  auto stash_part = [&](auto guard, int p, int kt, const float4* a_reg, const float4* b_reg) {
+    constexpr bool GUARD = decltype(guard)::value;
+    const int k0 = kbeg + min(kt, nk - 1) * BK;
+    char* a_dst = lds + (kt & 1) * STAGE;
+    if (p < PA) {
+      if (AKC) KA::template store<PLANES, GUARD, F16>(a_dst, a_reg, p, k0, kend, sc_a);
+      else MA::template store<PLANES, GUARD, F16>(a_dst, a_reg, p, k0, kend, sc_a);
+    } else {
+      if (BKC) KB::template store<PLANES, GUARD, F16>(a_dst + SIZE_A, b_reg, p - PA, k0, kend, sc_b);
+      else MB::template store<PLANES, GUARD, F16>(a_dst + SIZE_A, b_reg, p - PA, k0, kend, sc_b);
+    }
+  };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto products = [&](f32x16& c, const bf16x8* fa, const bf16x8* fb) {
+    if constexpr (F16) {  // all four products of the two-way fp16 split, smallest first (the fragments hold fp16 bit patterns)
+      auto h = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[1]), h(fb[1]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[0]), h(fb[1]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[1]), h(fb[0]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[0]), h(fb[0]), c, 0, 0, 0);
+    } else {
+      if (PLANES == 3) {  // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2 % PLANES], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 % PLANES], fb[0], c, 0, 0, 0);
+      }
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], c, 0, 0, 0);
+    }
+  };
+  // the MFMAs of stage kt (LDS buffer kt & 1) with the stash of stage kt + 1 spread between the accumulator rows; B fragments for the
+  // whole stage, A fragments one 32-row block at a time (registers)
+  auto multiply = [&](auto guard, int kt, bool stash, const float4* a_next, const float4* b_next) {
+    const char* a_cur = lds + (kt & 1) * STAGE;
+    const char* b_cur = a_cur + SIZE_A;
+    bf16x8 fb[NT][PLANES];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int p = 0; p < PLANES; ++p) fb[b][p] = frag(b_cur, wn0 + b * 32 + li, p, lh, I::RS);
+    int done = 0;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      bf16x8 fa[PLANES];
+#pragma unroll
+      for (int p = 0; p < PLANES; ++p) fa[p] = frag(a_cur, wm0 + a * 32 + li, p, lh, I::RS);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) products(acc[a][b], fa, fb[b]);
+      const int upto = (a + 1) * (PA + PB) / MT;  // parts stashed once this accumulator row is issued
+      if (stash)
+        for (; done < upto; ++done) stash_part(guard, done, kt + 1, a_next, b_next);
+    }
+  };
+  if (nkf > 0) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fetch(d, ra[d], rb[d]);
+#pragma unroll
+    for (int p = 0; p < PA + PB; ++p) stash_part(std::false_type{}, p, 0, ra[0], rb[0]);
+    lds_barrier();
+    int kt = 0;
+    for (; kt + DEPTH <= nkf; kt += DEPTH) {
+#pragma unroll
+      for (int s = 0; s < DEPTH; ++s) {
+        // slot s held stage kt+s (already in LDS); it is refilled with stage kt+s+DEPTH while stage kt+s is multiplied and stage kt+s+1
+        // (slot (s+1) % DEPTH) goes to the other LDS buffer
+        fetch(kt + s + DEPTH, ra[s], rb[s]);
+        multiply(std::false_type{}, kt + s, true, ra[(s + 1) % DEPTH], rb[(s + 1) % DEPTH]);
+        lds_barrier();
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; ++s)
+      if (kt + s < nkf) {
+        fetch(kt + s + DEPTH, ra[s], rb[s]);
+        multiply(std::false_type{}, kt + s, true, ra[(s + 1) % DEPTH], rb[(s + 1) % DEPTH]);
+        lds_barrier();
+      }
+  }
+  if (nk > nkf) {  // K tail: one guarded, unpipelined stage (every wave is past the last barrier of the pipeline)
+    fetch(nkf, ra[0], rb[0]);
+#pragma unroll
+    for (int p = 0; p < PA + PB; ++p) stash_part(std::true_type{}, p, nkf, ra[0], rb[0]);
+    lds_barrier();
+    multiply(std::true_type{}, nkf, false, ra[0], rb[0]);
+  }
+  __syncthreads();
+  addhip_epi::gemm_epilogue<MT, NT, EPI, false, true>(g, acc, lds + wave * addhip_epi::EpiBuf<NT>::WAVE_BYTES, lane, m0 + wm0, n0 + wn0, blockIdx.z, alpha);
+}
+
+typedef BigCfg<2, 4, 4, 2> SplitBig;   // 256x256: 8 waves of 128x64
+typedef BigCfg<4, 2, 2, 2> SplitWide;  // 256x128: 8 waves of 64x64
+
+template <typename Q, int PLANES, bool F16>
+int launch_split_big(const addhip_gemm_t& g, hipStream_t st) {
+  const int tiles_m = (g.M + Q::BM - 1) / Q::BM, tiles_n = (g.N + Q::BN - 1) / Q::BN;
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  dim3 grid(tiles_m * tiles_n, 1, split), block(Q::THREADS);
+#define ADDHIP_LAUNCH(AK, BKc, EPI) hipLaunchKernelGGL((gemm_split_big_kernel<Q, AK, BKc, EPI, PLANES, F16>), grid, block, 0, st, g, tiles_m, tiles_n)
+  if (g.a_kcontig && g.b_kcontig) {
+    if (g.epilogue == ADDHIP_EPI_BIAS_RELU) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_BIAS_RELU);
+    else if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_LAUNCH(true, true, ADDHIP_EPI_MASK);
+    else ADDHIP_LAUNCH(true, true, EPI_RUNTIME);
+  } else if (g.a_kcontig && !g.b_kcontig) {
+    if (g.epilogue == ADDHIP_EPI_MASK) ADDHIP_LAUNCH(true, false, ADDHIP_EPI_MASK);
+    else ADDHIP_LAUNCH(true, false, EPI_RUNTIME);
+  } else if (!g.a_kcontig && g.b_kcontig) {
+    ADDHIP_LAUNCH(false, true, EPI_RUNTIME);
+  } else {
+    if (g.epilogue == ADDHIP_EPI_NONE) ADDHIP_LAUNCH(false, false, ADDHIP_EPI_NONE);
+    else ADDHIP_LAUNCH(false, false, EPI_RUNTIME);
+  }
+#undef ADDHIP_LAUNCH
+  return addhip::check_launch("gemm_split_big_kernel");
+}
+
 template <int PLANES, bool F16 = false>
 int launch_split(const addhip_gemm_t& g, hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
@@ -362,11 +626,24 @@ int launch_split(const addhip_gemm_t& g, hipStream_t st) {
 
 namespace addhip {
 // called by addhip_gemm_f32 (gemm.hip) after argument validation, for the shapes that fill the chip with 128x128 tiles
-int gemm_split_dispatch(const addhip_gemm_t& g, int planes, hipStream_t st) {
+int gemm_split_dispatch(const addhip_gemm_t& g, int planes, hipStream_t st) {  // planes: ADDHIP_PREC_* (1..4)
   if (g.a_mean && g.K > 512) return (set_error("gemm: fused normalisation on the bf16 paths needs K <= 512"), -1);
   // ADDHIP_PREC_F16X2 needs both operand bounds and no fused normalisation (the normalised values' maximum is not tracked): otherwise the
   // exact bf16 split, which needs neither
-  if (planes == ADDHIP_PREC_F16X2) return (g.a_amax && g.b_amax && !g.a_mean) ? launch_split<2, true>(g, st) : launch_split<3>(g, st);
+  const bool f16 = planes == ADDHIP_PREC_F16X2 && g.a_amax && g.b_amax && !g.a_mean;
+  if (planes == ADDHIP_PREC_F16X2 && !f16) planes = ADDHIP_PREC_BF16X3;
+  // 256-row tiles (8 waves: half the split arithmetic per MFMA) where they fill the chip; ADDHIP_GEMM_HINT_* override (tools, tests)
+  const long long split = g.split_k > 1 ? g.split_k : 1;
+  auto wgs = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * split; };
+  int cfg = g.a_mean || planes == ADDHIP_PREC_BF16 ? 2 : wgs(256, 256) >= 224 ? 0 : wgs(256, 128) >= 224 ? 1 : 2;
+  if (!g.a_mean && planes != ADDHIP_PREC_BF16) {
+    if (g.hint & ADDHIP_GEMM_HINT_BIG_TILE) cfg = 0;
+    if (g.hint & ADDHIP_GEMM_HINT_WIDE_TILE) cfg = 1;
+    if (g.hint & ADDHIP_GEMM_HINT_NO_BIG_TILE) cfg = 2;
+  }
+  if (cfg == 0) return f16 ? launch_split_big<SplitBig, 2, true>(g, st) : planes == 3 ? launch_split_big<SplitBig, 3, false>(g, st) : launch_split_big<SplitBig, 2, false>(g, st);
+  if (cfg == 1) return f16 ? launch_split_big<SplitWide, 2, true>(g, st) : planes == 3 ? launch_split_big<SplitWide, 3, false>(g, st) : launch_split_big<SplitWide, 2, false>(g, st);
+  if (f16) return launch_split<2, true>(g, st);
   return planes == 3 ? launch_split<3>(g, st) : planes == 2 ? launch_split<2>(g, st) : launch_split<1>(g, st);
 }
 }  // namespace addhip

@@ -44,7 +44,7 @@ def amax_slots(t):
     return slots
 
 
-def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, seed=0, precision=0, accumulate=0, scale_a=1.0, scale_b=1.0, check_amax=False):
+def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, seed=0, precision=0, accumulate=0, scale_a=1.0, scale_b=1.0, check_amax=False, hint=0):
     import torch
     import add_gym_amd._lib as L
     from add_gym_amd.hotpath import gemm
@@ -66,7 +66,7 @@ def run_gemm(M, N, K, a_kc, b_kc, epilogue=0, split_k=1, norm=False, alpha=1.0, 
     dcs = torch.full((N,), 0.5, device="cuda")  # MASK epilogue also accumulates the column sums (bias gradient) here
     g = gemm(M, N, K, L.ptr(dA), lda, a_kc, L.ptr(dB), ldb, b_kc, L.ptr(dC), ldc, epilogue, L.ptr(dbias), L.ptr(dmask), N,
              L.ptr(dmean) if norm else None, L.ptr(dstd) if norm else None, split_k, alpha, L.ptr(dcs) if epilogue == 3 else None, precision,
-             accumulate=accumulate)
+             accumulate=accumulate, hint=hint)
     if precision == 4 and not norm:  # the fp16 split scales each operand by its tracked maximum
         g.a_amax, g.b_amax = L.ptr(amax_slots(dA)), L.ptr(amax_slots(dB))
     out_amax = torch.zeros(L.AMAX_SLOTS, dtype=torch.int32, device="cuda")
@@ -119,6 +119,23 @@ def test_gemm_epilogues(epi):
     run_gemm(515, 1024, 264, 1, 1, epilogue=epi)
     run_gemm(129, 32, 512, 1, 1, epilogue=epi)  # 29/32-wide head shape
     run_gemm(257, 512, 1024, 1, 0, epilogue=epi)
+
+
+@pytest.mark.parametrize("precision", [4, 3, 2])
+@pytest.mark.parametrize("config", ["256x256", "256x128"])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_split_256_row_tiles(a_kc, b_kc, config, precision):
+    """The 8-wave forms of the split kernel (gemm_split_big_kernel: 256x256 and 256x128 tiles), forced on shapes the dispatcher would also give
+    to the 128x128 kernel: every operand layout, ragged edges, K tails and K shorter than the register ring, epilogues, split-K."""
+    h = {"256x256": 1, "256x128": 32}[config]
+    run_gemm(520, 392, 1024 + 12, a_kc, b_kc, precision=precision, hint=h)
+    run_gemm(256, 256, 16, a_kc, b_kc, precision=precision, hint=h)
+    run_gemm(4100, 1000, 272, a_kc, b_kc, precision=precision, hint=h, check_amax=True)
+    if a_kc:
+        for epi in (1, 2, 3):
+            run_gemm(1000, 512, 520, 1, b_kc, epilogue=epi, precision=precision, hint=h, check_amax=True)
+    if not a_kc and not b_kc:
+        run_gemm(1024, 272, 4096 + 4, 0, 0, split_k=5, precision=precision, hint=h)
 
 
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
