@@ -119,7 +119,7 @@ class PpoLossT(C.Structure):
                 ("norm_action", f32p),
                 ("old_logp", f32p), ("adv", f32p), ("tar_val", f32p), ("rand_mask", f32p), ("action_std", C.c_float), ("logp_const", C.c_float),
                 ("ppo_clip_ratio", C.c_float), ("action_bound_weight", C.c_float), ("action_reg_weight", C.c_float), ("critic_loss_weight", C.c_float),
-                ("grad_scale", C.c_float), ("head_precision", C.c_int32), ("mean", f32p), ("d_mean", f32p), ("dv", f32p), ("num_valid", f32p), ("stats", f32p)]
+                ("grad_scale", C.c_float), ("dist", f32p), ("g_logstd", f32p), ("head_precision", C.c_int32), ("mean", f32p), ("d_mean", f32p), ("dv", f32p), ("num_valid", f32p), ("stats", f32p)]
 
 
 class PpoMarksT(C.Structure):
@@ -135,7 +135,7 @@ class DiscLossT(C.Structure):
 class ActorHeadT(C.Structure):
     _fields_ = [("rows", C.c_int32), ("hidden", C.c_int32), ("H", f32p), ("Wh", f32p), ("bh", f32p), ("norm_action", f32p), ("old_logp", f32p), ("adv", f32p),
                 ("rand_mask", f32p), ("n_valid", f32p), ("action_std", C.c_float), ("logp_const", C.c_float), ("clip_ratio", C.c_float),
-                ("bound_weight", C.c_float), ("reg_weight", C.c_float), ("loss_scale", C.c_float), ("dz", f32p), ("dz16", f32p), ("planes16", C.c_int32),
+                ("bound_weight", C.c_float), ("reg_weight", C.c_float), ("loss_scale", C.c_float), ("dist", f32p), ("dz", f32p), ("dz16", f32p), ("planes16", C.c_int32),
                 ("slabs", f32p), ("num_slabs", C.c_int32), ("gb_top", f32p), ("gb_replicas", C.c_int32), ("ld_gb", C.c_int32), ("stats", f32p), ("amax", f32p)]
 
 
@@ -151,6 +151,12 @@ RIGID_BODY_W, RIGID_TOPO_W = 32, 8
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
 PREC_F32, PREC_BF16, PREC_BF16X2, PREC_BF16X3, PREC_F16X2 = 0, 1, 2, 3, 4
 ORDERED_BLOCKS, HEAD_BWD_BLOCKS = 64, 256  # fixed-order reductions (agent.deterministic)
+DIST_FLOATS = 64                           # addhip_dist_refresh's vector (actor_std_type CONSTANT)
+
+
+def actor_head_slab(hidden):
+    """ADDHIP_ACTOR_HEAD_SLAB: floats of one workgroup's slab of addhip_actor_head."""
+    return 32 * hidden + 64
 AMAX_SLOTS, MLP_AMAX_TENSORS = 64, 12  # tracked operand maxima of PREC_F16X2 (include/addhip.h)
 STORE_BF16, STORE_BF16X3 = 1, 3  # 16-bit storage formats of GEMM operands (include/addhip.h, "plane storage")
 GEMM_HINT_BIG_TILE, GEMM_HINT_NO_BIG_TILE, GEMM_HINT_ONE_STAGE, GEMM_HINT_TWO_STAGE, GEMM_HINT_REG_STAGED, GEMM_HINT_WIDE_TILE = 1, 2, 4, 8, 16, 32
@@ -178,7 +184,8 @@ SIGNATURES = {
     "addhip_slab_reduce_pair": [vp, i32, i64, vp, i64, f32, i32, vp, i32, i32, vp, i32, i32, i32, vp],
     "addhip_col_sum": [vp, i32, i32, i32, vp, f32, i32, vp],
     "addhip_col_sum_ordered": [vp, i32, i32, i32, vp, f32, i32, vp, vp],
-    "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp],
+    "addhip_dist_refresh": [vp, vp, vp],
+    "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp],
     "addhip_fill_normal": [vp, i64, u64, u64, vp],
     "addhip_fill_uniform": [vp, i64, u64, u64, vp],
     "addhip_fill_normal_at": [vp, i64, u64, u64, vp, vp],
@@ -193,7 +200,7 @@ SIGNATURES = {
     "addhip_norm_merge": [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
     "addhip_diffnorm_merge": [vp, vp, vp, i64, i32, vp],
     "addhip_gather_minibatch": [P(GatherT), vp],
-    "addhip_actor_loss": [vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
+    "addhip_actor_loss": [vp, vp, vp, vp, vp, i32, f32, f32, vp, f32, f32, f32, f32, vp, vp, vp, vp, vp],
     "addhip_count_mask": [vp, i32, vp, vp],
     "addhip_actor_head_slabs": [i32],     # returns the slab count
     "addhip_actor_head": [P(ActorHeadT), vp],

@@ -37,7 +37,7 @@ __device__ __forceinline__ unsigned short ah_bf16(float v) {
   return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-constexpr int ah_lds_floats(int K) { return 2 * 32 * (K + 4) + 4 * 1024 + 32 * 33; }
+constexpr int ah_lds_floats(int K) { return 2 * 32 * (K + 4) + 4 * 1024 + 2 * 32 * 33; }
 
 template <int K>  // width of the last hidden layer: four waves x K/4 columns, K/4 a multiple of 32
 __global__ __launch_bounds__(256, 1) void actor_head_kernel(addhip_actor_head_t p) {
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256, 1) void actor_head_kernel(addhip_actor_head_t 
   float* Ws = Hs + 32 * LD;   // [32][LD]  the head weights (rows 29..31 are zero)
   float* red = Ws + 32 * LD;  // [4][16][64] the waves' partial mean tiles, accumulator layout
   float* dm = red + 4 * 1024; // [32][33]  d_mean by rows
+  float* dl = dm + 32 * 33;   // [32][33]  d loss / d logstd terms by rows (trainable log-std only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int k0 = wave * KS;
   const int nblk = (p.rows + 31) / 32;
@@ -55,9 +56,13 @@ __global__ __launch_bounds__(256, 1) void actor_head_kernel(addhip_actor_head_t 
     const int row = i / (K / 4), c4 = (i % (K / 4)) * 4;
     *reinterpret_cast<float4*>(&Ws[row * LD + c4]) = *reinterpret_cast<const float4*>(&p.Wh[(size_t)row * K + c4]);
   }
-  float bias[16];
+  float bias[16], sd[16];  // head bias and standard deviation of action dim acc_row(x, lh)
 #pragma unroll
-  for (int x = 0; x < 16; ++x) bias[x] = p.bh[acc_row(x, lh)];
+  for (int x = 0; x < 16; ++x) {
+    bias[x] = p.bh[acc_row(x, lh)];
+    sd[x] = p.dist ? p.dist[acc_row(x, lh)] : p.action_std;
+  }
+  const float logp_const = p.dist ? p.dist[32] : p.logp_const;
   const float nv = fmaxf(p.n_valid[0], 1.f);
   f32x16 dW[NT];
   float gb[NT];
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void actor_head_kernel(addhip_actor_head_t 
 #pragma unroll
     for (int x = 0; x < 16; ++x) dW[t][x] = 0.f;
   }
-  float gbh = 0.f, amx = 0.f;
+  float gbh = 0.f, gls = 0.f, amx = 0.f;
   float st_min = 0.f, st_clip = 0.f, st_ratio = 0.f, st_bound = 0.f, st_reg = 0.f;
 
   for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void actor_head_kernel(addhip_actor_head_t 
       const bool col_ok = j < ADDHIP_NUM_DOF;
       const float mu_all = ((red[x * 64 + lane] + red[1024 + x * 64 + lane]) + red[2048 + x * 64 + lane]) + red[3072 + x * 64 + lane] + bias[x];
       mu[x] = col_ok ? mu_all : 0.f;
-      dd[x] = col_ok ? (na[x] - mu[x]) / p.action_std : 0.f;
+      dd[x] = col_ok ? (na[x] - mu[x]) / sd[x] : 0.f;
       vi[x] = col_ok ? fminf(mu[x] + 1.f, 0.f) + fmaxf(mu[x] - 1.f, 0.f) : 0.f;  // base_agent.py:536-541 (one of the two is 0)
       sq += dd[x] * dd[x];
       vs += vi[x] * vi[x];
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void actor_head_kernel(addhip_actor_head_t 
     sq += __shfl_xor(sq, 32, 64);
     vs += __shfl_xor(vs, 32, 64);
     ms += __shfl_xor(ms, 32, 64);
-    const float logp = -0.5f * sq + p.logp_const;
+    const float logp = -0.5f * sq + logp_const;
     const float ratio = expf(logp - p.old_logp[rr]);
     const float adv = p.adv[rr];
     const float l0 = adv * ratio;
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void actor_head_kernel(addhip_actor_head_t 
 #pragma unroll
     for (int x = 0; x < 16; ++x) {
       float g = 0.f;
-      if (valid && acc_row(x, lh) < ADDHIP_NUM_DOF) g = g_logp * (dd[x] / p.action_std) + (p.bound_weight * 2.f * vi[x] + p.reg_weight * 2.f * mu[x]) / nv;
+      if (valid && acc_row(x, lh) < ADDHIP_NUM_DOF) g = g_logp * (dd[x] / sd[x]) + (p.bound_weight * 2.f * vi[x] + p.reg_weight * 2.f * mu[x]) / nv;
       dmean[x] = p.loss_scale * g;
     }
     if (wave == 0) {
@@ -152,6 +157,10 @@ __global__ __launch_bounds__(256, 1) void actor_head_kernel(addhip_actor_head_t 
       }
 #pragma unroll
       for (int x = 0; x < 16; ++x) dm[acc_row(x, lh) * 33 + li] = dmean[x];  // d_mean^T [action dim][row]
+      if (p.dist) {  // d logp / d logstd_j = dd_j^2 - 1  (distribution_gaussian_diag.py:90-94 differentiated; 0 on the padding dims)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) dl[acc_row(x, lh) * 33 + li] = acc_row(x, lh) < ADDHIP_NUM_DOF ? p.loss_scale * g_logp * (dd[x] * dd[x] - 1.f) : 0.f;
+      }
     }
     __syncthreads();
     if (wave == 0 && lh == 0) {  // d bh[li] += sum over the block's rows
@@ -159,6 +168,12 @@ __global__ __launch_bounds__(256, 1) void actor_head_kernel(addhip_actor_head_t 
 #pragma unroll
       for (int r = 0; r < 32; ++r) s += dm[li * 33 + r];
       gbh += s;
+      if (p.dist) {
+        float sl = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) sl += dl[li * 33 + r];
+        gls += sl;
+      }
     }
     float dT[16];  // d_mean^T fragments of the weight-gradient product: action dim li, rows acc_row(x, lh)
 #pragma unroll
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void actor_head_kernel(addhip_actor_head_t 
     }
   }
   // ---- this workgroup's partial of (dWh | dbh) -> its slab; db_top -> its replica row; loss diagnostics
-  float* slab = p.slabs + (size_t)blockIdx.x * (32 * K + 32);
+  float* slab = p.slabs + (size_t)blockIdx.x * ADDHIP_ACTOR_HEAD_SLAB(K);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int kc = k0 + 32 * t + li;
@@ -205,7 +220,10 @@ __global__ __launch_bounds__(256, 1) void actor_head_kernel(addhip_actor_head_t 
     for (int x = 0; x < 16; ++x) slab[acc_row(x, lh) * K + kc] = dW[t][x];
     if (lh == 0 && p.gb_top) atomicAdd(&p.gb_top[(size_t)(blockIdx.x % p.gb_replicas) * p.ld_gb + kc], gb[t]);
   }
-  if (wave == 0 && lh == 0) slab[32 * K + li] = gbh;  // (lane li: action dim li)
+  if (wave == 0 && lh == 0) {  // (lane li: action dim li)
+    slab[32 * K + li] = gbh;
+    slab[32 * K + 32 + li] = gls;
+  }
   if (p.amax) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));

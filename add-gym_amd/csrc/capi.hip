@@ -15,7 +15,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace addhip
 
 extern "C" const char* addhip_last_error(void) { return g_err; }
-extern "C" int addhip_version(void) { return 5; }
+extern "C" int addhip_version(void) { return 6; }
 // sizeof() of the parameter blocks, in the order they are declared in include/addhip.h: lets a binding check its own layout
 extern "C" int addhip_abi_sizes(int32_t* out, int32_t count) {
   const int32_t sizes[] = {(int32_t)sizeof(addhip_motion_t), (int32_t)sizeof(addhip_task_t), (int32_t)sizeof(addhip_env_t), (int32_t)sizeof(addhip_step_out_t),

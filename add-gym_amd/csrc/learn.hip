@@ -91,10 +91,26 @@ __global__ void fill_normal_kernel(float* out, long long n, uint64_t seed, uint6
 }
 
 // ------------------------------------------------------------------ rollout actor head
-__global__ __launch_bounds__(256) void actor_sample_kernel(const float* mean, int ldm, const float* noise, float stdv, float logp_const,
+// log-std vector -> {std, log-probability constant, entropy} (distribution_gaussian_diag.py:63-67, 90-99): one wave
+__global__ __launch_bounds__(64) void dist_refresh_kernel(const float* logstd, float* dist) {
+  const int lane = threadIdx.x;
+  const float ls = lane < ADDHIP_NUM_DOF ? logstd[lane] : 0.f;
+  if (lane < 32) dist[lane] = lane < ADDHIP_NUM_DOF ? expf(ls) : 1.f;
+  const float s = wave_sum(ls);
+  if (lane == 0) {
+    dist[32] = __fsub_rn((float)(-0.5 * ADDHIP_NUM_DOF * 1.8378770664093453), s);        // -0.5 * 29 * log(2 pi) - sum(logstd)
+    dist[33] = __fadd_rn(s, (float)(0.5 * ADDHIP_NUM_DOF * 2.8378770664093453));         // sum(logstd) + 0.5 * 29 * log(2 pi e)
+  }
+}
+
+__global__ __launch_bounds__(256) void actor_sample_kernel(const float* mean, int ldm, const float* noise, float stdv, float logp_const, const float* dist,
                                                            const float* a_mean, const float* a_std, int n, int deterministic_all,
                                                            const float* explore_u, float exp_prob, float* action, float* a_logp, float* rand_mask) {
   const int lane = threadIdx.x & 63;
+  if (dist) {  // trainable log-std: a standard deviation per action dimension
+    stdv = dist[lane & 31];
+    logp_const = dist[32];
+  }
   for (int env = blockIdx.x * 4 + (threadIdx.x >> 6); env < n; env += gridDim.x * 4) {
     // rand_action_mask = bernoulli(exp_prob) per env (ppo_agent.py:80-88): a uniform draw below the probability explores
     const bool deterministic = deterministic_all || (explore_u && !(explore_u[env] < exp_prob));
@@ -370,11 +386,17 @@ __global__ __launch_bounds__(256) void count_mask_kernel(const float* mask, int 
 }
 
 __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, const float* na, const float* old_logp, const float* adv,
-                                                         const float* mask, int M, float stdv, float logp_const, float clip, float bound_w,
-                                                         float reg_w, float loss_scale, const float* n_valid, float* d_mean, float* stats) {
+                                                         const float* mask, int M, float stdv, float logp_const, const float* dist, float clip, float bound_w,
+                                                         float reg_w, float loss_scale, const float* n_valid, float* d_mean, float* g_logstd, float* stats) {
   __shared__ float sh[4];
+  __shared__ float sh_ls[4][32];
   const int lane = threadIdx.x & 63;
   const float nv = fmaxf(n_valid[0], 1.f);
+  if (dist) {
+    stdv = dist[lane & 31];
+    logp_const = dist[32];
+  }
+  float gls = 0.f;  // d loss / d logstd[lane], this wave's rows
   float st_min = 0.f, st_clip = 0.f, st_ratio = 0.f, st_bound = 0.f, st_reg = 0.f;
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
     const bool valid = mask[r] == 1.0f;  // ppo_agent.py:229-233
@@ -400,6 +422,7 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, cons
       float g = 0.f;
       if (valid && lane < ADDHIP_NUM_DOF) g = g_logp * (d / stdv) + (bound_w * 2.f * viol + reg_w * 2.f * mu) / nv;
       d_mean[(size_t)r * 32 + lane] = loss_scale * g;
+      if (lane < ADDHIP_NUM_DOF) gls += loss_scale * g_logp * (d * d - 1.f);  // d logp / d logstd_j = d_j^2 - 1
     }
     if (valid && lane == 0) {
       st_min += fminf(l0, l1);
@@ -411,6 +434,11 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, cons
   }
   float t0 = block_sum(st_min, sh), t1 = block_sum(st_clip, sh), t2 = block_sum(st_ratio, sh), t3 = block_sum(st_bound, sh);
   float t5 = block_sum(st_reg, sh);
+  if (dist && g_logstd) {
+    if (lane < 32) sh_ls[threadIdx.x >> 6][lane] = gls;
+    __syncthreads();
+    if (threadIdx.x < ADDHIP_NUM_DOF) atomicAdd(&g_logstd[threadIdx.x], (sh_ls[0][threadIdx.x] + sh_ls[1][threadIdx.x]) + (sh_ls[2][threadIdx.x] + sh_ls[3][threadIdx.x]));
+  }
   if (threadIdx.x == 0) {  // per-minibatch MEANS over the exploring samples (ppo_agent.py:229-247): nv varies with exp_prob < 1
     atomicAdd(&stats[0], t0 / nv); atomicAdd(&stats[1], t1 / nv); atomicAdd(&stats[2], t2 / nv); atomicAdd(&stats[3], t3 / nv);
     if (reg_w != 0.f) atomicAdd(&stats[5], t5 / nv);
@@ -776,13 +804,20 @@ extern "C" int addhip_fill_uniform_at(float* out, int64_t count, uint64_t seed, 
   return addhip::check_launch("fill_uniform_kernel");
 }
 
-extern "C" int addhip_actor_sample(const float* mean, int32_t ld_mean, const float* noise, float stdv, float logp_const, const float* a_mean,
+extern "C" int addhip_dist_refresh(const float* logstd, float* dist, void* stream) {
+  ADDHIP_REQUIRE(logstd && dist, "dist_refresh: null argument");
+  ADDHIP_RECORDABLE(addhip_dist_refresh, logstd, dist);
+  hipLaunchKernelGGL(dist_refresh_kernel, dim3(1), dim3(64), 0, ST, logstd, dist);
+  return addhip::check_launch("dist_refresh_kernel");
+}
+
+extern "C" int addhip_actor_sample(const float* mean, int32_t ld_mean, const float* noise, float stdv, float logp_const, const float* dist, const float* a_mean,
                                    const float* a_std, int32_t num_envs, int32_t deterministic, const float* explore_u, float exp_prob, float* action,
                                    float* a_logp, float* rand_mask, void* stream) {
   ADDHIP_REQUIRE(mean && a_mean && a_std && action && a_logp && rand_mask && num_envs > 0, "actor_sample: bad arguments");
   ADDHIP_REQUIRE(deterministic || noise, "actor_sample: noise missing");
-  ADDHIP_RECORDABLE(addhip_actor_sample, mean, ld_mean, noise, stdv, logp_const, a_mean, a_std, num_envs, deterministic, explore_u, exp_prob, action, a_logp, rand_mask);
-  hipLaunchKernelGGL(actor_sample_kernel, dim3(row_grid(num_envs)), dim3(256), 0, ST, mean, ld_mean, noise, stdv, logp_const, a_mean, a_std,
+  ADDHIP_RECORDABLE(addhip_actor_sample, mean, ld_mean, noise, stdv, logp_const, dist, a_mean, a_std, num_envs, deterministic, explore_u, exp_prob, action, a_logp, rand_mask);
+  hipLaunchKernelGGL(actor_sample_kernel, dim3(row_grid(num_envs)), dim3(256), 0, ST, mean, ld_mean, noise, stdv, logp_const, dist, a_mean, a_std,
                      num_envs, deterministic, explore_u, exp_prob, action, a_logp, rand_mask);
   return addhip::check_launch("actor_sample_kernel");
 }
@@ -908,12 +943,13 @@ extern "C" int addhip_count_mask(const float* rand_mask, int32_t M, float* out, 
 }
 
 extern "C" int addhip_actor_loss(const float* mean, const float* norm_action, const float* old_logp, const float* adv, const float* rand_mask, int32_t M,
-                                 float stdv, float logp_const, float clip_ratio, float bound_weight, float reg_weight, float loss_scale,
-                                 const float* n_valid, float* d_mean, float* stats, void* stream) {
+                                 float stdv, float logp_const, const float* dist, float clip_ratio, float bound_weight, float reg_weight, float loss_scale,
+                                 const float* n_valid, float* d_mean, float* g_logstd, float* stats, void* stream) {
   ADDHIP_REQUIRE(mean && norm_action && old_logp && adv && rand_mask && n_valid && d_mean && stats && M > 0, "actor_loss: bad arguments");
-  ADDHIP_RECORDABLE(addhip_actor_loss, mean, norm_action, old_logp, adv, rand_mask, M, stdv, logp_const, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, stats);
+  ADDHIP_REQUIRE(!dist || g_logstd, "actor_loss: a trainable log-std (dist) needs g_logstd");
+  ADDHIP_RECORDABLE(addhip_actor_loss, mean, norm_action, old_logp, adv, rand_mask, M, stdv, logp_const, dist, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, g_logstd, stats);
   hipLaunchKernelGGL(actor_loss_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, mean, norm_action, old_logp, adv, rand_mask, M,
-                     stdv, logp_const, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, stats);
+                     stdv, logp_const, dist, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, g_logstd, stats);
   return addhip::check_launch("actor_loss_kernel");
 }
 

@@ -306,7 +306,8 @@ static int ppo_loss_impl(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, 
   // The head section: one launch (csrc/actor_head.hip: head forward, loss, gradient, backward step into the last hidden layer) where the
   // last hidden layer is 128 / 256 / 512 wide; the three 32-wide GEMMs + loss + column sums otherwise.
   const int head_slabs = addhip_actor_head_slabs(Mb);
-  const bool fused = (hA == 128 || hA == 256 || hA == 512) && (int64_t)head_slabs * (32 * hA + 32) <= A.slab_floats;
+  const bool fused = (hA == 128 || hA == 256 || hA == 512) && (int64_t)head_slabs * ADDHIP_ACTOR_HEAD_SLAB(hA) <= A.slab_floats;
+  ADDHIP_REQUIRE(!d->dist || d->g_logstd, "ppo_loss_fwd_bwd: a trainable log-std (dist) needs its gradient g_logstd");
   const bool planes = store_fmt(A) == ADDHIP_STORE_BF16X3;
   LAUNCH(addhip_count_mask(d->rand_mask, Mb, d->num_valid, stream));
   if (fused) {
@@ -315,7 +316,7 @@ static int ppo_loss_impl(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, 
     h.rows = Mb; h.hidden = hA;
     h.H = A.h[nA - 1]; h.Wh = A.Wh; h.bh = A.bh;
     h.norm_action = d->norm_action; h.old_logp = d->old_logp; h.adv = d->adv; h.rand_mask = d->rand_mask; h.n_valid = d->num_valid;
-    h.action_std = d->action_std; h.logp_const = d->logp_const; h.clip_ratio = d->ppo_clip_ratio; h.bound_weight = d->action_bound_weight;
+    h.action_std = d->action_std; h.logp_const = d->logp_const; h.dist = d->dist; h.clip_ratio = d->ppo_clip_ratio; h.bound_weight = d->action_bound_weight;
     h.reg_weight = d->action_reg_weight; h.loss_scale = d->grad_scale;
     h.dz = s16 ? nullptr : A.dz[nA - 1]; h.dz16 = s16 ? A.dz16[nA - 1] : nullptr; h.planes16 = store_fmt(A);
     h.slabs = A.slabs; h.num_slabs = head_slabs;
@@ -323,21 +324,23 @@ static int ppo_loss_impl(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, 
     h.stats = d->stats;
     h.amax = amax_of(A, AMAX_DZ + nA - 1);
     LAUNCH(addhip_actor_head(&h, stream));
-    const int64_t stride = 32LL * hA + 32;
-    if (A.gbh == A.gWh + 32LL * hA) {  // (the flat layout places a head's bias behind its weight)
-      LAUNCH(addhip_slab_reduce(A.slabs, head_slabs, stride, A.gWh, stride, 1.0f, 0, stream));
+    const int64_t stride = ADDHIP_ACTOR_HEAD_SLAB(hA);
+    const bool ls_follows = d->dist && d->g_logstd == A.gbh + 32;
+    if (A.gbh == A.gWh + 32LL * hA) {  // (the flat layout places a head's bias behind its weight, a trainable log-std behind the bias)
+      LAUNCH(addhip_slab_reduce(A.slabs, head_slabs, stride, A.gWh, 32LL * hA + (ls_follows ? 64 : 32), 1.0f, 0, stream));
     } else {
       LAUNCH(addhip_slab_reduce(A.slabs, head_slabs, stride, A.gWh, 32LL * hA, 1.0f, 0, stream));
-      LAUNCH(addhip_slab_reduce(A.slabs + 32LL * hA, head_slabs, stride, A.gbh, 32, 1.0f, 0, stream));
+      LAUNCH(addhip_slab_reduce(A.slabs + 32LL * hA, head_slabs, stride, A.gbh, ls_follows ? 64 : 32, 1.0f, 0, stream));
     }
+    if (d->dist && !ls_follows) LAUNCH(addhip_slab_reduce(A.slabs + 32LL * hA + 32, head_slabs, stride, d->g_logstd, 32, 1.0f, 0, stream));
   } else {
     {
       addhip_gemm_t g = gemm(Mb, 32, hA, A.h[nA - 1], hA, 1, A.Wh, hA, 1, d->mean, 32, ADDHIP_EPI_BIAS, A.bh);
       g.precision = d->head_precision;
       LAUNCH(addhip_gemm_f32(&g, stream));
     }
-    LAUNCH(addhip_actor_loss(d->mean, d->norm_action, d->old_logp, d->adv, d->rand_mask, Mb, d->action_std, d->logp_const, d->ppo_clip_ratio,
-                             d->action_bound_weight, d->action_reg_weight, d->grad_scale, d->num_valid, d->d_mean, d->stats, stream));
+    LAUNCH(addhip_actor_loss(d->mean, d->norm_action, d->old_logp, d->adv, d->rand_mask, Mb, d->action_std, d->logp_const, d->dist, d->ppo_clip_ratio,
+                             d->action_bound_weight, d->action_reg_weight, d->grad_scale, d->num_valid, d->d_mean, d->g_logstd, d->stats, stream));
     {  // head weight gradient: d_mean^T h over Mb rows, 32 K slices
       addhip_gemm_t g = gemm(32, hA, Mb, d->d_mean, 32, 0, A.h[nA - 1], hA, 0, A.slabs, hA);
       g.split_k = 32;
@@ -467,22 +470,23 @@ extern "C" int addhip_update_schedule(int32_t base, const addhip_ppo_marks_t* pp
   const int a0 = base, ea = base + ppo->actor_early, end_a = base + ppo->actor_end, ec = base + ppo->critic_early, end_ac = base + ppo->launches;
   const int d0 = end_ac, d_head = d0 + disc->head, d_gp = d0 + disc->chain, d_bwd = d0 + disc->backward, dw_first = d0 + disc->top_dw_first,
             dw_last = d0 + disc->top_dw_last, end_d = d0 + disc->launches;
-  // Actor and critic hand over everything but their first layers as soon as it is final; the collectives are issued in the order they
-  // become ready, because one communicator runs them in issue order.  The discriminator's section is the longest chain of the step, so
-  // its independent pieces run side by side on two streams: the logit loss and its backward step through the head (stream 3) beside the
-  // gradient-penalty chain (stream 2), then the top layer's weight gradient (stream 3, own split-K scratch) beside the dX GEMM and the
-  // first layer's.  {stream, first, last, wait_before, wait_after, bucket}
+  // Actor and critic hand over everything but their first layers as soon as it is final, then their two first layers as ONE bucket as
+  // soon as both are; the collectives are issued in the order they become ready, because one communicator runs them in issue order, and
+  // only the discriminator's -- the last section to finish -- is left with nothing to hide behind.  The discriminator's section is the
+  // longest chain of the step, so its independent pieces run side by side on two streams: the logit loss and its backward step through
+  // the head (stream 3) beside the gradient-penalty chain (stream 2), then the top layer's weight gradient (stream 3, own split-K
+  // scratch) beside the dX GEMM and the first layer's.  {stream, first, last, wait_before, wait_after, bucket}
   const addhip_section_t s[10] = {
       {0, a0, ea, -1, -1, 0},            // 0: actor up to its early mark -> bucket 0
       {1, end_a, ec, -1, -1, 1},         // 1: critic likewise -> bucket 1
-      {2, d0, d_head, -1, -1, -1},       // 2: L2 terms, forward
-      {3, d_head, d_gp, 2, -1, -1},      // 3: logit loss, head backward -> top dz
-      {2, d_gp, d_bwd, -1, -1, -1},      // 4: gradient-penalty chain
-      {3, d_bwd, dw_first, -1, -1, -1},  // 5: (bf16 storage without a pre-cast top gradient: its rounding)
-      {3, dw_first, dw_last, 4, -1, -1}, // 6: top-layer weight gradient (needs the chain's a2 / e1)
-      {2, dw_last, end_d, 5, 6, 2},      // 7: dX, first-layer weight gradient -> bucket 2 once section 6 is in too
-      {0, ea, end_a, -1, -1, -1},        // 8, 9: the two first layers (one bucket after the join: the host's)
-      {1, ec, end_ac, -1, -1, -1},
+      {1, ec, end_ac, -1, -1, -1},       // 2: the critic's first layer
+      {0, ea, end_a, -1, 2, 3},          // 3: the actor's first layer -> bucket 3 (both first layers) once section 2 is in too
+      {2, d0, d_head, -1, -1, -1},       // 4: L2 terms, forward
+      {3, d_head, d_gp, 4, -1, -1},      // 5: logit loss, head backward -> top dz
+      {2, d_gp, d_bwd, -1, -1, -1},      // 6: gradient-penalty chain
+      {3, d_bwd, dw_first, -1, -1, -1},  // 7: (bf16 storage without a pre-cast top gradient: its rounding)
+      {3, dw_first, dw_last, 6, -1, -1}, // 8: top-layer weight gradient (needs the chain's a2 / e1)
+      {2, dw_last, end_d, 7, 8, 2},      // 9: dX, first-layer weight gradient -> bucket 2 once section 8 is in too
   };
   for (int i = 0; i < 10; ++i) out[i] = s[i];
   return 10;

@@ -213,6 +213,8 @@ class ADDAgent(AgentIO):
         self._norm_adv_clip = float(c["norm_adv_clip"])
         self._action_bound_weight = float(c["action_bound_weight"])
         self._action_entropy_weight = float(c["action_entropy_weight"])  # ppo_agent.py:262-272
+        if self._action_entropy_weight != 0 and str(c["model"].get("actor_std_type", "FIXED")) != "FIXED":
+            raise NotImplementedError("agent.action_entropy_weight != 0 with a trainable log-std (the entropy's gradient) is not implemented")
         self._action_reg_weight = float(c["action_reg_weight"])
         self._critic_loss_weight = float(c["critic_loss_weight"])
         self._exp_anneal_samples = float(c.get("exp_anneal_samples", float("inf")))  # ppo_agent.py:32-34
@@ -236,7 +238,8 @@ class ADDAgent(AgentIO):
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
         from .model import split_k_for
 
-        need = 32 * 32 * m.actor.hidden[-1]  # actor-head weight-gradient slabs
+        # actor-head weight-gradient slabs: 32 K slices of the 32-wide GEMM, or one per workgroup of addhip_actor_head (<= 256)
+        need = max(32 * 32 * m.actor.hidden[-1], 256 * L.actor_head_slab(m.actor.hidden[-1]))
         for net in m.nets:
             for i, h in enumerate(net.hidden):
                 in_ld = net.in_ld if i == 0 else net.hidden[i - 1]
@@ -319,7 +322,7 @@ class ADDAgent(AgentIO):
         br = m.bucket_ranges
         # the plan and its schedule live in the library (include/addhip.h, "recorded plans"): one optimiser step's sections are ONE C
         # call (addhip_schedule_run: launches, stream forks / joins by HIP events, bucket call-backs), for this host or any other
-        self._schedule = Schedule(p, secs, 1 + len(self._side_streams), buckets=[br["actor_tail"], br["critic_tail"], br["disc"]])
+        self._schedule = Schedule(p, secs, 1 + len(self._side_streams), buckets=[br["actor_tail"], br["critic_tail"], br["disc"], br["first_layers"]])
 
         # ---- build-train-data: critic over the T+1 obs slots and the N obs_timeout rows, discriminator over the T*N
         # differences, in chunks of _eval_rows rows (plans prebuilt once like the act / update plans)
@@ -360,7 +363,8 @@ class ADDAgent(AgentIO):
         import ctypes as C
         ppo = L.PpoLossT(C.pointer(self._mlp_c["actor"]), C.pointer(self._mlp_c["critic"]), Mb, L.ptr(W["norm_obs"]), L.ptr(W["norm_obs16"]) if s16 else None,
                          L.ptr(W["mb_amax"][0]) if self._f16x2 else None, L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_tar"]), L.ptr(W["mb_mask"]), m.std32, m.logp_const,
-                         self._ppo_clip_ratio, self._action_bound_weight, self._action_reg_weight, self._critic_loss_weight, gs, self._prec_small,
+                         self._ppo_clip_ratio, self._action_bound_weight, self._action_reg_weight, self._critic_loss_weight, gs,
+                         m.dist_ptr(), m.g("actor", "logstd") if m.dist is not None else None, self._prec_small,
                          L.ptr(W["mean"]), L.ptr(W["d_mean"]), L.ptr(W["dv"]), L.ptr(W["nv"]), L.ptr(W["stats"]))
         o = (lambda k: L.ptr(W[k])) if s16 else (lambda k: None)
         f = (lambda k: None) if s16 else (lambda k: L.ptr(W[k]))
@@ -462,7 +466,7 @@ class ADDAgent(AgentIO):
                 else:
                     L.call("addhip_fill_uniform", L.ptr(W["explore_u"]), self.N, self._seed, (3 << 40) + self._iter * self.T + t, st)
                 explore_u = L.ptr(W["explore_u"])
-        L.call("addhip_actor_sample", L.ptr(W["mean"]), 32, L.ptr(W["noise"]), m.std32, m.logp_const, L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), self.N,
+        L.call("addhip_actor_sample", L.ptr(W["mean"]), 32, L.ptr(W["noise"]), m.std32, m.logp_const, m.dist_ptr(), L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), self.N,
                int(deterministic), explore_u, exp_prob, L.ptr(B["action"][slot_t]), L.ptr(B["a_logp"][slot_t]), L.ptr(B["rand_mask"][slot_t]), st)
 
     def _get_exp_prob(self):
@@ -646,6 +650,7 @@ class ADDAgent(AgentIO):
             o.step = m.opt_step
             L.call("addhip_optimizer_step", o, st)
             m.refresh_w_amax(st)  # (f16x2: the new parameters' tracked maximum, the scale of the next step's weight operands)
+            m.refresh_dist(st)    # (actor_std_type CONSTANT: std and the log-probability constant of the new log-std)
             if gathered is not None:
                 main.wait_event(gathered)
         return steps
@@ -683,9 +688,7 @@ class ADDAgent(AgentIO):
         # the sections on their streams: fork from `main`, event dependencies between sections, join back into `main`
         self._schedule.run([s.cuda_stream for s in streams], on_bucket if overlap else None)
         # (every loss coefficient of the plan carries 1/world, so the SUM over ranks is already the mean: no scaling pass)
-        if overlap:
-            a, b = m.bucket_ranges["first_layers"]
-            pending.append(D.all_reduce_sum_async(m.grads[a:b]))
+        if overlap:  # (four buckets: actor tail, critic tail, the two first layers, discriminator -- each issued where it became final)
             D.wait_all(pending)
         elif exchange:
             D.all_reduce_sum_(m.grads)

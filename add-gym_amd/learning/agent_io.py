@@ -93,7 +93,7 @@ class AgentIO:
         """torch.optim.AdamW.state_dict() layout over the 22 trainable tensors in registration order (mp_optimizer.py:48-52)."""
         m = self._model
         ea, es = m.export(m.exp_avg), m.export(m.exp_avg_sq)
-        keys = [k for k in ea if k != "_model._action_dist._logstd_net"]
+        keys = [k for k in ea if k != "_model._action_dist._logstd_net" or m.std_type == "CONSTANT"]  # (a FIXED log-std is not trainable: no optimiser state)
         if self._opt_type == "SGD":  # torch.optim.SGD.state_dict(): one momentum buffer per parameter
             state = {i: {"momentum_buffer": ea[k]} for i, k in enumerate(keys)} if m.opt_step > 0 else {}
             group = dict(lr=self._lr, momentum=0.9, dampening=0, weight_decay=self._wd, nesterov=False, maximize=False, foreach=None,
@@ -128,11 +128,11 @@ class AgentIO:
         Nm["d_cnt"].copy_(sd["_disc_obs_norm._count"])
         Nm["d_abs"][:tk.disc_dim] = sd["_disc_obs_norm._mean_abs"].to(self._device)
         if opt is not None and opt.get("state") and "momentum_buffer" in opt["state"][0]:
-            keys = [k for k in m.export() if k != "_model._action_dist._logstd_net"]
+            keys = [k for k in m.export() if k != "_model._action_dist._logstd_net" or m.std_type == "CONSTANT"]  # (a FIXED log-std is not trainable: no optimiser state)
             m.load({k: opt["state"][i]["momentum_buffer"] for i, k in enumerate(keys)}, m.exp_avg)
             m.opt_step = max(m.opt_step, 1)  # (torch's SGD keeps no step count: any value > 0 means "buffers are live")
         elif opt is not None and opt.get("state"):
-            keys = [k for k in m.export() if k != "_model._action_dist._logstd_net"]
+            keys = [k for k in m.export() if k != "_model._action_dist._logstd_net" or m.std_type == "CONSTANT"]  # (a FIXED log-std is not trainable: no optimiser state)
             ea = {k: opt["state"][i]["exp_avg"] for i, k in enumerate(keys)}
             es = {k: opt["state"][i]["exp_avg_sq"] for i, k in enumerate(keys)}
             m.load(ea, m.exp_avg)

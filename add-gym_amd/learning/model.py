@@ -50,8 +50,14 @@ class Model:
         self.disc = Mlp("disc", disc_dim, disc_ld, build_net_sizes(model_cfg["disc_net"]), 1)
         self.nets = [self.actor, self.critic, self.disc]
         self.action_std = float(model_cfg["action_std"])
-        if model_cfg.get("actor_std_type", "FIXED") != "FIXED":
-            raise NotImplementedError("only actor_std_type FIXED (configs/agent/add_g1.yaml) is implemented")
+        # distribution_gaussian_diag.py:19-45.  FIXED: the log-std is a constant (a scalar argument of the kernels).  CONSTANT: one trainable
+        # log-std per action dimension -- 32 floats behind the actor head's bias in the flat buffers (gradient, AdamW state, the actor's
+        # exchange bucket all follow from that), from which addhip_dist_refresh derives the kernels' `dist` vector after every change.
+        self.std_type = str(model_cfg.get("actor_std_type", "FIXED"))
+        if self.std_type not in ("FIXED", "CONSTANT"):
+            raise NotImplementedError("actor_std_type VARIABLE (a second head on the actor) is not implemented: FIXED or CONSTANT")
+        if self.std_type == "CONSTANT":
+            self.actor.specs.append(("logstd", (32,)))
         self.init_output_scale = float(model_cfg["actor_init_output_scale"])
         # Flat layout, chosen for the data-parallel exchange (each bucket one contiguous range, in the order the gradients
         # become final during a backward pass): [actor W1.. head][critic W1.. head][discriminator][actor W0 b0][critic W0 b0]
@@ -82,7 +88,9 @@ class Model:
         self.opt_step = 0
         self.params16 = None  # bf16 shadow of params (agent.matmul_precision = bf16), refreshed after every optimiser step
         self.w_amax = None    # tracked maximum |parameter| (agent.matmul_precision = f16x2: the scale of every weight operand), likewise
+        self.dist = torch.zeros(L.DIST_FLOATS, device=device) if self.std_type == "CONSTANT" else None
         self._init_params(seed)
+        self.refresh_dist()
         # distribution_gaussian_diag.py:24-31, 63-94: fp32 logstd vector -> std and the log-prob constant
         logstd = torch.full((L.NUM_DOF,), float(math.log(self.action_std)), dtype=torch.float32)
         self.std32 = float(torch.exp(logstd)[0].item())
@@ -134,11 +142,20 @@ class Model:
             L.call("addhip_fill_zero", L.ptr(self.w_amax), L.AMAX_SLOTS, stream)
             L.call("addhip_amax_f32", L.ptr(self.params), self.count, L.ptr(self.w_amax), stream)
 
+    def refresh_dist(self, stream=None):
+        """actor_std_type CONSTANT: std / log-probability constant / entropy from the current log-std (one launch, in stream order)."""
+        if self.dist is not None:
+            L.call("addhip_dist_refresh", self.p("actor", "logstd"), L.ptr(self.dist), L.current_stream() if stream is None else stream)
+
+    def dist_ptr(self):
+        return None if self.dist is None else L.ptr(self.dist)
+
     def refresh_shadow(self, stream=None):
         """Derived parameter state after the parameters changed (optimiser step, load, broadcast): params16 = bf16(params), round to nearest
         even, + the transposed copies in one launch (storage modes); the tracked maximum (f16x2)."""
         st = L.current_stream() if stream is None else stream
         self.refresh_w_amax(st)
+        self.refresh_dist(st)
         if self.params16 is not None:
             offs, rows, cols, n = self._shadow_table
             L.call("addhip_shadow_refresh", L.ptr(self.params), L.ptr(self.params16), L.ptr(self.params16t), self.count, offs, rows, cols, n, self.shadow_planes, st)
@@ -180,6 +197,10 @@ class Model:
             wh = self.view(net.name, "Wh")
             wh.zero_()
             wh[:net.head_dim] = uniform((net.head_dim, fan_in), bound).to(self.device)
+        if self.std_type == "CONSTANT":  # distribution_gaussian_diag.py:25, 32-37
+            ls = self.view("actor", "logstd")
+            ls.zero_()
+            ls[:L.NUM_DOF] = float(math.log(self.action_std))
 
     # ---- reference checkpoint keys <-> flat buffers
     def _key_map(self):
@@ -190,6 +211,8 @@ class Model:
             for i in range(len(net.hidden)):
                 m.append((f"{prefix}.{2 * i}.weight", net, f"W{i}"))
                 m.append((f"{prefix}.{2 * i}.bias", net, f"b{i}"))
+            if net is self.actor and self.std_type == "CONSTANT":  # (registered before the mean head: distribution_gaussian_diag.py:19-37)
+                m.append(("_model._action_dist._logstd_net", net, "logstd"))
             m.append((f"{head}.weight", net, "Wh"))
             m.append((f"{head}.bias", net, "bh"))
         return m
@@ -200,6 +223,8 @@ class Model:
             return (net.hidden[i], net.in_dim if i == 0 else net.hidden[i - 1])
         if key.startswith("b") and key != "bh":
             return (net.hidden[int(key[1:])],)
+        if key == "logstd":
+            return (L.NUM_DOF,)
         return (net.head_dim, net.hidden[-1]) if key == "Wh" else (net.head_dim,)
 
     def export(self, buf=None):
@@ -212,7 +237,7 @@ class Model:
                 v = v[:shape[0], :shape[1]]
             else:
                 v = v[:shape[0]]
-            if name == "_model._action_dist._mean_net.weight":  # the reference's registration order: logstd precedes the mean head
+            if name == "_model._action_dist._mean_net.weight" and self.std_type == "FIXED":  # the reference's registration order: logstd precedes the mean head
                 out["_model._action_dist._logstd_net"] = torch.full((L.NUM_DOF,), float(math.log(self.action_std)), dtype=torch.float32)
             out[name] = v.detach().clone().cpu()
         return out

@@ -360,8 +360,14 @@ int addhip_col_sum_ordered(const float* X, int32_t M, int32_t N, int32_t ld, flo
  *      deterministic != 0: mode for every env (test mode).  Otherwise, with explore_u [N] uniforms in [0,1) (or NULL =
  *      always explore): env n samples iff explore_u[n] < exp_prob, else takes the mode and gets rand_mask 0
  *      (rand_action_mask = bernoulli(exp_prob), ppo_agent.py:80-88, 161-168) ---- */
+/* The policy's standard deviation.  actor_std_type FIXED (distribution_gaussian_diag.py:26-31): the scalar arguments `std`, `logp_const`
+ * of the calls below, `dist` = NULL.  actor_std_type CONSTANT (:32-37, a trainable log-std per action dimension): `dist` points at
+ * ADDHIP_DIST_FLOATS device floats kept current by addhip_dist_refresh -- [0, 29) std_j = exp(logstd_j), [32] the log-probability
+ * constant fl32(-0.5*29*log(2pi)) - sum(logstd), [33] the entropy sum(logstd) + 0.5*29*log(2 pi e) -- and the scalars are ignored. */
+#define ADDHIP_DIST_FLOATS 64
+int addhip_dist_refresh(const float* logstd /*[29]*/, float* dist /*[ADDHIP_DIST_FLOATS]*/, void* stream);
 int addhip_actor_sample(const float* mean, int32_t ld_mean, const float* noise /*[N,29] N(0,1)*/, float std,
-                        float logp_const /* fl32(-0.5*29*log(2pi)) - sum(logstd) */, const float* a_mean, const float* a_std, int32_t num_envs,
+                        float logp_const /* fl32(-0.5*29*log(2pi)) - sum(logstd) */, const float* dist /* or NULL */, const float* a_mean, const float* a_std, int32_t num_envs,
                         int32_t deterministic, const float* explore_u, float exp_prob, float* action /*[N,32]*/, float* a_logp,
                         float* rand_mask, void* stream);
 
@@ -436,18 +442,21 @@ int addhip_gather_minibatch(const addhip_gather_t* g, void* stream);
  * regulariser reg_weight * mean(sum mean^2) (action_reg_weight, ppo_agent.py:268-272, distribution_gaussian_diag.py:113-116; the
  * entropy term of :262-266 is a constant for the fixed-std policy and has no gradient).
  * d_mean[M,32] = d loss / d mean;  stats[0..3] += means over the exploring samples of {min-term, clipped?, ratio, bound},
- * stats[5] += mean of sum mean^2 (only when reg_weight != 0) */
+ * stats[5] += mean of sum mean^2 (only when reg_weight != 0).
+ * With `dist` (trainable log-std): g_logstd[j] += d loss / d logstd_j = sum_rows d loss/d logp * (((a_j - mean_j) / std_j)^2 - 1)
+ * (float atomics; :90-94 differentiated). */
 int addhip_actor_loss(const float* mean, const float* norm_action, const float* old_logp, const float* adv,
-                      const float* rand_mask, int32_t M, float std, float logp_const, float clip_ratio,
+                      const float* rand_mask, int32_t M, float std, float logp_const, const float* dist /* or NULL */, float clip_ratio,
                       float bound_weight, float reg_weight, float loss_scale, const float* n_valid /*device [1]*/, float* d_mean,
-                      float* stats, void* stream);
+                      float* g_logstd /* [29], with dist */, float* stats, void* stream);
 /* The actor's head section as ONE launch: mean = H Wh^T + bh (DistributionGaussianDiagBuilder.forward, distribution_gaussian_diag.py:47-58),
  * addhip_actor_loss on it (same arguments, same stats slots), and the backward step through the head into the last hidden layer:
  *   dz = (d_mean Wh) * (H > 0)   -> dz [rows, hidden] fp32 and / or dz16 (ADDHIP_STORE_* format planes16),
  *   db_top[k] += sum_rows dz     -> added to row (workgroup % gb_replicas) of gb_top [gb_replicas, ld_gb] (gb_replicas = 1: plain atomics on one row),
- *   (dWh | dbh) partial sums     -> slabs [num_slabs][32 * hidden + 32], one per workgroup, to be combined by
- *                                   addhip_slab_reduce(slabs, num_slabs, 32 * hidden + 32, gWh, 32 * hidden + 32, 1, 0) when the head's
- *                                   bias gradient directly follows its weight gradient in memory (or by two calls).
+ *   (dWh | dbh | dlogstd) partial sums -> slabs [num_slabs][ADDHIP_ACTOR_HEAD_SLAB(hidden) = 32 * hidden + 64], one per workgroup, to be
+ *                                   combined by addhip_slab_reduce(slabs, num_slabs, 32 * hidden + 64, gWh, 32 * hidden + 32, 1, 0) when the
+ *                                   head's bias gradient directly follows its weight gradient in memory (or by two calls); with `dist`
+ *                                   the last 32 floats of a slab are the log-std gradient's partial sums (zeros without).
  * Replaces three 32-wide GEMM launches + addhip_actor_loss + addhip_col_sum of the step (csrc/actor_head.hip).  hidden: 128, 256 or 512;
  * Wh [32, hidden] with zero rows past ADDHIP_NUM_DOF; num_slabs = addhip_actor_head_slabs(rows). */
 typedef struct {
@@ -455,12 +464,14 @@ typedef struct {
   const float* H; const float* Wh; const float* bh;
   const float* norm_action; const float* old_logp; const float* adv; const float* rand_mask; const float* n_valid;
   float action_std, logp_const, clip_ratio, bound_weight, reg_weight, loss_scale;
+  const float* dist;        /* trainable log-std (addhip_dist_refresh) or NULL: the scalars above */
   float* dz; uint16_t* dz16; int32_t planes16;
   float* slabs; int32_t num_slabs;
   float* gb_top; int32_t gb_replicas, ld_gb;
   float* stats;
   uint32_t* amax;           /* optional: max |dz| into ADDHIP_AMAX_SLOTS slots (caller zeroes) */
 } addhip_actor_head_t;
+#define ADDHIP_ACTOR_HEAD_SLAB(hidden) (32 * (hidden) + 64)
 int addhip_actor_head_slabs(int32_t rows);
 int addhip_actor_head(const addhip_actor_head_t* p, void* stream);
 /* count of rand_mask == 1 -> out[0] */
@@ -683,6 +694,7 @@ typedef struct {
   const float* norm_action;                       /* [Mb, 32] */
   const float* old_logp; const float* adv; const float* tar_val; const float* rand_mask;   /* [Mb] */
   float action_std, logp_const, ppo_clip_ratio, action_bound_weight, action_reg_weight, critic_loss_weight, grad_scale;
+  const float* dist; float* g_logstd;             /* actor_std_type CONSTANT: addhip_dist_refresh's vector and the log-std's gradient [32] (NULL: FIXED) */
   int32_t head_precision;                         /* ADDHIP_PREC_* of the three 32-wide head GEMMs (fp32 operands in every mode) */
   float* mean; float* d_mean;                     /* workspace [Mb, 32] each */
   float* dv;                                      /* workspace [Mb] */
@@ -720,7 +732,8 @@ int addhip_disc_loss_fwd_bwd(const addhip_disc_loss_t* d, addhip_disc_marks_t* m
 
 /* The schedule of one optimiser step recorded as  addhip_ppo_loss_fwd_bwd  then  addhip_disc_loss_fwd_bwd  into a plan whose size was
  * `base` before the first: ten sections on four streams (actor | critic | discriminator x 2), buckets 0 = actor but its first layer,
- * 1 = critic likewise, 2 = discriminator (the two first layers are final after the join).  -> out[0..10), returns 10. */
+ * 1 = critic likewise, 3 = the two first layers, 2 = discriminator -- reported in that order (0, 1, 3, 2: the order in which they become
+ * final, so that only the last one's exchange has no launches left to overlap).  -> out[0..10), returns 10. */
 int addhip_update_schedule(int32_t base, const addhip_ppo_marks_t* ppo, const addhip_disc_marks_t* disc, addhip_section_t* out, int32_t capacity);
 
 #ifdef __cplusplus

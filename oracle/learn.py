@@ -28,13 +28,36 @@ PARAM_SHAPES = [
 ]
 
 
-def synth_params(seed, obs_dim=264, disc_dim=114, bias_scale=0.02):
+# hidden layer widths of the reference's net modules (nets/fc_*layers_*units.py: layer_sizes), by module name (nets/net_builder.py:5-11)
+NET_LAYERS = {"fc_3layers_1024units": [1024, 1024, 512], "fc_2layers_1024units": [1024, 512], "fc_2layers_512units": [512, 256],
+              "fc_2layers_256units": [256, 128], "fc_2layers_128units": [128, 64], "fc_2layers_64units": [64, 32]}
+
+
+def param_shapes(nets=None, obs_dim=264, disc_dim=114):
+    """PARAM_SHAPES for a choice of net modules {"actor_net": ..., "critic_net": ..., "disc_net": ...} (None: add_g1.yaml's)."""
+    nets = {"actor_net": "fc_3layers_1024units", "critic_net": "fc_3layers_1024units", "disc_net": "fc_2layers_1024units", **(nets or {})}
+    out = []
+    for key, prefix, head, in_dim, head_dim in (("actor_net", "_model._actor_layers", "_model._action_dist._mean_net", obs_dim, 29),
+                                                ("critic_net", "_model._critic_layers", "_model._critic_out", obs_dim, 1),
+                                                ("disc_net", "_model._disc_layers", "_model._disc_logits", disc_dim, 1)):
+        prev = in_dim
+        for i, h in enumerate(NET_LAYERS[nets[key]]):
+            out += [(f"{prefix}.{2 * i}.weight", (h, prev)), (f"{prefix}.{2 * i}.bias", (h,))]
+            prev = h
+        out += [(f"{head}.weight", (head_dim, prev)), (f"{head}.bias", (head_dim,))]
+    return out
+
+
+LOGSTD_KEY = "_model._action_dist._logstd_net"
+
+
+def synth_params(seed, obs_dim=264, disc_dim=114, bias_scale=0.02, nets=None, logstd=False):
     """Deterministic parameter set (numpy legacy RandomState: stable across versions) used by
     fixtures instead of shipping 17 MB of weights.  Same distributions as the reference's init
      except that biases are non-zero so that bias gradients/ReLU masks are exercised."""
     rng = np.random.RandomState(seed)
     out = {}
-    for name, shape in PARAM_SHAPES:
+    for name, shape in (PARAM_SHAPES if nets is None else param_shapes(nets)):
         shape = tuple(obs_dim if (s == 264) else disc_dim if (s == 114) else s for s in shape)
         if name.endswith("weight"):
             fan_in = shape[1]
@@ -46,6 +69,14 @@ def synth_params(seed, obs_dim=264, disc_dim=114, bias_scale=0.02):
             out[name] = rng.uniform(-bound, bound, size=shape).astype(F)
         else:
             out[name] = (rng.uniform(-1, 1, size=shape) * bias_scale).astype(F)
+    if logstd:  # a trainable log-std (actor_std_type CONSTANT), different per action dimension, at its place in the registration order
+        ls = (np.log(0.05) + np.random.RandomState(seed + 7919).uniform(-0.4, 0.4, size=29)).astype(F)
+        ordered = {}
+        for k, v in out.items():
+            if k == "_model._action_dist._mean_net.weight":
+                ordered[LOGSTD_KEY] = ls
+            ordered[k] = v
+        out = ordered
     return out
 
 
@@ -156,16 +187,26 @@ class Model:
 
     def __init__(self, params, action_std=0.05):
         self.p = {k: torch.tensor(np.asarray(v, F)).to(_DTYPE).requires_grad_(True) for k, v in params.items()}
-        # distribution_gaussian_diag.py:24-31, 63-67: fixed fp32 logstd vector, std = exp(logstd)
-        self.logstd = torch.full((29,), float(np.log(action_std)), dtype=torch.float32)
-        self.std = torch.exp(self.logstd).to(_DTYPE)
-        self.logstd = self.logstd.to(_DTYPE)
+        # distribution_gaussian_diag.py:24-31, 63-67: fixed fp32 logstd vector, std = exp(logstd).  A parameter set that holds LOGSTD_KEY is
+        # the CONSTANT std type (:32-37): the log-std is one more trainable tensor, registered before the mean head
+        fixed = torch.full((29,), float(np.log(action_std)), dtype=torch.float32)
+        self._std_fixed = torch.exp(fixed).to(_DTYPE)
+        self._logstd_fixed = fixed.to(_DTYPE)
+
+    @property
+    def logstd(self):
+        return self.p[LOGSTD_KEY] if LOGSTD_KEY in self.p else self._logstd_fixed
+
+    @property
+    def std(self):
+        return torch.exp(self.p[LOGSTD_KEY]) if LOGSTD_KEY in self.p else self._std_fixed
 
     def names(self):
-        return [n for n, _ in PARAM_SHAPES]
+        return list(self.p)  # (registration order: the order of PARAM_SHAPES / param_shapes())
 
-    def _mlp(self, x, prefix, idxs):
-        for i in idxs:
+    def _mlp(self, x, prefix, idxs=None):
+        # (every hidden layer the parameter set holds for this stack: Sequential indices 0, 2, 4, ...)
+        for i in sorted(int(k[len(prefix) + 1:].split(".")[0]) for k in self.p if k.startswith(prefix + ".") and k.endswith(".weight")):
             x = torch.relu(torch.nn.functional.linear(x, self.p[f"{prefix}.{i}.weight"], self.p[f"{prefix}.{i}.bias"]))
         return x
 

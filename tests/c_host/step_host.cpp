@@ -127,7 +127,7 @@ int main() {
     norm += mx;
     for (size_t k = 0; k < g_plan[i].size(); ++k) worst = std::fmax(worst, std::fabs(g_plan[i][k] - g_direct[i][k]) / mx);
   }
-  printf("launches=%d buckets=%d order=%d,%d,%d grad_scale=%.3e worst_rel_diff=%.3e\n", addhip_plan_size(plan), g_buckets, seen[0], seen[1], seen[2], norm, worst);
+  printf("launches=%d buckets=%d order=%d,%d,%d,%d grad_scale=%.3e worst_rel_diff=%.3e\n", addhip_plan_size(plan), g_buckets, seen[0], seen[1], seen[2], seen[3], norm, worst);
   ADD(addhip_schedule_destroy(step));
   ADD(addhip_plan_destroy(plan));
   for (void* p : g_allocs) (void)hipFree(p);

@@ -55,7 +55,8 @@ def test_cpp_host_without_pytorch_runs_the_step_on_the_gpu(tmp_path):
                     "-Wl,-rpath," + libdir], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
-    m = re.search(r"launches=(\d+) buckets=(\d+) order=(\d+),(\d+),(\d+) grad_scale=([\d.e+-]+) worst_rel_diff=([\d.e+-]+)", r.stdout)
+    m = re.search(r"launches=(\d+) buckets=(\d+) order=(\d+),(\d+),(\d+),(\d+) grad_scale=([\d.e+-]+) worst_rel_diff=([\d.e+-]+)", r.stdout)
     assert m, r.stdout
-    assert int(m.group(1)) >= 50 and int(m.group(2)) == 3 and [int(m.group(i)) for i in (3, 4, 5)] == [0, 1, 2]
-    assert float(m.group(6)) > 0 and float(m.group(7)) < 1e-4
+    # four exchange buckets, reported where they become final: actor tail, critic tail, the two first layers (3), the discriminator (2)
+    assert int(m.group(1)) >= 50 and int(m.group(2)) == 4 and [int(m.group(i)) for i in (3, 4, 5, 6)] == [0, 1, 3, 2]
+    assert float(m.group(7)) > 0 and float(m.group(8)) < 1e-4

@@ -74,18 +74,41 @@ def test_minibatch_loss_gradients_and_adamw_match_reference(precision):
     minibatch_loss_gradients_and_adamw(precision)
 
 
-def minibatch_loss_gradients_and_adamw(precision="fp32"):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])  # (fp32-class modes: this fixture's 12-sigma actions amplify bf16 storage rounding to tens of percent)
+def test_other_net_modules_match_reference(precision):
+    """agent.model.{actor,critic,disc}_net other than add_g1.yaml's (the reference's net registry, nets/net_builder.py:5-11): a 256/128
+    actor, a 512/256 critic, a 128/64 discriminator through the same update plan (the 128-wide actor head takes the fused kernel),
+    against gradients and parameters the reference produced with those modules (tools/gen_golden_agent.py: gen_losses_small_nets)."""
+    minibatch_loss_gradients_and_adamw(precision, "losses_small_nets")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])  # (fp32-class modes: this fixture's 12-sigma actions amplify bf16 storage rounding to tens of percent)
+def test_trainable_log_std_matches_reference(precision):
+    """agent.model.actor_std_type CONSTANT (distribution_gaussian_diag.py:32-37): one trainable log-std per action dimension -- its gradient
+    through the fused actor head, its AdamW step, the refreshed std / log-probability constant of the next step -- against the reference's
+    gradients and parameters (tools/gen_golden_agent.py: gen_losses_constant_std)."""
+    minibatch_loss_gradients_and_adamw(precision, "losses_constant_std")
+
+
+def minibatch_loss_gradients_and_adamw(precision="fp32", fixture="losses"):
     """(At this fixture's 256 rows every GEMM is below the size from which the bf16-MFMA kernels are dispatched, so the three
     modes run the same kernels here; the modes themselves are pinned at full size in tests/test_hip_fullsize.py.)"""
     import torch
     import add_gym_amd._lib as L
 
-    g = gload("losses")
+    import json
+
+    g = gload(fixture)
+    nets = json.loads(str(g["nets"])) if "nets" in g.files else None
     M = g["in.obs"].shape[0]
     cfg = make_cfg(M // 4, steps_per_iter=8, matmul_precision=precision)
+    cfg["agent"]["model"].update(nets or {})
+    logstd = "logstd" in g.files
+    if logstd:
+        cfg["agent"]["model"]["actor_std_type"] = "CONSTANT"
     ag = make_agent(cfg, [gload("motion_small")["frames"]], [1.0])
     assert ag.Mb == M
-    params = OL.synth_params(int(g["seed"]))
+    params = OL.synth_params(int(g["seed"]), nets=nets, logstd=logstd)
     ag._model.load({k: torch.tensor(v) for k, v in params.items()})
     on = OL.Normalizer(264, g["obs_mean"], g["obs_std"])
     an = OL.Normalizer(29, g["a_mean"], g["a_std"])
@@ -114,7 +137,7 @@ def minibatch_loss_gradients_and_adamw(precision="fp32"):
         m.grads.zero_()  # zero_grad: _run_update_sections does it before the sections fork
         ag._update_plan.run(st)
         torch.cuda.synchronize()
-        grads_hip = {k: v.numpy() for k, v in m.export(m.grads).items() if k != "_model._action_dist._logstd_net"}
+        grads_hip = {k: v.numpy() for k, v in m.export(m.grads).items() if k != OL.LOGSTD_KEY or logstd}
         loss, info = OL.compute_loss(model, OL.LossCfg(), mb)
         grads_orc = opt.step(loss)
         if step == 0:
@@ -122,7 +145,11 @@ def minibatch_loss_gradients_and_adamw(precision="fp32"):
             for k, go in grads_orc.items():
                 gh = grads_hip[k]
                 scale = np.abs(go).max() + 1e-12
-                assert np.abs(gh - go).max() <= 2e-4 * scale + 1e-9, (k, float(np.abs(gh - go).max()), float(scale))
+                # (the fixture's actions lie ~12 sigma out: |logp| ~ 2e3, where one fp32 ulp is 1.2e-4 -- the importance ratio, and with it
+                # every actor gradient, carries that much noise in ANY fp32 evaluation order, torch's included: tests/test_oracle_vs_golden.py)
+                # (measured over the precision modes: up to 3.1e-4 of a tensor's largest gradient; the golden summaries below are held to 5e-4)
+                tol = 4e-4 if "_actor_layers" in k or "_action_dist" in k else 2e-4
+                assert np.abs(gh - go).max() <= tol * scale + 1e-9, (k, float(np.abs(gh - go).max()), float(scale))
             # (2) against the reference's own gradients (golden summaries)
             _check_summary(g, "grad", grads_hip, rtol=5e-4)
             # logged scalars of the step
@@ -138,7 +165,7 @@ def minibatch_loss_gradients_and_adamw(precision="fp32"):
         m.refresh_shadow()  # (what the agent's own optimiser step keeps current: the plane-storage shadow, the tracked parameter maximum)
         torch.cuda.synchronize()
         if step in (0, 2):
-            ph = {k: v.numpy() for k, v in m.export().items() if k != "_model._action_dist._logstd_net"}
+            ph = {k: v.numpy() for k, v in m.export().items() if k != OL.LOGSTD_KEY or logstd}
             # Adam's early steps move every weight by ~lr*sign(g): where a gradient is ~0 its sign is rounding noise, so
             # a few elements may differ by up to 2*lr per step; everything else must agree to fp32 rounding
             _check_param_summary(g, f"param{step + 1}", ph, step + 1)

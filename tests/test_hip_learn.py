@@ -39,12 +39,15 @@ def logp_const():
     return float((-0.5 * 29 * np.log(2.0 * np.pi) - torch.sum(logstd)).item()), float(torch.exp(logstd)[0].item())
 
 
-def test_actor_sample_matches_reference_golden():
+@pytest.mark.parametrize("name", ["actor_step", "actor_step_constant_std"])
+def test_actor_sample_matches_reference_golden(name):
+    """(`_constant_std`: actor_std_type CONSTANT -- a trainable log-std per action dimension through addhip_dist_refresh's vector.)"""
     import torch
     import add_gym_amd._lib as L
 
-    g = gload("actor_step")
-    model = OL.Model(OL.synth_params(int(g["seed"])))
+    g = gload(name)
+    params = OL.synth_params(int(g["seed"]), logstd=name.endswith("constant_std"))
+    model = OL.Model(params)
     on = OL.Normalizer(264, g["obs_mean"], g["obs_std"])
     with torch.no_grad():
         mean = model.actor_mean(OL.t32(on.normalize(g["obs"]))).numpy()
@@ -52,10 +55,21 @@ def test_actor_sample_matches_reference_golden():
     mean32 = np.zeros((n, 32), F)
     mean32[:, :29] = mean
     c, std = logp_const()
+    dist = None
+    if OL.LOGSTD_KEY in params:  # the scalars are ignored then
+        dist_t = torch.zeros(L.DIST_FLOATS, device="cuda")
+        L.call("addhip_dist_refresh", P(T(params[OL.LOGSTD_KEY])), L.ptr(dist_t), L.current_stream())
+        torch.cuda.synchronize()
+        ls = params[OL.LOGSTD_KEY]
+        np.testing.assert_allclose(dist_t.cpu().numpy()[:29], np.exp(ls), rtol=2e-7)
+        c = float(dist_t[32])
+        np.testing.assert_allclose(c, -0.5 * 29 * np.log(2 * np.pi) - ls.astype(np.float64).sum(), rtol=1e-6)
+        np.testing.assert_allclose(float(dist_t[33]), ls.astype(np.float64).sum() + 0.5 * 29 * np.log(2 * np.pi * np.e), rtol=1e-6)
+        dist, std = L.ptr(dist_t), float("nan")
     act = torch.zeros(n, 32, device="cuda")
     logp = torch.zeros(n, device="cuda")
     mask = torch.zeros(n, device="cuda")
-    L.call("addhip_actor_sample", P(T(mean32)), 32, P(T(g["noise"])), std, c, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0, None, 1.0,
+    L.call("addhip_actor_sample", P(T(mean32)), 32, P(T(g["noise"])), std, c if dist is None else float("nan"), dist, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0, None, 1.0,
            L.ptr(act), L.ptr(logp), L.ptr(mask), L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(act.cpu().numpy()[:, :29], g["action"], rtol=0, atol=1e-5)
@@ -64,7 +78,7 @@ def test_actor_sample_matches_reference_golden():
     # exploration probability < 1 (ppo_agent.py:80-88): env i explores iff u[i] < p, else it takes the mode with mask 0
     u = np.random.default_rng(3).random(n).astype(F)
     act2, logp2, mask2 = torch.zeros(n, 32, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-    L.call("addhip_actor_sample", P(T(mean32)), 32, P(T(g["noise"])), std, c, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0, P(T(u)), 0.5,
+    L.call("addhip_actor_sample", P(T(mean32)), 32, P(T(g["noise"])), std, c, dist, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0, P(T(u)), 0.5,
            L.ptr(act2), L.ptr(logp2), L.ptr(mask2), L.current_stream())
     torch.cuda.synchronize()
     ex = u < 0.5
@@ -240,7 +254,9 @@ def test_gather_minibatch():
         assert np.array_equal(o[k].cpu().numpy(), sc[kk][idx])
 
 
-def test_actor_loss_head_gradient():
+@pytest.mark.parametrize("trainable_std", [False, True])
+def test_actor_loss_head_gradient(trainable_std):
+    """(trainable_std: actor_std_type CONSTANT -- per-dimension standard deviations, and d loss / d logstd against autograd.)"""
     import torch
     import add_gym_amd._lib as L
 
@@ -253,8 +269,18 @@ def test_actor_loss_head_gradient():
     mask = (rng.rand(M) < 0.9).astype(F)
     c, std = logp_const()
     mt = torch.tensor(mean, requires_grad=True)
-    d = (torch.tensor(na) - mt) / std
-    logp = -0.5 * torch.sum(d * d, -1) + c
+    dist, gls = None, torch.zeros(32, device="cuda")
+    if trainable_std:
+        lst = torch.tensor((np.log(0.05) + rng.uniform(-0.4, 0.4, 29)).astype(F), requires_grad=True)
+        na = (mean + rng.standard_normal((M, 29)) * np.exp(lst.detach().numpy())).astype(F)
+        d = (torch.tensor(na) - mt) / torch.exp(lst)
+        logp = -0.5 * torch.sum(d * d, -1) + (-0.5 * 29 * np.log(2.0 * np.pi) - torch.sum(lst))  # distribution_gaussian_diag.py:90-94
+        dist_t = torch.zeros(L.DIST_FLOATS, device="cuda")
+        L.call("addhip_dist_refresh", P(T(lst.detach().numpy())), L.ptr(dist_t), L.current_stream())
+        dist = L.ptr(dist_t)
+    else:
+        d = (torch.tensor(na) - mt) / std
+        logp = -0.5 * torch.sum(d * d, -1) + c
     old = (logp.detach() + torch.tensor(rng.standard_normal(M).astype(F) * 0.3)).numpy()
     sel = torch.tensor(mask) == 1.0
     ratio = torch.exp(logp - torch.tensor(old))[sel]
@@ -270,10 +296,14 @@ def test_actor_loss_head_gradient():
     stats = torch.zeros(8, device="cuda")
     dmask = T(mask)
     L.call("addhip_count_mask", L.ptr(dmask), M, L.ptr(nv), L.current_stream())
-    L.call("addhip_actor_loss", P(T(pad(mean))), P(T(pad(na))), P(T(old)), P(T(adv)), L.ptr(dmask), M, std, c, 0.2, 10.0, 0.3, 1.0, L.ptr(nv),
-           L.ptr(dm), L.ptr(stats), L.current_stream())
+    L.call("addhip_actor_loss", P(T(pad(mean))), P(T(pad(na))), P(T(old)), P(T(adv)), L.ptr(dmask), M, std, c, dist, 0.2, 10.0, 0.3, 1.0, L.ptr(nv),
+           L.ptr(dm), L.ptr(gls) if trainable_std else None, L.ptr(stats), L.current_stream())
     torch.cuda.synchronize()
     assert float(nv.item()) == mask.sum()
+    if trainable_std:
+        gl = lst.grad.numpy()
+        np.testing.assert_allclose(gls.cpu().numpy()[:29], gl, rtol=2e-4, atol=2e-4 * np.abs(gl).max())
+        assert float(gls[29:].abs().max()) == 0.0
     g = mt.grad.numpy()
     np.testing.assert_allclose(dm.cpu().numpy()[:, :29], g, rtol=2e-4, atol=1e-6 + 2e-4 * np.abs(g).max())
     s = stats.cpu().numpy()
@@ -638,8 +668,8 @@ def test_fixed_order_reductions_repeat_bit_for_bit():
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-3)
 
 
-@pytest.mark.parametrize("hidden,rows", [(512, 4000), (256, 129), (128, 32)])
-def test_fused_actor_head_equals_the_unfused_sequence(hidden, rows):
+@pytest.mark.parametrize("hidden,rows,trainable_std", [(512, 4000, False), (256, 129, False), (128, 32, False), (512, 1500, True), (128, 70, True)])
+def test_fused_actor_head_equals_the_unfused_sequence(hidden, rows, trainable_std):
     """addhip_actor_head (csrc/actor_head.hip) against the launches it replaces -- head GEMM, addhip_actor_loss, weight-gradient GEMM + slab
     reduce, column sums, dz GEMM with the ReLU mask -- on the same inputs: dz, d loss / d Wh, d bh, the top layer's bias gradient and the
     loss diagnostics; ragged row counts, masked-out samples, action-bound violations."""
@@ -665,10 +695,16 @@ def test_fused_actor_head_equals_the_unfused_sequence(hidden, rows):
     nv = z(1)
     L.call("addhip_count_mask", L.ptr(dmask), M, L.ptr(nv), st)
     std, logp_const, clip, bw, rw, ls = 0.05, float(-0.5 * 29 * np.log(2 * np.pi) - 29 * np.log(0.05)), 0.2, 10.0, 0.01, 0.5
+    dist, want_gls = None, z(32)
+    if trainable_std:  # actor_std_type CONSTANT: standard deviations ~1 so that the unit-normal actions above stay a few sigma out
+        dist_t = z(L.DIST_FLOATS)
+        L.call("addhip_dist_refresh", P(T(rng.uniform(-0.4, 0.4, 29).astype(F))), L.ptr(dist_t), st)
+        dist = L.ptr(dist_t)
     # --- the unfused sequence
     mean, d_mean, stats_a = z(M, 32), z(M, 32), z(8)
     L.call("addhip_gemm_f32", gemm(M, 32, K, L.ptr(H), K, 1, L.ptr(dWh), K, 1, L.ptr(mean), 32, L.EPI_BIAS, L.ptr(dbh)), st)
-    L.call("addhip_actor_loss", L.ptr(mean), L.ptr(dna), L.ptr(dol), L.ptr(dadv), L.ptr(dmask), M, std, logp_const, clip, bw, rw, ls, L.ptr(nv), L.ptr(d_mean), L.ptr(stats_a), st)
+    L.call("addhip_actor_loss", L.ptr(mean), L.ptr(dna), L.ptr(dol), L.ptr(dadv), L.ptr(dmask), M, std, logp_const, dist, clip, bw, rw, ls, L.ptr(nv), L.ptr(d_mean),
+           L.ptr(want_gls) if trainable_std else None, L.ptr(stats_a), st)
     torch.cuda.synchronize()
     dm64, H64 = d_mean.cpu().numpy().astype(np.float64), H.cpu().numpy().astype(np.float64)
     want_gW, want_gb = dm64.T @ H64, dm64.sum(0)
@@ -676,14 +712,19 @@ def test_fused_actor_head_equals_the_unfused_sequence(hidden, rows):
     # --- one launch
     ns = L.load().addhip_actor_head_slabs(M)
     dz, dz16 = z(M, K), torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
-    slabs, gb_top, stats_b = torch.full((ns, 32 * K + 32), 7.0, device="cuda"), z(4, K), z(8)
+    SL = L.actor_head_slab(K)
+    slabs, gb_top, stats_b = torch.full((ns, SL), 7.0, device="cuda"), z(4, K), z(8)
     amax = torch.zeros(L.AMAX_SLOTS, dtype=torch.int32, device="cuda")
-    h = L.ActorHeadT(M, K, L.ptr(H), L.ptr(dWh), L.ptr(dbh), L.ptr(dna), L.ptr(dol), L.ptr(dadv), L.ptr(dmask), L.ptr(nv), std, logp_const, clip, bw, rw, ls,
+    h = L.ActorHeadT(M, K, L.ptr(H), L.ptr(dWh), L.ptr(dbh), L.ptr(dna), L.ptr(dol), L.ptr(dadv), L.ptr(dmask), L.ptr(nv), std, logp_const, clip, bw, rw, ls, dist,
                      L.ptr(dz), L.ptr(dz16), L.STORE_BF16, L.ptr(slabs), ns, L.ptr(gb_top), 4, K, L.ptr(stats_b), L.ptr(amax))
     L.call("addhip_actor_head", h, st)
-    out = z(32 * K + 32)
-    L.call("addhip_slab_reduce", L.ptr(slabs), ns, 32 * K + 32, L.ptr(out), 32 * K + 32, 1.0, 0, st)
+    out = z(SL)
+    L.call("addhip_slab_reduce", L.ptr(slabs), ns, SL, L.ptr(out), SL, 1.0, 0, st)
     torch.cuda.synchronize()
+    # d loss / d logstd: the slab's last 32 floats (zeros without a trainable log-std)
+    gl = want_gls.cpu().numpy()
+    np.testing.assert_allclose(out[32 * K + 32:].cpu().numpy(), gl, rtol=1e-4, atol=2e-5 * np.abs(gl).max())
+    assert trainable_std == (np.abs(gl).max() > 0)
     scale = np.abs(want_dz).max()
     assert scale > 0
     np.testing.assert_allclose(dz.cpu().numpy(), want_dz, rtol=1e-4, atol=2e-5 * scale)
@@ -691,7 +732,7 @@ def test_fused_actor_head_equals_the_unfused_sequence(hidden, rows):
     assert float(amax.cpu().numpy().view(np.float32).max()) == float(dz.abs().max())
     gW = out[:32 * K].view(32, K).cpu().numpy()
     np.testing.assert_allclose(gW, want_gW, rtol=1e-4, atol=2e-5 * np.abs(want_gW).max())
-    np.testing.assert_allclose(out[32 * K:].cpu().numpy(), want_gb, rtol=1e-4, atol=2e-5 * np.abs(want_gb).max())
+    np.testing.assert_allclose(out[32 * K:32 * K + 32].cpu().numpy(), want_gb, rtol=1e-4, atol=2e-5 * np.abs(want_gb).max())
     np.testing.assert_allclose(gb_top.sum(0).cpu().numpy(), want_dz.sum(0), rtol=1e-3, atol=1e-4 * np.abs(want_dz).sum(0).max())
     np.testing.assert_allclose(stats_b.cpu().numpy(), stats_a.cpu().numpy(), rtol=2e-5, atol=1e-6)
     assert float(gW[29:].max()) == 0.0 and float(np.abs(gW[29:]).max()) == 0.0  # padding rows of the head receive no gradient

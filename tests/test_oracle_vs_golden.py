@@ -235,9 +235,11 @@ def test_normalizers():
     close(dn.normalize(g["yq"]), g["yq_norm"])
 
 
-def test_actor_step():
-    g = gload("actor_step")
-    model = L.Model(L.synth_params(int(g["seed"])))
+@pytest.mark.parametrize("name", ["actor_step", "actor_step_constant_std"])
+def test_actor_step(name):
+    """(`_constant_std`: actor_std_type CONSTANT -- a standard deviation per action dimension, distribution_gaussian_diag.py:32-37, 47-58.)"""
+    g = gload(name)
+    model = L.Model(L.synth_params(int(g["seed"]), logstd=name.endswith("constant_std")))
     on = L.Normalizer(264, g["obs_mean"], g["obs_std"])
     an = L.Normalizer(29, g["a_mean"], g["a_std"])
     a, logp, _ = L.actor_step(model, on, an, g["obs"], g["noise"], g["rand_action_mask"])
@@ -274,9 +276,17 @@ def _check_summary(g, prefix, named, rtol, atol_scale=1.0):
         np.testing.assert_allclose(sample, g[f"{prefix}.{name}.sample"], rtol=rtol * 20, atol=rtol * atol_scale * max(ref_l2 / np.sqrt(np.asarray(val).size), 1e-12) * 20)
 
 
-def test_losses_grads_adamw():
-    g = gload("losses")
-    model = L.Model(L.synth_params(int(g["seed"])))
+def golden_nets(g):
+    """The net modules a losses fixture was generated with (None: add_g1.yaml's)."""
+    import json
+
+    return json.loads(str(g["nets"])) if "nets" in g.files else None
+
+
+@pytest.mark.parametrize("name", ["losses", "losses_small_nets", "losses_constant_std"])
+def test_losses_grads_adamw(name):
+    g = gload(name)
+    model = L.Model(L.synth_params(int(g["seed"]), nets=golden_nets(g), logstd="logstd" in g.files))
     on = L.Normalizer(264, g["obs_mean"], g["obs_std"])
     an = L.Normalizer(29, g["a_mean"], g["a_std"])
     dn = L.DiffNormalizer(114)

@@ -117,8 +117,8 @@ def test_composite_entry_points_record_their_launches():
     secs = (L.SectionT * 10)()
     assert lib.addhip_update_schedule(5, C.byref(pm), C.byref(dm), secs, 10) == 10
     got = [(s.stream, s.first, s.last, s.wait_before, s.wait_after, s.bucket) for s in secs]
-    assert got == [(0, 5, 25, -1, -1, 0), (1, 35, 55, -1, -1, 1), (2, 65, 75, -1, -1, -1), (3, 75, 77, 2, -1, -1), (2, 77, 85, -1, -1, -1),
-                   (3, 85, 86, -1, -1, -1), (3, 86, 89, 4, -1, -1), (2, 89, 105, 5, 6, 2), (0, 25, 35, -1, -1, -1), (1, 55, 65, -1, -1, -1)]
+    assert got == [(0, 5, 25, -1, -1, 0), (1, 35, 55, -1, -1, 1), (1, 55, 65, -1, -1, -1), (0, 25, 35, -1, 2, 3), (2, 65, 75, -1, -1, -1),
+                   (3, 75, 77, 4, -1, -1), (2, 77, 85, -1, -1, -1), (3, 85, 86, -1, -1, -1), (3, 86, 89, 6, -1, -1), (2, 89, 105, 7, 8, 2)]
     assert lib.addhip_update_schedule(5, C.byref(pm), C.byref(dm), secs, 9) != 0
 
 

@@ -13,8 +13,8 @@ for M in (32 * 256, 32 * 512, 32 * 1024, 32 * 2048):
     na = torch.zeros(M, 32, device=dev); na[:, :29] = torch.randn(M, 29, device=dev)
     ol, adv, mask, nv = torch.randn(M, device=dev) * 0.3 - 30, torch.randn(M, device=dev), torch.ones(M, device=dev), torch.full((1,), float(M), device=dev)
     ns = L.load().addhip_actor_head_slabs(M)
-    dz, slabs, gb, stats = torch.zeros(M, K, device=dev), torch.zeros(ns, 32 * K + 32, device=dev), torch.zeros(16, K, device=dev), torch.zeros(8, device=dev)
-    h = L.ActorHeadT(M, K, L.ptr(H), L.ptr(Wh), L.ptr(bh), L.ptr(na), L.ptr(ol), L.ptr(adv), L.ptr(mask), L.ptr(nv), 0.05, 40.0, 0.2, 10.0, 0.0, 1.0,
+    dz, slabs, gb, stats = torch.zeros(M, K, device=dev), torch.zeros(ns, L.actor_head_slab(K), device=dev), torch.zeros(16, K, device=dev), torch.zeros(8, device=dev)
+    h = L.ActorHeadT(M, K, L.ptr(H), L.ptr(Wh), L.ptr(bh), L.ptr(na), L.ptr(ol), L.ptr(adv), L.ptr(mask), L.ptr(nv), 0.05, 40.0, 0.2, 10.0, 0.0, 1.0, None,
                      L.ptr(dz), None, 0, L.ptr(slabs), ns, L.ptr(gb), 16, K, L.ptr(stats), None)
     for _ in range(5): L.call("addhip_actor_head", h, st.cuda_stream)
     torch.cuda.synchronize()

@@ -1,6 +1,7 @@
 """Agent-level golden fixtures (task layer, learner, full iteration) taken from the reference's
 ADDAgent running on tools/ref_harness.FakeEngine.  Build-container tooling only."""
 import contextlib
+import json
 import os
 import sys
 
@@ -10,7 +11,7 @@ import torch
 import ref_harness as H
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.learn import PARAM_SHAPES, synth_params  # noqa: E402  (shared deterministic weights)
+from oracle.learn import PARAM_SHAPES, param_shapes, synth_params  # noqa: E402  (shared deterministic weights)
 
 
 def _save(name, **arrays):
@@ -55,7 +56,7 @@ class DrawLog:
         return out
 
 
-def build_agent(num_envs, clip_frames=200, seed=3, two_clip=False, task_over=None, **agent_over):
+def build_agent(num_envs, clip_frames=200, seed=3, two_clip=False, task_over=None, model_over=None, **agent_over):
     from add_gym.learning.add.add_agent import ADDAgent
 
     if two_clip:
@@ -67,14 +68,16 @@ def build_agent(num_envs, clip_frames=200, seed=3, two_clip=False, task_over=Non
     cfg = H.load_ref_config(num_envs, mf, **agent_over)
     if task_over:
         cfg["task"].update(task_over)
+    if model_over:
+        cfg["agent"]["model"].update(model_over)
     torch.manual_seed(seed)
     ag = ADDAgent(cfg)
     return ag, cfg
 
 
-def load_synth(ag, seed):
+def load_synth(ag, seed, nets=None, logstd=False):
     sd = ag.state_dict()
-    for k, v in synth_params(seed).items():
+    for k, v in synth_params(seed, nets=nets, logstd=logstd).items():
         assert tuple(sd[k].shape) == v.shape, k
         sd[k] = T(v)
     ag.load_state_dict(sd)
@@ -239,10 +242,10 @@ def gen_sampler():
           fd_in=tt, fd_out=(tt // 0.01) * 0.01)
 
 
-def gen_actor_step():
+def gen_actor_step(name="actor_step", logstd=False):
     n = 96
-    ag, cfg = build_agent(n)
-    load_synth(ag, 101)
+    ag, cfg = build_agent(n, model_over={"actor_std_type": "CONSTANT"} if logstd else None)
+    load_synth(ag, 101, logstd=logstd)
     rng = np.random.RandomState(2)
     ag._reset_envs()
     randomize_sim(ag, rng, 6.0)
@@ -254,7 +257,7 @@ def gen_actor_step():
     log = DrawLog()
     with log.recording(), torch.no_grad():
         a, a_info = ag._decide_action(obs, None)
-    _save("actor_step", seed=101, obs=obs, obs_mean=ag._obs_norm._mean, obs_std=ag._obs_norm._std,
+    _save(name, seed=101, obs=obs, obs_mean=ag._obs_norm._mean, obs_std=ag._obs_norm._std,
           a_mean=ag._a_norm._mean, a_std=ag._a_norm._std, noise=log.take("normal")[0], action=a, a_logp=a_info["a_logp"],
           rand_action_mask=a_info["rand_action_mask"])
 
@@ -295,11 +298,25 @@ def param_summary(named):
     return out
 
 
-def gen_losses():
+SMALL_NETS = dict(actor_net="fc_2layers_256units", critic_net="fc_2layers_512units", disc_net="fc_2layers_128units")
+
+
+def gen_losses_small_nets():
+    """The same minibatch through other modules of the reference's net registry (nets/net_builder.py:5-11): a two-layer actor and
+    critic of different widths and a 128/64 discriminator."""
+    gen_losses("losses_small_nets", SMALL_NETS)
+
+
+def gen_losses_constant_std():
+    """actor_std_type CONSTANT (distribution_gaussian_diag.py:32-37): the log-std is a trainable vector, different per action dimension here."""
+    gen_losses("losses_constant_std", None, logstd=True)
+
+
+def gen_losses(name="losses", nets=None, logstd=False):
     n = 64
     M = 256
-    ag, cfg = build_agent(n)
-    load_synth(ag, 202)
+    ag, cfg = build_agent(n, model_over=dict(nets or {}, **({"actor_std_type": "CONSTANT"} if logstd else {})))
+    load_synth(ag, 202, nets, logstd)
     rng = np.random.RandomState(17)
     # non-trivial normalisers
     ag._obs_norm._mean[:] = T(rng.standard_normal(264).astype(np.float32) * 0.3)
@@ -323,7 +340,12 @@ def gen_losses():
     out = {"in." + k: v for k, v in inp.items()}
     out.update(obs_mean=ag._obs_norm._mean, obs_std=ag._obs_norm._std, disc_mean_abs=ag._disc_obs_norm._mean_abs,
                a_mean=ag._a_norm._mean, a_std=ag._a_norm._std, seed=202)
-    names = [n_ for n_, _ in PARAM_SHAPES]
+    names = list(synth_params(202, nets=nets, logstd=logstd))  # (registration order)
+    assert names == [n_ for n_, p_ in ag.named_parameters() if p_.requires_grad and n_ in names] and len(names) == sum(p_.requires_grad for p_ in ag.parameters())
+    if nets is not None:
+        out["nets"] = np.array(json.dumps(nets))
+    if logstd:
+        out["logstd"] = np.array(1)
     sd_params = dict(ag.named_parameters())
     for step in range(3):
         info = ag._compute_loss({k: v.clone() for k, v in inp.items()})
@@ -334,7 +356,7 @@ def gen_losses():
             out.update({"grad." + k: v for k, v in param_summary({n_: sd_params[n_].grad for n_ in names}).items()})
         if step in (0, 2):
             out.update({f"param{step + 1}." + k: v for k, v in param_summary({n_: sd_params[n_] for n_ in names}).items()})
-    _save("losses", **out)
+    _save(name, **out)
 
 
 def gen_normalizers():
@@ -574,4 +596,4 @@ def gen_test_rollout():
 
 
 AGENT_GENS = dict(loop_1iter_two=gen_loop_1iter_two, loop_1iter_time=gen_loop_1iter_time, logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
-                  td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
+                  td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, losses_small_nets=gen_losses_small_nets, losses_constant_std=gen_losses_constant_std, actor_step_constant_std=lambda: gen_actor_step("actor_step_constant_std", True), normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
