@@ -371,13 +371,38 @@ __global__ __launch_bounds__(256) void slab_reduce_pair_kernel(const float4* in,
     }
     return;
   }
-  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < count2; n += gridDim.x * blockDim.x) {
+  // 64 columns per workgroup; wave w adds rows w, w + 4, w + 8, ... in increasing order (eight loads in flight), the four partial sums are
+  // added in wave order: a FIXED order whatever the launch -- with agent.deterministic there are rows / 32 replica rows (512 at the headline's
+  // minibatch), which one thread per column walking them all took 1.2 ms per launch for
+  __shared__ float part[4][64];
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int n0 = blockIdx.x * 64; n0 < count2; n0 += gridDim.x * 64) {
+    const int n = n0 + c;
     float s = 0.f;
-    for (int r = 0; r < rows2; ++r) {
-      s += in2[(size_t)r * ld2 + n];
-      if (clear2) in2[(size_t)r * ld2 + n] = 0.f;
+    if (n < count2) {
+      int r = w;
+      for (; r + 28 < rows2; r += 32) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = in2[(size_t)(r + 4 * k) * ld2 + n];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          s += v[k];
+          if (clear2) in2[(size_t)(r + 4 * k) * ld2 + n] = 0.f;
+        }
+      }
+      for (; r < rows2; r += 4) {
+        s += in2[(size_t)r * ld2 + n];
+        if (clear2) in2[(size_t)r * ld2 + n] = 0.f;
+      }
     }
-    out2[n] = accumulate2 ? out2[n] + s : s;
+    part[w][c] = s;
+    __syncthreads();
+    if (w == 0 && n < count2) {
+      const float t = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+      out2[n] = accumulate2 ? out2[n] + t : t;
+    }
+    __syncthreads();
   }
 }
 
@@ -391,8 +416,17 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* X, int M, int
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   float s = 0.f;
-  if (c < N)
-    for (int r = r0 + w; r < r1; r += 4) s += X[(size_t)r * ld + c];
+  if (c < N) {
+    int r = r0 + w;
+    for (; r + 28 < r1; r += 32) {  // eight loads in flight, added in row order
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = X[(size_t)(r + 4 * k) * ld + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; r < r1; r += 4) s += X[(size_t)r * ld + c];
+  }
   part[w][threadIdx.x & 63] = s;
   __syncthreads();
   if (w == 0 && c < N) {
@@ -410,8 +444,17 @@ __global__ __launch_bounds__(256) void col_sum_slices_kernel(const float* X, int
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   float s = 0.f;
-  if (c < N)
-    for (int r = r0 + w; r < r1; r += 4) s += X[(size_t)r * ld + c];
+  if (c < N) {
+    int r = r0 + w;
+    for (; r + 28 < r1; r += 32) {  // eight loads in flight, added in row order
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = X[(size_t)(r + 4 * k) * ld + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; r < r1; r += 4) s += X[(size_t)r * ld + c];
+  }
   part[w][threadIdx.x & 63] = s;
   __syncthreads();
   if (w == 0 && c < N) scratch[(size_t)blockIdx.y * N + c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
@@ -599,7 +642,7 @@ extern "C" int addhip_slab_reduce_pair(const float* in, int32_t slabs, int64_t s
   ADDHIP_RECORDABLE(addhip_slab_reduce_pair, in, slabs, slab_stride, out, count, scale, accumulate, in2, rows2, ld2, out2, count2, accumulate2, clear2);
   long long b4 = (count / 4 + 255) / 256;
   if (b4 > 2048) b4 = 2048;
-  const long long b2 = (count2 + 255) / 256;
+  const long long b2 = (count2 + 63) / 64;
   if (b4 < b2) b4 = b2;
   hipLaunchKernelGGL(slab_reduce_pair_kernel, dim3((unsigned)b4, 2), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(in), slabs,
                      (long long)slab_stride / 4, reinterpret_cast<float4*>(out), (long long)count / 4, scale, accumulate, in2, rows2, ld2, out2, count2, accumulate2,

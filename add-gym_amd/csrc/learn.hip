@@ -591,14 +591,30 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* v, cons
   if (amax) amax_commit(amax, amx);
 }
 
+// 64 outputs per workgroup; wave w adds the partials of workgroups w, w + 4, ... in increasing order (eight loads in flight), the four sums are
+// added in wave order: a fixed order
 __global__ __launch_bounds__(256) void head_backward_combine_kernel(const float* ordered, int blocks, int K, float* dW, float* db, float* dbt) {
-  const int i = blockIdx.x * 256 + threadIdx.x;  // 0..K) dW, K..2K) dbt, 2K db
-  if (i > 2 * K) return;
-  float* out = i < K ? (dW ? dW + i : nullptr) : i < 2 * K ? (dbt ? dbt + (i - K) : nullptr) : db;
-  if (!out) return;
+  __shared__ float part[4][64];
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;  // 0..K) dW, K..2K) dbt, 2K db
+  const size_t stride = (size_t)(2 * K + 4);
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += ordered[(size_t)b * (2 * K + 4) + i];
-  *out += s;  // (the outputs are accumulated into, as the atomics form does)
+  if (i <= 2 * K) {
+    int b = w;
+    for (; b + 28 < blocks; b += 32) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = ordered[(size_t)(b + 4 * k) * stride + i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; b < blocks; b += 4) s += ordered[(size_t)b * stride + i];
+  }
+  part[w][c] = s;
+  __syncthreads();
+  if (w != 0 || i > 2 * K) return;
+  float* out = i < K ? (dW ? dW + i : nullptr) : i < 2 * K ? (dbt ? dbt + (i - K) : nullptr) : db;
+  if (out) *out += ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];  // (the outputs are accumulated into, as the atomics form does)
 }
 
 __global__ __launch_bounds__(256) void grad_penalty_kernel(const float* g, int ld, int dim, int M, float coef, float* G, unsigned short* G16, int planes16, float* stats, unsigned* amax) {
@@ -997,7 +1013,7 @@ extern "C" int addhip_head_backward(const float* v, const float* w, const float*
   const int grid = row_grid(rows) < 256 ? row_grid(rows) : 256;
   hipLaunchKernelGGL(head_backward_kernel, dim3(grid), dim3(256), 0, ST, v, w, H, ld, K, (long long)rows, dZ, dZ16, planes16, dW_head, db_head, db_top, amax,
                      ordered_scratch);
-  if (ordered_scratch) hipLaunchKernelGGL(head_backward_combine_kernel, dim3((2 * K + 1 + 255) / 256), dim3(256), 0, ST, ordered_scratch, grid, K, dW_head, db_head, db_top);
+  if (ordered_scratch) hipLaunchKernelGGL(head_backward_combine_kernel, dim3((2 * K + 1 + 63) / 64), dim3(256), 0, ST, ordered_scratch, grid, K, dW_head, db_head, db_top);
   return addhip::check_launch("head_backward_kernel");
 }
 

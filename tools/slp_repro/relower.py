@@ -64,6 +64,26 @@ STAGE2 = {
 }
 
 
+# Stage 4: the faulty lowering needs the whole kernel around it (the 8-instruction dataflow alone, pk_repro/, compiles correctly), which
+# points behind instruction selection: which machine pass?  One switched off at a time.
+STAGE4 = {
+    "slp-no-subreg-liveness": ([], None, ["-enable-subreg-liveness=false"]),
+    "slp-no-coalescer": ([], None, ["-join-liveintervals=false"]),
+    "slp-regalloc-basic": ([], None, ["-vgpr-regalloc=basic"]),
+    "slp-no-rewrite-partial-reg-uses": ([], None, ["-amdgpu-enable-rewrite-partial-reg-uses=false"]),
+    "slp-no-machine-cse": ([], None, ["-disable-machine-cse"]),
+    "slp-no-machine-sink": ([], None, ["-disable-machine-sink"]),
+    "slp-no-peephole": ([], None, ["-disable-peephole"]),
+    "slp-no-dce-in-ra": ([], None, ["-amdgpu-dce-in-ra=false"]),
+    "slp-no-vgpr-liverange-opt": ([], None, ["-amdgpu-opt-vgpr-liverange=false"]),
+    "slp-no-early-ifcvt": ([], None, ["-amdgpu-early-ifcvt=false", "-disable-early-ifcvt"]),
+    "slp-no-pre-ra-opts": ([], None, ["-amdgpu-enable-pre-ra-optimizations=false"]),
+    "slp-no-copyprop": ([], None, ["-disable-copyprop"]),
+    "slp-no-scalar-ir-passes": ([], None, ["-amdgpu-scalar-ir-passes=false"]),
+    "slp-no-cgp": ([], None, ["-disable-cgp"]),
+    "slp-no-load-store-vectorizer": ([], None, ["-amdgpu-load-store-vectorizer=false"]),
+}
+
 # Stage 3: stage 2 says it is the <2 x float> fadd / fsub / fmul (963 in the kernel): scalarized alone they cure it, nothing else does, and
 # disabling the DAG combiner does not.  Which of them?  All of them scalarized EXCEPT one window of the file order: a variant is wrong
 # exactly when its window holds an instruction whose vector lowering is wrong.
@@ -91,6 +111,7 @@ def build(variants=VARIANTS, log="build.log"):
     irs = {}
     report = []
     for name, (fe, edit, llc) in variants.items():
+      try:
         key = " ".join(fe)
         if key not in irs:
             ll = os.path.join(OUT, "ir_" + ("noslp" if fe else "slp") + ".ll")
@@ -140,6 +161,10 @@ def build(variants=VARIANTS, log="build.log"):
             os.remove(f)
         report.append(f"{name:22s} <2 x float> arithmetic in IR {vec2:5d}   v_pk_* in rigid_step4_kernel<false> {pk:4d} of {insts} instructions")
         print(report[-1], flush=True)
+      except RuntimeError as e:  # (some switches crash this llc: reported, not run)
+        msg = "the compiler crashed" if "PrintStackTrace" in str(e) else str(e).splitlines()[-1][:120]
+        report.append(f"{name:22s} NOT BUILT: {msg}")
+        print(report[-1], flush=True)
     open(os.path.join(OUT, log), "w").write("\n".join(report) + "\n")
 
 
@@ -150,6 +175,11 @@ def run_all(variants=VARIANTS, log="build.log", out_name="slp_relower.log"):
     with open(out, "w") as f:
         for name in variants:
             lib = os.path.join(OUT, f"libaddhip_{name}.so")
+            if not os.path.exists(lib):
+                line = f"{name:22s} not built | {build_log.get(name, '').strip()}"
+                print(line, flush=True)
+                f.write(line + "\n")
+                continue
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "slp_repro", "gpu_case.py"), lib], capture_output=True, text=True, timeout=300)
             cases = [l for l in r.stdout.splitlines() if l.startswith("CASE")]
             verdict = "WRONG" if any("WRONG" in c for c in cases) else ("ok" if len(cases) == 2 else "FAILED " + r.stderr[-300:])
@@ -159,8 +189,13 @@ def run_all(variants=VARIANTS, log="build.log", out_name="slp_relower.log"):
 
 
 if __name__ == "__main__":
-    s3 = stage3(*(int(x) for x in sys.argv[2:5])) if len(sys.argv) > 2 else stage3()
-    tag = "_".join(sys.argv[2:5])
+    if len(sys.argv) > 2 and ":" in sys.argv[2]:  # explicit windows  a:b,c:d,...
+        s3 = {f"slp-vector-arith-only-{w.replace(':', '-')}": ([], f"unvec:farith@{w}", []) for w in sys.argv[2].split(",")}
+        tag = "w" + str(abs(hash(sys.argv[2])) % 100000) if len(sys.argv) < 4 else sys.argv[3]
+    else:
+        s3 = stage3(*(int(x) for x in sys.argv[2:5])) if len(sys.argv) > 2 else stage3()
+        tag = "_".join(sys.argv[2:5])
     {"build": build, "run": run_all, "build2": lambda: build(STAGE2, "build2.log"),
      "run2": lambda: run_all(STAGE2, "build2.log", "slp_relower2.log"),
+     "build4": lambda: build(STAGE4, "build3_stage4.log"), "run4": lambda: run_all(STAGE4, "build3_stage4.log", "slp_relower4.log"),
      "build3": lambda: build(s3, f"build3_{tag}.log"), "run3": lambda: run_all(s3, f"build3_{tag}.log", f"slp_relower3_{tag}.log")}[sys.argv[1]]()
