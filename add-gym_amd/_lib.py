@@ -33,7 +33,7 @@ class TaskT(C.Structure):
                 ("pose_w", C.c_float), ("vel_w", C.c_float), ("root_pose_w", C.c_float), ("root_vel_w", C.c_float),
                 ("pose_scale", C.c_float), ("vel_scale", C.c_float), ("root_pose_scale", C.c_float), ("root_vel_scale", C.c_float),
                 ("obs_dim", C.c_int32), ("obs_stride", C.c_int32), ("disc_dim", C.c_int32), ("disc_stride", C.c_int32),
-                ("enable_vel_obs", C.c_int32), ("enable_phase_obs", C.c_int32), ("num_phase_encoding", C.c_int32)]
+                ("enable_vel_obs", C.c_int32), ("enable_phase_obs", C.c_int32), ("num_phase_encoding", C.c_int32), ("num_disc_obs_steps", C.c_int32)]
 
 
 class EnvT(C.Structure):

@@ -108,7 +108,10 @@ __device__ __forceinline__ int disc_src(const addhip_task_t& t, int o, bool demo
   if (o >= t.disc_dim) return OFF_ZERO;
   constexpr int pw = 3 + 6 + ADDHIP_NUM_DOF;  // 38
   const int sw = pw + (t.enable_vel_obs ? 6 + ADDHIP_NUM_DOF : 0);
-  const int s = o / sw, c = o - s * sw;
+  const int c = o - (o / sw) * sw;
+  // step s of S = t.num_disc_obs_steps, oldest first: the last one is the current pose / the reference frame, the ones before it the
+  // history rows / the earlier clip frames (S = 2: one of each)
+  const int s = (o / sw == t.num_disc_obs_steps - 1) ? 2 : o / sw;
   const int row = demo ? (s == 0 ? R_DEMO0 : (s == 1 ? R_DEMO1 : R_REF)) : (s == 0 ? R_H0 : (s == 1 ? R_H1 : R_SIM));
   const int slot = demo ? (s == 0 ? TN_D0 : (s == 1 ? TN_D1 : TN_REF)) : (s == 0 ? TN_H0 : (s == 1 ? TN_H1 : TN_SIMG));
   if (c < 3) return (!t.global_obs && c < 2) ? OFF_ZERO : row_off(row, c);
@@ -161,6 +164,7 @@ enum { ROLE_SKIP = 0, ROLE_TABLE = 1, ROLE_ENV = 2 };
 template <bool VEL, bool FRESH>
 __device__ __forceinline__ Role lane_role(const addhip_task_t& t, const Tables& tb, const EnvPtrs& ep, int lane, int pass, int h0, int h1) {
   constexpr bool fresh = FRESH;
+  const bool three = t.num_disc_obs_steps == ADDHIP_HIST;  // (two steps: the second history / clip row is not staged)
   const int r = pass * 16 + (lane >> 2), q = lane & 3;
   int kind = K_SKIP, hslot = 0;
   float dt = 0.0f;
@@ -171,15 +175,15 @@ __device__ __forceinline__ Role lane_role(const addhip_task_t& t, const Tables& 
     const int k = r - R_TAR;
     if (k < t.num_tar_steps) { kind = K_POSE; dt = tar_dt_at(t, k); }  // add_observation.py:214-215
   } else if (r == R_DEMO0 || (r == R_H0 && fresh)) { kind = K_POSE; dt = t.demo_dt[0]; }   // :362-375
-  else if (r == R_DEMO1 || (r == R_H1 && fresh)) { kind = K_POSE; dt = t.demo_dt[1]; }
+  else if (r == R_DEMO1 || (r == R_H1 && fresh)) { if (three) { kind = K_POSE; dt = t.demo_dt[1]; } }
   else if (r == R_H0) { kind = K_HIST; hslot = h0; }
-  else if (r == R_H1) { kind = K_HIST; hslot = h1; }
+  else if (r == R_H1) { if (three) { kind = K_HIST; hslot = h1; } }
   else if (r == R_SIMV) { if (VEL || !FRESH) kind = fresh ? K_VEL : K_SIMV; }  // the step's reward reads it too
   else if (VEL) {
     if (r == R_D0V || (r == R_H0V && fresh)) { kind = K_VEL; dt = t.demo_dt[0]; }
-    else if (r == R_D1V || (r == R_H1V && fresh)) { kind = K_VEL; dt = t.demo_dt[1]; }
+    else if (r == R_D1V || (r == R_H1V && fresh)) { if (three) { kind = K_VEL; dt = t.demo_dt[1]; } }
     else if (r == R_H0V) { kind = K_HISTV; hslot = h0; }
-    else if (r == R_H1V) { kind = K_HISTV; hslot = h1; }
+    else if (r == R_H1V) { if (three) { kind = K_HISTV; hslot = h1; } }
   }
   Role ro{ROLE_SKIP, dt, nullptr, PW};
   if (kind == K_SKIP) return ro;
@@ -190,7 +194,7 @@ __device__ __forceinline__ Role lane_role(const addhip_task_t& t, const Tables& 
   const bool table = FRESH || kind == K_POSE || kind == K_VEL, ring = kind == K_HIST || kind == K_HISTV;
   ro.kind = table ? ROLE_TABLE : ROLE_ENV;
   ro.base = reinterpret_cast<const float*>(b) + (ring ? hslot * PW : 0) + q * 9;
-  ro.mul = ring ? ADDHIP_HIST * PW : PW;
+  ro.mul = ring ? t.num_disc_obs_steps * PW : PW;
   return ro;
 }
 
@@ -419,7 +423,8 @@ __global__ __launch_bounds__(64 * WAVES) void env_step_kernel(addhip_task_t t, S
   float* w = lds[wv];
   float* slots = slot_mem[wv];
   build_maps(t, maps);
-  const int h0 = (a.head + 1) % ADDHIP_HIST, h1 = (a.head + 2) % ADDHIP_HIST;
+  const int S = t.num_disc_obs_steps;  // ring depth
+  const int h0 = (a.head + 1) % S, h1 = (a.head + 2) % S;
   const EnvPtrs ep{a.sim_pose, a.sim_vel, a.hist, a.hist_vel};
   const Role ro = lane_role<VEL, false>(t, a.tb, ep, lane, 0, h0, h1);
   Role ro1{ROLE_SKIP, 0.0f, nullptr, PW};
@@ -487,8 +492,8 @@ __global__ __launch_bounds__(64 * WAVES) void env_step_kernel(addhip_task_t t, S
       if (a.demo) emit(w, maps + n_obs + n_disc, n_disc, a.demo + (size_t)env * n_disc, lane);
       if (lane < PW) {
         // history push (circular_buffer.py:17-20) and, optionally, the reference state (add_observation.py:163-174)
-        a.hist[((size_t)env * ADDHIP_HIST + a.head) * PW + lane] = w[row_off(R_SIM, lane)];
-        if (VEL) a.hist_vel[((size_t)env * ADDHIP_HIST + a.head) * PW + lane] = w[row_off(R_SIMV, lane)];
+        a.hist[((size_t)env * S + a.head) * PW + lane] = w[row_off(R_SIM, lane)];
+        if (VEL) a.hist_vel[((size_t)env * S + a.head) * PW + lane] = w[row_off(R_SIMV, lane)];
         if (a.ref_pose) a.ref_pose[(size_t)env * PW + lane] = w[row_off(R_REF, lane)];
         if (a.ref_vel) a.ref_vel[(size_t)env * PW + lane] = w[row_off(R_REFV, lane)];
       }
@@ -615,15 +620,17 @@ __global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_task_t t, 
         if (a.ref_pose) a.ref_pose[(size_t)env * PW + lane] = pose;
         if (a.ref_vel) a.ref_vel[(size_t)env * PW + lane] = vel;
         // CircularBuffer.fill (circular_buffer.py:22-29): get_all() order = demo frames t-2dt, t-dt, t
-        float* hb = a.hist + (size_t)env * ADDHIP_HIST * PW;
-        hb[((a.head + 0) % ADDHIP_HIST) * PW + lane] = w[row_off(R_DEMO0, lane)];
-        hb[((a.head + 1) % ADDHIP_HIST) * PW + lane] = w[row_off(R_DEMO1, lane)];
-        hb[((a.head + 2) % ADDHIP_HIST) * PW + lane] = pose;
+        // (S = t.num_disc_obs_steps slots: S = 2 holds t-dt, t)
+        const int S = t.num_disc_obs_steps;
+        float* hb = a.hist + (size_t)env * S * PW;
+        hb[((a.head + 0) % S) * PW + lane] = w[row_off(R_DEMO0, lane)];
+        if (S == ADDHIP_HIST) hb[((a.head + 1) % S) * PW + lane] = w[row_off(R_DEMO1, lane)];
+        hb[((a.head + S - 1) % S) * PW + lane] = pose;
         if (VEL) {
-          float* hv = a.hist_vel + (size_t)env * ADDHIP_HIST * PW;
-          hv[((a.head + 0) % ADDHIP_HIST) * PW + lane] = w[row_off(R_D0V, lane)];
-          hv[((a.head + 1) % ADDHIP_HIST) * PW + lane] = w[row_off(R_D1V, lane)];
-          hv[((a.head + 2) % ADDHIP_HIST) * PW + lane] = vel;
+          float* hv = a.hist_vel + (size_t)env * S * PW;
+          hv[((a.head + 0) % S) * PW + lane] = w[row_off(R_D0V, lane)];
+          if (S == ADDHIP_HIST) hv[((a.head + 1) % S) * PW + lane] = w[row_off(R_D1V, lane)];
+          hv[((a.head + S - 1) % S) * PW + lane] = vel;
         }
       }
       if (lane == 0) {
@@ -667,14 +674,15 @@ int check_common(const addhip_motion_t* m, const addhip_task_t* t, const addhip_
   ADDHIP_REQUIRE((long long)m->total_steps * PW < (1ll << 31), "motion table too large for 32-bit row offsets");
   ADDHIP_REQUIRE((long long)e->num_envs * ADDHIP_HIST * PW < (1ll << 31), "env count too large for 32-bit row offsets");
   ADDHIP_REQUIRE(t->num_tar_steps >= 0 && t->num_tar_steps <= ADDHIP_MAX_TAR_STEPS, "num_tar_steps out of range");
-  ADDHIP_REQUIRE(t->demo_dt[ADDHIP_HIST - 1] == 0.0f, "demo_dt[last] must be 0 (newest demo frame == reference frame)");
+  ADDHIP_REQUIRE(t->num_disc_obs_steps >= 2 && t->num_disc_obs_steps <= ADDHIP_HIST, "num_disc_obs_steps must be 2 or %d", ADDHIP_HIST);
+  ADDHIP_REQUIRE(t->demo_dt[t->num_disc_obs_steps - 1] == 0.0f, "demo_dt[last] must be 0 (newest demo frame == reference frame)");
   const int hc = t->root_height_obs ? 1 : 0;
   const int vw = t->enable_vel_obs ? 6 + ADDHIP_NUM_DOF : 0;
   ADDHIP_REQUIRE(t->num_phase_encoding >= 0 && t->num_phase_encoding <= MAX_PHASE_ENC, "num_phase_encoding must be in 0..%d", MAX_PHASE_ENC);
   const int want = hc + 6 + ADDHIP_NUM_DOF + vw + (t->enable_phase_obs ? 1 + 2 * t->num_phase_encoding : 0) +
                    t->num_tar_steps * ((hc ? 3 : 2) + 6 + ADDHIP_NUM_DOF);
   ADDHIP_REQUIRE(t->obs_dim == want, "obs_dim %d does not match the task flags (expected %d)", t->obs_dim, want);
-  ADDHIP_REQUIRE(t->disc_dim == ADDHIP_HIST * (9 + ADDHIP_NUM_DOF + vw), "disc_dim must be %d", ADDHIP_HIST * (9 + ADDHIP_NUM_DOF + vw));
+  ADDHIP_REQUIRE(t->disc_dim == t->num_disc_obs_steps * (9 + ADDHIP_NUM_DOF + vw), "disc_dim must be %d", t->num_disc_obs_steps * (9 + ADDHIP_NUM_DOF + vw));
   ADDHIP_REQUIRE(!t->enable_vel_obs || e->hist_vel, "hist_vel is required when enable_vel_obs is set");
   ADDHIP_REQUIRE(t->obs_stride >= t->obs_dim && t->disc_stride >= t->disc_dim, "strides smaller than dims");
   const int map_max = map_of(t->enable_vel_obs != 0, t->enable_phase_obs != 0);
@@ -699,7 +707,7 @@ extern "C" int addhip_env_step(const addhip_motion_t* m, const addhip_task_t* t,
   if (int rc = check_common(m, t, e)) return rc;
   ADDHIP_REQUIRE(o, "null outputs");
   ADDHIP_REQUIRE(!o->obs_timeout || o->obs, "obs_timeout needs obs");
-  ADDHIP_REQUIRE(head >= 0 && head < ADDHIP_HIST, "head out of range");
+  ADDHIP_REQUIRE(head >= 0 && head < t->num_disc_obs_steps, "head out of range");
   ADDHIP_RECORDABLE(addhip_env_step, m, t, e, o, head);
   hipStream_t st = (hipStream_t)stream;
   // envs per wave: enough waves to fill the chip (256 CUs x ~24 resident waves) first, then amortise the per-group part
@@ -735,7 +743,7 @@ extern "C" int addhip_env_reset(const addhip_motion_t* m, const addhip_task_t* t
   ADDHIP_REQUIRE(s && s->errors && s->seg_size && s->clip_cdf && s->temp_bits, "sampler pointers missing");
   ADDHIP_REQUIRE(s->num_segments > 0 && s->num_segments <= 64, "num_segments must be in 1..64");
   ADDHIP_REQUIRE(u_clip && u_seg && u_jit, "uniform draws missing");
-  ADDHIP_REQUIRE(head >= 0 && head < ADDHIP_HIST, "head out of range");
+  ADDHIP_REQUIRE(head >= 0 && head < t->num_disc_obs_steps, "head out of range");
   ADDHIP_RECORDABLE(addhip_env_reset, m, t, e, s, u_clip, u_seg, u_jit, obs_out, disc_obs_out, disc_demo_out, reset_all, head);
   hipStream_t st = (hipStream_t)stream;
   ADDHIP_HIP(hipMemsetAsync(s->temp_bits, 0, sizeof(uint32_t), st));

@@ -17,7 +17,12 @@ def obs_dims(task):
     vel = VEL_W if task.get("enable_vel_obs", False) else 0
     phase = (1 + 2 * int(task.get("num_phase_encoding", 0))) if task.get("enable_phase_obs", True) else 0
     obs_dim = hc + 6 + L.NUM_DOF + vel + phase + k * ((3 if hc else 2) + 6 + L.NUM_DOF)
-    return obs_dim, L.HIST * (L.DISC_STEP_W + vel)
+    return obs_dim, disc_steps(task) * (L.DISC_STEP_W + vel)
+
+
+def disc_steps(task):
+    """task.num_disc_obs_steps: poses per discriminator observation = depth of the history ring (add_observation.py:276-294)."""
+    return int(task.get("num_disc_obs_steps", L.HIST))
 
 
 def pad4(n):
@@ -35,8 +40,8 @@ def check_supported(task):
     Anything else fails loudly instead of silently computing something different."""
     if task.get("enable_phase_obs", True) and int(task.get("num_phase_encoding", 0)) > 8:
         raise NotImplementedError("task.num_phase_encoding must be <= 8")
-    if task.get("num_disc_obs_steps", L.HIST) != L.HIST:
-        raise NotImplementedError("task.num_disc_obs_steps must be 3")
+    if not 2 <= disc_steps(task) <= L.HIST:
+        raise NotImplementedError(f"task.num_disc_obs_steps must be 2 or {L.HIST} (the env-step kernel stages at most {L.HIST - 1} history rows)")
     if task.get("visualize_ref_char", False):
         raise NotImplementedError("task.visualize_ref_char needs a viewer (out of scope)")
     if len(task.get("tar_obs_steps", [1])) > L.MAX_TAR:
@@ -58,7 +63,8 @@ def make_task(task, dt, max_episode_length=None):
     tar = (F(dt) * np.asarray(steps, F)).astype(F)
     for i, v in enumerate(tar):
         t.tar_dt[i] = float(v)
-    demo = (F(-dt) * np.arange(L.HIST, dtype=F))[::-1].astype(F)
+    t.num_disc_obs_steps = disc_steps(task)
+    demo = (F(-dt) * np.arange(t.num_disc_obs_steps, dtype=F))[::-1].astype(F)
     for i, v in enumerate(demo):
         t.demo_dt[i] = float(v)
     t.max_episode_length = float(task.get("max_episode_length", max_episode_length if max_episode_length is not None else 0.0))

@@ -125,7 +125,7 @@ class ADDAgent(AgentIO):
             allowed = [ent.get_link(name=nm).idx for nm in names]
             self._noncontact_ids = torch.tensor([l.idx for l in ent.links if l.idx not in allowed], dtype=torch.long, device=dev)
         self._S = S = dict(sim_pose=sim_pose, sim_vel=sim_vel, contact=contact, time=env.time_buf, time_off=z(N), motion_id=z(N, dt=torch.int32),
-                           hist=z(N, L.HIST, L.POSE_W), hist_vel=z(N, L.HIST, L.POSE_W) if tk.enable_vel_obs else None, done=z(N, dt=torch.int32),
+                           hist=z(N, tk.num_disc_obs_steps, L.POSE_W), hist_vel=z(N, tk.num_disc_obs_steps, L.POSE_W) if tk.enable_vel_obs else None, done=z(N, dt=torch.int32),
                            ref_pose=None, ref_vel=None,  # optional outputs of the step kernel (gathered reference rows); not needed here
                            ret_acc=z(N), len_acc=z(N, dt=torch.int32), ret_acc_test=z(N), len_acc_test=z(N, dt=torch.int32))
         jw = task.get("joint_err_w", None)  # add_reward.py:24-52: per joint in kinematic-tree order; every G1 joint has one dof
@@ -484,7 +484,7 @@ class ADDAgent(AgentIO):
         if not self._fast_engine:
             self._sync_foreign_engine_in()
         L.call("addhip_env_step", self._motion_lib.c_struct, self._task, env_c, out_c, self._head, self._stream())
-        self._head = (self._head + 1) % L.HIST
+        self._head = (self._head + 1) % self._task.num_disc_obs_steps
 
     # ------------------------------------------------------------------ training loop
     def _rollout_train(self):
@@ -536,14 +536,14 @@ class ADDAgent(AgentIO):
             self._graph_warm = True
             return
         g = self._graphs.get(h0)
-        if g is None:  # one graph per ring phase (the ring slot of step t is (h0 + t) % 3, a launch argument)
+        if g is None:  # one graph per ring phase (the ring slot of step t is (h0 + t) % ring depth, a launch argument)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._rollout_body_relative()
             self._graphs[h0] = g
         self._head = h0
         g.replay()
-        self._head = (h0 + T) % L.HIST
+        self._head = (h0 + T) % self._task.num_disc_obs_steps
 
     def _build_train_data(self):
         """add_agent.py:110-139 then ppo_agent.py:111-159."""

@@ -33,7 +33,7 @@ def export_playback(cfg, out_file, steps, source="policy"):
             S["sim_pose"].copy_(pose)
             S["sim_vel"].copy_(vel)
             L.call("addhip_env_step", lib.c_struct, agent._task, agent._env_c_test, out, agent._head, agent._stream())
-            agent._head = (agent._head + 1) % L.HIST
+            agent._head = (agent._head + 1) % agent._task.num_disc_obs_steps
         else:
             agent._decide_action(0, 0, True)
             agent._step_env(0, out, agent._env_c_test)

@@ -73,6 +73,8 @@ typedef struct {
   int32_t enable_vel_obs;         /* root vel / ang vel / dof vel in the policy and discriminator observations */
   int32_t enable_phase_obs;       /* motion phase (+ 2*num_phase_encoding positional terms) in the policy observation */
   int32_t num_phase_encoding;     /* <= 8 */
+  int32_t num_disc_obs_steps;     /* S = 2 or 3 (ADDHIP_HIST): poses per discriminator observation = depth of the history ring [N, S, 36]
+                                     (add_observation.py:276-294, 362-375); demo_dt[0..S) are used, demo_dt[S-1] = 0 */
 } addhip_task_t;
 
 /* ---- per-env state between the engine boundary and the agent ---- */

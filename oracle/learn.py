@@ -57,7 +57,7 @@ def synth_params(seed, obs_dim=264, disc_dim=114, bias_scale=0.02, nets=None, lo
      except that biases are non-zero so that bias gradients/ReLU masks are exercised."""
     rng = np.random.RandomState(seed)
     out = {}
-    for name, shape in (PARAM_SHAPES if nets is None else param_shapes(nets)):
+    for name, shape in (PARAM_SHAPES if nets is None and (obs_dim, disc_dim) == (264, 114) else param_shapes(nets, obs_dim, disc_dim)):
         shape = tuple(obs_dim if (s == 264) else disc_dim if (s == 114) else s for s in shape)
         if name.endswith("weight"):
             fan_in = shape[1]

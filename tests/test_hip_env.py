@@ -151,7 +151,9 @@ def fixture_hist_vel(v, prefix=""):
 VARIANTS = {"default": {}, "local": dict(global_obs=False), "noheight": dict(root_height_obs=False),
             "local_noheight": dict(global_obs=False, root_height_obs=False),
             "vel_phase": dict(enable_vel_obs=True, enable_phase_obs=True, num_phase_encoding=4),
-            "local_vel": dict(global_obs=False, enable_vel_obs=True)}
+            "local_vel": dict(global_obs=False, enable_vel_obs=True),
+            # task.num_disc_obs_steps = 2 (add_observation.py:276-294, 362-375; fixture obs_reward_done_s2): the ring depth is a task field
+            "two_steps": dict(num_disc_obs_steps=2), "two_steps_local_vel": dict(num_disc_obs_steps=2, global_obs=False, enable_vel_obs=True)}
 
 
 @pytest.mark.parametrize("vname", list(VARIANTS) + ["joint_w"])
@@ -161,7 +163,9 @@ def test_env_step_matches_reference(vname):
     from add_gym_amd.hotpath import make_task
 
     # "joint_w": non-uniform task.joint_err_w (add_reward.py:24-52), its own fixture; same states as "default"
-    v = variant(gload("obs_reward_done_jw" if vname == "joint_w" else "obs_reward_done"), vname)
+    from tests.test_oracle_vs_golden import step_fixture
+
+    v = variant(gload(step_fixture(vname)), vname)
     task = make_task({**DEFAULT_TASK, **VARIANTS.get(vname, {})}, 0.01)
     mot = HipMotion()
     n = v["time"].shape[0]
@@ -169,6 +173,7 @@ def test_env_step_matches_reference(vname):
     vel = pack_vel(v["root_vel"], v["root_ang_vel"], v["dof_vel"])
     head = int(v["hist_head"])
     with_vel = bool(task.enable_vel_obs)
+    assert fixture_hist(v).shape[1] == task.num_disc_obs_steps and task.disc_dim == task.num_disc_obs_steps * (38 + (35 if with_vel else 0))
     st, env = make_env(L, n, pose, vel, v["time"], v["time_off"], v["motion_ids"], fixture_hist(v), v["contact"],
                        fixture_hist_vel(v) if with_vel else None, v["dof_err_w"] if vname == "joint_w" else None)
     o, out = make_out(L, n, task)
@@ -199,7 +204,8 @@ def test_env_step_matches_reference(vname):
     # ring: the new state landed in slot `head`, the other two slots are untouched
     h = st["hist"].cpu().numpy()
     assert np.array_equal(h[:, head], pose)
-    for s in range(3):
+    assert h.shape[1] == task.num_disc_obs_steps
+    for s in range(h.shape[1]):
         if s != head:
             assert np.array_equal(h[:, s], fixture_hist(v)[:, s])
     # return tracker: finished episodes were folded into ep_stats and cleared
@@ -215,16 +221,18 @@ def _mid_bin_u(cdf, k):
     return F(0.5 * (lo + float(cdf[k])))
 
 
-@pytest.mark.parametrize("tag", ["one", "two"])
+@pytest.mark.parametrize("tag", ["one", "two", "one_two_steps"])
 def test_env_reset_matches_reference(tag):
+    """(`one_two_steps`: task.num_disc_obs_steps = 2, fixture reset_s2 -- the reset fills a two-deep ring with the clip frames t-dt, t.)"""
     import torch
     import add_gym_amd._lib as L
     from add_gym_amd.hotpath import make_task
     from oracle.task import SegmentSampler
 
-    v = variant(gload("reset"), tag)
+    s2 = tag == "one_two_steps"
+    v = variant(gload("reset_s2" if s2 else "reset"), "one" if s2 else tag)
     two = tag == "two"
-    task = make_task(DEFAULT_TASK, 0.01)
+    task = make_task({**DEFAULT_TASK, **(dict(num_disc_obs_steps=2) if s2 else {})}, 0.01)
     mot = HipMotion(two)
     n = v["time"].shape[0]
     pose = pack_pose(v["sim_root_pos"], v["sim_root_rot"], v["sim_dof_pos"])
@@ -266,8 +274,10 @@ def test_env_reset_matches_reference(tag):
     assert np.array_equal(st["sim_vel"].cpu().numpy()[:, :35], post_vel[:, :35])
     assert np.array_equal(st["hist"].cpu().numpy(), fixture_hist(v, "post_"))
     np.testing.assert_allclose(obs.cpu().numpy()[env_ids][:, :264], v["obs"][env_ids], rtol=0, atol=ATOL)
-    np.testing.assert_allclose(disc.cpu().numpy()[env_ids][:, :114], v["disc_obs"][env_ids], rtol=0, atol=ATOL)
-    np.testing.assert_allclose(demo.cpu().numpy()[env_ids][:, :114], v["disc_obs_demo"][env_ids], rtol=0, atol=ATOL)
+    dd = task.disc_dim
+    assert dd == (76 if s2 else 114) and v["disc_obs"].shape[1] == dd
+    np.testing.assert_allclose(disc.cpu().numpy()[env_ids][:, :dd], v["disc_obs"][env_ids], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(demo.cpu().numpy()[env_ids][:, :dd], v["disc_obs_demo"][env_ids], rtol=0, atol=ATOL)
     untouched = np.setdiff1d(np.arange(n), env_ids)
     assert np.all(obs.cpu().numpy()[untouched] == 0)
 

@@ -122,8 +122,16 @@ VARIANTS = {
     "local_noheight": dict(global_obs=False, root_height_obs=False),
     "vel_phase": dict(enable_vel_obs=True, enable_phase_obs=True),
     "local_vel": dict(global_obs=False, enable_vel_obs=True),
+    # task.num_disc_obs_steps = 2 (fixture obs_reward_done_s2): a two-deep history ring, two clip frames per demo observation
+    "two_steps": dict(num_disc_obs_steps=2),
+    "two_steps_local_vel": dict(num_disc_obs_steps=2, global_obs=False, enable_vel_obs=True),
 }
 FIELDS = T.TaskState.FIELDS
+
+
+def step_fixture(vname):
+    """The fixture that holds a variant of the env-step case."""
+    return "obs_reward_done_jw" if vname == "joint_w" else "obs_reward_done_s2" if vname.startswith("two_steps") else "obs_reward_done"
 
 
 def _task_from_fixture(v, cfg, lib, n, prefix="", sim_prefix=None):
@@ -139,7 +147,7 @@ def _task_from_fixture(v, cfg, lib, n, prefix="", sim_prefix=None):
 
 @pytest.mark.parametrize("vname", list(VARIANTS))
 def test_obs_reward_done(vname):
-    v = variant(gload("obs_reward_done"), vname)
+    v = variant(gload(step_fixture(vname)), vname)
     cfg = T.TaskCfg(**VARIANTS[vname])
     lib = oracle_lib(golden_tables=True)
     n = v["time"].shape[0]
@@ -154,6 +162,8 @@ def test_obs_reward_done(vname):
     close(d_demo, v["disc_obs_demo"], atol=3e-6)
     close(r, v["reward"], atol=3e-6)
     assert done.dtype == np.int32 and np.array_equal(done, v["done"])
+    if vname == "two_steps":
+        assert d_obs.shape[1] == 76 and ts.hist["root_pos"].shape[1] == 2
     if vname == "default":
         assert obs.shape[1] == 264 and d_obs.shape[1] == 114
         assert set(np.unique(done)) == {0, 1, 2, 3}  # every flag occurs
@@ -177,8 +187,16 @@ def test_obs_reward_done_joint_error_weights():
 
 @pytest.mark.parametrize("tag", ["one", "two"])
 def test_reset(tag):
-    v = variant(gload("reset"), tag)
-    cfg = T.TaskCfg()
+    _reset_case("reset", tag, T.TaskCfg())
+
+
+def test_reset_two_disc_obs_steps():
+    """task.num_disc_obs_steps = 2: CircularBuffer.fill writes the clip frames t-dt, t (circular_buffer.py:22-29)."""
+    _reset_case("reset_s2", "one", T.TaskCfg(num_disc_obs_steps=2))
+
+
+def _reset_case(fixture, tag, cfg):
+    v = variant(gload(fixture), tag)
     lib = oracle_lib(two=(tag == "two"), golden_tables=True)
     n = v["time"].shape[0]
     ts = _task_from_fixture(v, cfg, lib, n)
@@ -309,7 +327,8 @@ def test_losses_grads_adamw(name):
 
 
 LOOP_VARIANTS = {"loop_1iter": dict(two=False, task={}), "loop_1iter_two": dict(two=True, task={}),
-                 "loop_1iter_time": dict(two=False, task=dict(max_episode_length=0.4))}
+                 "loop_1iter_time": dict(two=False, task=dict(max_episode_length=0.4)),
+                 "loop_1iter_s2": dict(two=False, task=dict(num_disc_obs_steps=2))}
 
 
 @pytest.mark.parametrize("name", list(LOOP_VARIANTS))
@@ -320,7 +339,7 @@ def test_loop_one_iteration(name):
     v = LOOP_VARIANTS[name]
     n = g["noise"].shape[1]
     lib = oracle_lib(two=v["two"], golden_tables=True)
-    ag = LP.Agent(LP.AgentCfg(), T.TaskCfg(**v["task"]), lib, n, L.synth_params(int(g["seed"])))
+    ag = LP.Agent(LP.AgentCfg(), T.TaskCfg(**v["task"]), lib, n, L.synth_params(int(g["seed"]), disc_dim=38 * v["task"].get("num_disc_obs_steps", 3)))
     ag.init(dict(ids=g["init_ids"], segments=g["init_segments"], jitter=g["init_jitter"]))
     ag.task.time = (ag.task.time + g["time_preset"]).astype(np.float32)          # (zeros except in the time variant)
     ag.task.time_off = (ag.task.time_off - g["time_preset"]).astype(np.float32)

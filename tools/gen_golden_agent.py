@@ -75,9 +75,9 @@ def build_agent(num_envs, clip_frames=200, seed=3, two_clip=False, task_over=Non
     return ag, cfg
 
 
-def load_synth(ag, seed, nets=None, logstd=False):
+def load_synth(ag, seed, nets=None, logstd=False, disc_dim=114):
     sd = ag.state_dict()
-    for k, v in synth_params(seed, nets=nets, logstd=logstd).items():
+    for k, v in synth_params(seed, nets=nets, logstd=logstd, disc_dim=disc_dim).items():
         assert tuple(sd[k].shape) == v.shape, k
         sd[k] = T(v)
     ag.load_state_dict(sd)
@@ -129,6 +129,12 @@ JOINT_ERR_W = [0.5, 0.5, 2.0, 1.0, 1.0, 2.0, 1.5, 1.5, 0.25, 3.0, 3.0, 1.0, 0.75
 def gen_obs_reward_done_jw():
     """A separate fixture (the first one stays byte-identical): non-uniform joint error weights."""
     gen_obs_reward_done({"joint_w": dict(joint_err_w=JOINT_ERR_W)}, "obs_reward_done_jw")
+
+
+def gen_obs_reward_done_s2():
+    """task.num_disc_obs_steps = 2 (add_observation.py:276-294, 362-375): a two-deep history ring, two clip frames per demo observation."""
+    gen_obs_reward_done({"two_steps": dict(num_disc_obs_steps=2), "two_steps_local_vel": dict(num_disc_obs_steps=2, global_obs=False, enable_vel_obs=True)},
+                        "obs_reward_done_s2")
 
 
 def gen_obs_reward_done(variants=None, name="obs_reward_done"):
@@ -185,11 +191,15 @@ def gen_obs_reward_done(variants=None, name="obs_reward_done"):
     _save(name, **out)
 
 
-def gen_reset():
+def gen_reset_s2():
+    gen_reset("reset_s2", dict(num_disc_obs_steps=2), (("one", False),))
+
+
+def gen_reset(name="reset", task_over=None, tags=(("one", False), ("two", True))):
     n = 48
     out = {}
-    for tag, two in (("one", False), ("two", True)):
-        ag, cfg = build_agent(n, two_clip=two)
+    for tag, two in tags:
+        ag, cfg = build_agent(n, two_clip=two, task_over=task_over)
         rng = np.random.RandomState(4)
         ag._reset_envs()
         for _ in range(2 if not two else 1):
@@ -214,7 +224,7 @@ def gen_reset():
                    disc_obs_demo=info["disc_obs_demo"].clone(), probs=ag._add_motion.sampler.get_probs(mult[0]))
         for k, v in {**pre, **post, **res}.items():
             out[f"{tag}.{k}"] = v
-    _save("reset", **out)
+    _save(name, **out)
 
 
 def gen_sampler():
@@ -400,7 +410,7 @@ def gen_loop_1iter_time():
 def gen_loop_1iter(name="loop_1iter", two_clip=False, task_over=None, time_preset=False):
     n = 32
     ag, cfg = build_agent(n, seed=5, two_clip=two_clip, task_over=task_over)
-    load_synth(ag, 303)
+    load_synth(ag, 303, disc_dim=38 * int((task_over or {}).get("num_disc_obs_steps", 3)))
     log0 = DrawLog()
     with log0.recording():
         ag._curr_obs, ag._curr_info = ag._reset_envs()
@@ -595,5 +605,5 @@ def gen_test_rollout():
           mean_return=float(info["mean_return"]), mean_ep_len=float(info["mean_ep_len"]), num_eps=int(info["num_eps"]))
 
 
-AGENT_GENS = dict(loop_1iter_two=gen_loop_1iter_two, loop_1iter_time=gen_loop_1iter_time, logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
+AGENT_GENS = dict(obs_reward_done_s2=gen_obs_reward_done_s2, reset_s2=gen_reset_s2, loop_1iter_s2=lambda: gen_loop_1iter("loop_1iter_s2", task_over=dict(num_disc_obs_steps=2)), loop_1iter_two=gen_loop_1iter_two, loop_1iter_time=gen_loop_1iter_time, logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
                   td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, losses_small_nets=gen_losses_small_nets, losses_constant_std=gen_losses_constant_std, actor_step_constant_std=lambda: gen_actor_step("actor_step_constant_std", True), normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
