@@ -46,7 +46,8 @@ int split_k_for(int out_dim, int in_dim, int64_t rows) {
 }
 
 // 16-bit storage of the net's GEMM operands: 0 = none (fp32 operands), ADDHIP_STORE_BF16 (bf16 storage), ADDHIP_STORE_BF16X3 (plane storage)
-int store_fmt(const addhip_mlp_t& n) { return n.storage == ADDHIP_STORE_BF16X3 ? ADDHIP_STORE_BF16X3 : n.precision == ADDHIP_PREC_BF16 ? ADDHIP_STORE_BF16 : 0; }
+// (storage 0 with precision ADDHIP_PREC_BF16: fp32 operands cut to bf16 on the way into LDS, one product per term -- no *16 buffers)
+int store_fmt(const addhip_mlp_t& n) { return n.storage == ADDHIP_STORE_BF16X3 ? ADDHIP_STORE_BF16X3 : n.storage == ADDHIP_STORE_BF16 ? ADDHIP_STORE_BF16 : 0; }
 bool storage16(const addhip_mlp_t& n) { return store_fmt(n) != 0; }  // (either format: the *16 buffers are the operands)
 void set_prec(addhip_gemm_t& g, const addhip_mlp_t& n) {
   g.precision = n.precision;

@@ -83,6 +83,14 @@ class ADDAgent(AgentIO):
         # "bf16x3", whose GEMMs split their fp32 operands on the fly (gemm_split.hip) -- as this mode's rollout / evaluation passes do.
         self._storage16 = {"bf16": L.STORE_BF16, "bf16x3_planes": L.STORE_BF16X3}.get(prec, 0)
         self._prec_small = H.PRECISIONS["bf16x2"] if self._storage16 == L.STORE_BF16 else self._prec
+        # agent.rollout_precision: the products of the rollout / value / discriminator-reward passes where they differ from the update
+        # step's -- i.e. in bf16-storage mode, whose rollout keeps fp32 operands.  Default bf16x2 (16-bit operands: actions within 5e-5 of
+        # the fp32 rollout); "bf16" = one bf16 product per term on operands cut to 8 bits on the way into LDS (what the update step's
+        # storage holds anyway), for configs[2]-style throughput runs
+        rp = cfg.get("rollout_precision", None)
+        if rp is not None and str(rp) not in ("bf16x2", "bf16", "bf16x3", "fp32"):
+            raise ValueError("agent.rollout_precision must be one of bf16x2, bf16, bf16x3, fp32 (or null: the mode's own)")
+        self._prec_roll = self._prec_small if rp is None or self._storage16 != L.STORE_BF16 else H.PRECISIONS[str(rp)]
 
         # ---- motion library + sampler (add_motion.py:14-33)
         kin = env.robot._kin_char_model
@@ -255,9 +263,9 @@ class ADDAgent(AgentIO):
         self._run_disc.aux_slabs = (len(m.disc.hidden) - 1, self._slabs_all[3])
         # rollout / evaluation passes: the same runners, except in bf16-storage mode (fp32 operands, bf16x2 products)
         if s16:
-            self._roll_actor = NetRunner(m, m.actor, N, dev, None, self._prec_small)
-            self._eval_critic = NetRunner(m, m.critic, self._eval_rows, dev, None, self._prec_small)
-            self._eval_disc = NetRunner(m, m.disc, self._eval_rows, dev, None, self._prec_small)
+            self._roll_actor = NetRunner(m, m.actor, N, dev, None, self._prec_roll)
+            self._eval_critic = NetRunner(m, m.critic, self._eval_rows, dev, None, self._prec_roll)
+            self._eval_disc = NetRunner(m, m.disc, self._eval_rows, dev, None, self._prec_roll)
         else:
             self._roll_actor, self._eval_critic, self._eval_disc = self._run_actor, self._run_critic, self._run_disc
         self._side_streams = _side_streams(dev)
@@ -274,7 +282,7 @@ class ADDAgent(AgentIO):
                            e1_16=b16(Mb, hd[0]))
 
     def _gemm(self, plan, *a, **k):
-        k.setdefault("precision", self._prec_small)
+        k.setdefault("precision", self._prec_roll)
         g = gemm(*a, **k)
         plan.hold(g)
         plan.add("addhip_gemm_f32", g)

@@ -616,9 +616,10 @@ typedef struct {
   int32_t in_dim, in_ld;                  /* input columns / row stride of the input rows (pad columns hold zeros) */
   int32_t hidden[ADDHIP_MLP_MAX_HIDDEN];  /* layer widths */
   int32_t head_rows;                      /* rows of the head weight: 32 for the 29-wide action-mean head (zero rows as padding), 1 for a scalar head */
-  int32_t precision;                      /* ADDHIP_PREC_* of this net's GEMMs; ADDHIP_PREC_BF16 = bf16 STORAGE (the *16 buffers below) */
-  int32_t storage;                        /* 0: by `precision` (fp32 operands, or ADDHIP_STORE_BF16 when precision == ADDHIP_PREC_BF16);
-                                             ADDHIP_STORE_BF16X3: the *16 buffers below hold plane storage (3 uint16 per value) and every
+  int32_t precision;                      /* ADDHIP_PREC_* of this net's GEMMs */
+  int32_t storage;                        /* 0: fp32 operands (precision ADDHIP_PREC_BF16 then means one bf16 product per term on operands cut
+                                             to bf16 on the way into LDS); ADDHIP_STORE_BF16 (with precision ADDHIP_PREC_BF16): bf16 STORAGE,
+                                             the *16 buffers below; ADDHIP_STORE_BF16X3: they hold plane storage (3 uint16 per value) and every
                                              hidden GEMM runs on them (csrc/gemm_x3.hip); precision is then ADDHIP_PREC_BF16X3 */
   /* parameters: W[i] [hidden[i], in_ld | hidden[i-1]] row major, b[i] [hidden[i]], Wh [head_rows, hidden[last]], bh; g* = their gradients */
   const float* W[ADDHIP_MLP_MAX_HIDDEN]; const float* b[ADDHIP_MLP_MAX_HIDDEN]; const float* Wh; const float* bh;
