@@ -176,6 +176,7 @@ SIGNATURES = {
     "addhip_gemm_f32": [P(GemmT), vp],
     "addhip_gemm_grouped": [P(GemmT), i32, vp],
     "addhip_to_bf16": [vp, vp, i64, i32, i32, i32, vp],
+    "addhip_normalize_to_bf16": [vp, vp, vp, vp, i64, i32, i32, i32, vp],
     "addhip_to_bf16x3": [vp, vp, i64, i32, i32, i32, vp],
     "addhip_to_bf16_t": [vp, vp, i32, i32, i32, i32, vp],
     "addhip_shadow_refresh": [vp, vp, vp, i64, vp, vp, vp, i32, i32, vp],

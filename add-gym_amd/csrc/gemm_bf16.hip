@@ -202,6 +202,22 @@ __global__ void to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ 
   }
 }
 
+// the same behind Normalizer.normalize: dst = bf16((src - mean[c]) / std[c])   (a true division, as normalizer.py:107-110 and the GEMMs' fused form)
+__global__ void normalize_to_bf16_kernel(const float* __restrict__ src, const float* __restrict__ mean, const float* __restrict__ stdv, u16* __restrict__ dst,
+                                         long long rows, int cols, int ld_src, int ld_dst) {
+  const int cq = cols >> 2;
+  const long long n = rows * cq;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cq;
+    const int c = (int)(i - r * cq) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), sd = *reinterpret_cast<const float4*>(stdv + c);
+    const unsigned lo = (unsigned)to_bf16((v.x - mu.x) / sd.x) | ((unsigned)to_bf16((v.y - mu.y) / sd.y) << 16);
+    const unsigned hi = (unsigned)to_bf16((v.z - mu.z) / sd.z) | ((unsigned)to_bf16((v.w - mu.w) / sd.w) << 16);
+    *reinterpret_cast<uint2*>(dst + r * ld_dst + c) = make_uint2(lo, hi);
+  }
+}
+
 // transposing variant: dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) through a 32x33 LDS tile (both sides coalesced)
 __global__ __launch_bounds__(256) void to_bf16_t_kernel(const float* __restrict__ src, u16* __restrict__ dst, int rows, int cols, int ld_src, int ld_dst) {
   __shared__ float tile[32][33];
@@ -347,6 +363,19 @@ extern "C" int addhip_to_bf16(const float* src, uint16_t* dst, int64_t rows, int
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(to_bf16_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)rows, cols, ld_src, ld_dst);
   return addhip::check_launch("to_bf16_kernel");
+}
+
+extern "C" int addhip_normalize_to_bf16(const float* src, const float* mean, const float* stdv, uint16_t* dst, int64_t rows, int32_t cols, int32_t ld_src,
+                                        int32_t ld_dst, void* stream) {
+  ADDHIP_REQUIRE(src && mean && stdv && dst && rows > 0 && cols > 0 && cols % 4 == 0 && ld_src >= cols && ld_dst >= cols && ld_src % 4 == 0 && ld_dst % 4 == 0,
+                 "normalize_to_bf16: bad arguments (cols and row strides must be multiples of 4)");
+  ADDHIP_REQUIRE(aligned16(src) && aligned16(mean) && aligned16(stdv) && (reinterpret_cast<uintptr_t>(dst) & 7u) == 0, "normalize_to_bf16: misaligned buffers");
+  ADDHIP_RECORDABLE(addhip_normalize_to_bf16, src, mean, stdv, dst, rows, cols, ld_src, ld_dst);
+  const long long n = (long long)rows * (cols / 4);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(normalize_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, mean, stdv, dst, (long long)rows, cols, ld_src, ld_dst);
+  return addhip::check_launch("normalize_to_bf16_kernel");
 }
 
 extern "C" int addhip_to_bf16x3(const float* src, uint16_t* dst, int64_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream) {

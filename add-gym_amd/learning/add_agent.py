@@ -86,11 +86,14 @@ class ADDAgent(AgentIO):
         # agent.rollout_precision: the products of the rollout / value / discriminator-reward passes where they differ from the update
         # step's -- i.e. in bf16-storage mode, whose rollout keeps fp32 operands.  Default bf16x2 (16-bit operands: actions within 5e-5 of
         # the fp32 rollout); "bf16" = one bf16 product per term on operands cut to 8 bits on the way into LDS (what the update step's
-        # storage holds anyway), for configs[2]-style throughput runs
+        # storage holds anyway); "bf16_storage" = those passes on bf16 STORAGE like the update step -- a normalise-and-round pass per batch of
+        # observations, then the storage GEMMs on the weight shadow (actions then carry the 8-bit operand rounding, ~1e-3: configs[2]-style
+        # throughput runs; tests/test_hip_fullsize.py states the tolerance)
         rp = cfg.get("rollout_precision", None)
-        if rp is not None and str(rp) not in ("bf16x2", "bf16", "bf16x3", "fp32"):
-            raise ValueError("agent.rollout_precision must be one of bf16x2, bf16, bf16x3, fp32 (or null: the mode's own)")
-        self._prec_roll = self._prec_small if rp is None or self._storage16 != L.STORE_BF16 else H.PRECISIONS[str(rp)]
+        if rp is not None and str(rp) not in ("bf16x2", "bf16", "bf16x3", "fp32", "bf16_storage"):
+            raise ValueError("agent.rollout_precision must be one of bf16x2, bf16, bf16x3, fp32, bf16_storage (or null: the mode's own)")
+        self._roll_storage = self._storage16 == L.STORE_BF16 and str(rp) == "bf16_storage"
+        self._prec_roll = self._prec_small if rp is None or self._storage16 != L.STORE_BF16 or self._roll_storage else H.PRECISIONS[str(rp)]
 
         # ---- motion library + sampler (add_motion.py:14-33)
         kin = env.robot._kin_char_model
@@ -262,7 +265,11 @@ class ADDAgent(AgentIO):
         self._run_disc = NetRunner(m, m.disc, Mb + 1 if s16 else rows, dev, self._slabs_all[2], self._prec, s16, det)
         self._run_disc.aux_slabs = (len(m.disc.hidden) - 1, self._slabs_all[3])
         # rollout / evaluation passes: the same runners, except in bf16-storage mode (fp32 operands, bf16x2 products)
-        if s16:
+        if self._roll_storage:
+            self._roll_actor = NetRunner(m, m.actor, N, dev, None, L.PREC_BF16, L.STORE_BF16)
+            self._eval_critic = NetRunner(m, m.critic, self._eval_rows, dev, None, L.PREC_BF16, L.STORE_BF16)
+            self._eval_disc = NetRunner(m, m.disc, self._eval_rows, dev, None, L.PREC_BF16, L.STORE_BF16)
+        elif s16:
             self._roll_actor = NetRunner(m, m.actor, N, dev, None, self._prec_roll)
             self._eval_critic = NetRunner(m, m.critic, self._eval_rows, dev, None, self._prec_roll)
             self._eval_disc = NetRunner(m, m.disc, self._eval_rows, dev, None, self._prec_roll)
@@ -280,6 +287,9 @@ class ADDAgent(AgentIO):
             b16 = lambda r, c: torch.zeros(r, s16 * c, dtype=torch.bfloat16, device=dev)  # (plane storage: three bf16 per value)
             self._W.update(norm_obs16=b16(Mb, OS), norm_diff16=b16(Mb + 1, DS), a2_16=b16(Mb, hd[-1]), a1_16=b16(Mb, hd[0]), G16=b16(Mb, DS),
                            e1_16=b16(Mb, hd[0]))
+        if self._roll_storage:  # normalised, rounded input rows of the rollout / evaluation passes
+            self._W.update(roll_x16=torch.zeros(N, OS, dtype=torch.bfloat16, device=dev), eval_x16=torch.zeros(self._eval_rows, OS, dtype=torch.bfloat16, device=dev),
+                           eval_d16=torch.zeros(self._eval_rows, DS, dtype=torch.bfloat16, device=dev))
 
     def _gemm(self, plan, *a, **k):
         k.setdefault("precision", self._prec_roll)
@@ -299,7 +309,11 @@ class ADDAgent(AgentIO):
         for t in range(T + 1):
             p = Plan()
             rr = self._roll_actor
-            rr.forward(p, L.ptr(B["obs"][t]), N, a_mean=L.ptr(Nm["obs_mean"]), a_std=L.ptr(Nm["obs_std"]))
+            if self._roll_storage:
+                p.add("addhip_normalize_to_bf16", L.ptr(B["obs"][t]), L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(W["roll_x16"]), N, OS, OS, OS)
+                rr.forward(p, None, N, x16_ptr=L.ptr(W["roll_x16"]))
+            else:
+                rr.forward(p, L.ptr(B["obs"][t]), N, a_mean=L.ptr(Nm["obs_mean"]), a_std=L.ptr(Nm["obs_std"]))
             self._gemm(p, N, 32, hA, L.ptr(rr.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
             self._act_plans.append(p)
         for t in range(T):
@@ -341,7 +355,11 @@ class ADDAgent(AgentIO):
                 rows = min(chunk, total - r0)
                 p = Plan()
                 ec = self._eval_critic
-                ec.forward(p, L.ptr(src) + 4 * r0 * OS, rows, a_mean=L.ptr(Nm["obs_mean"]), a_std=L.ptr(Nm["obs_std"]))
+                if self._roll_storage:
+                    p.add("addhip_normalize_to_bf16", L.ptr(src) + 4 * r0 * OS, L.ptr(Nm["obs_mean"]), L.ptr(Nm["obs_std"]), L.ptr(W["eval_x16"]), rows, OS, OS, OS)
+                    ec.forward(p, None, rows, x16_ptr=L.ptr(W["eval_x16"]))
+                else:
+                    ec.forward(p, L.ptr(src) + 4 * r0 * OS, rows, a_mean=L.ptr(Nm["obs_mean"]), a_std=L.ptr(Nm["obs_std"]))
                 p.add("addhip_head_gemv", L.ptr(ec.h[-1]), hC, hC, rows, m.p("critic", "Wh"), m.p("critic", "bh"), L.ptr(dst) + 4 * r0)
                 self._critic_eval.append(p)
         self._disc_eval = []  # (r0, rows, forward + logits plan)
@@ -349,7 +367,11 @@ class ADDAgent(AgentIO):
             rows = min(chunk, T * N - r0)
             p = Plan()
             ed = self._eval_disc
-            ed.forward(p, L.ptr(W["norm_diff"]), rows)
+            if self._roll_storage:
+                p.add("addhip_to_bf16", L.ptr(W["norm_diff"]), L.ptr(W["eval_d16"]), rows, DS, DS, DS)
+                ed.forward(p, None, rows, x16_ptr=L.ptr(W["eval_d16"]))
+            else:
+                ed.forward(p, L.ptr(W["norm_diff"]), rows)
             p.add("addhip_head_gemv", L.ptr(ed.h[-1]), hD, hD, rows, m.p("disc", "Wh"), m.p("disc", "bh"), L.ptr(W["logits"]))
             self._disc_eval.append((r0, rows, p))
 

@@ -417,12 +417,15 @@ def main():
         del agent3
     if not a.no_alt and not a.no_configs2:
         # BASELINE configs[2]: "G1 mixed locomotion motion set, num_envs=16384, 1xMI355X, bf16 MLP MFMA path" -- five synthetic clips,
-        # 16 384 envs per GPU, agent.matmul_precision=bf16 (bf16 storage); parity of this composition: tests/test_hip_fullsize.py
-        agent4 = make_agent("bf16", envs=16384, motion="synthetic:5x1200")
+        # 16 384 envs per GPU, agent.matmul_precision=bf16 (bf16 storage) in the update step AND, with agent.rollout_precision=bf16_storage, in the
+        # rollout / value / discriminator-reward passes; parity of this composition with its stated tolerances: tests/test_hip_fullsize.py
+        # (test_16384_envs_five_clips_subset_matches_oracle[bf16+bf16_storage])
+        agent4 = make_agent("bf16", envs=16384, motion="synthetic:5x1200", extra=("agent.rollout_precision=bf16_storage",))
         dt4 = timed(agent4)
         if rank == 0:
-            out["alt_config"] = {"config": "BASELINE configs[2]: 5-clip synthetic locomotion set, num_envs=16384/GPU, bf16-storage MLP MFMA path",
-                                 "envs": 16384, "precision": "bf16", "matmul_precision": "bf16", "motion_library": "synthetic:5x1200",
+            out["alt_config"] = {"config": "BASELINE configs[2]: 5-clip synthetic locomotion set, num_envs=16384/GPU, bf16-storage MLP MFMA path "
+                                           "(update step, rollout and evaluation passes: agent.matmul_precision=bf16, agent.rollout_precision=bf16_storage)",
+                                 "envs": 16384, "precision": "bf16", "matmul_precision": "bf16", "rollout_precision": "bf16_storage", "motion_library": "synthetic:5x1200",
                                  "value": agent4.T * agent4.N * world * a.steps / dt4, "unit": "env-steps/s", "ms_per_step": 1000.0 * dt4 / a.steps,
                                  "minibatch_rows": agent4.Mb, "roofline": gemm_roofline(agent4, "bf16", with_traffic=False)}
         del agent4

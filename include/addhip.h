@@ -321,6 +321,10 @@ int addhip_gemm_grouped(const addhip_gemm_t* problems, int32_t count, void* stre
 /* dst[r*ld_dst + c] = bf16(src[r*ld_src + c]), round to nearest even (bf16-storage mode: minibatch inputs, head gradients, the weight
  * shadow after an optimiser step); cols and both leading dimensions multiples of 4 */
 int addhip_to_bf16(const float* src, uint16_t* dst, int64_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream);
+/* dst = bf16((src - mean[c]) / std[c]), round to nearest even: Normalizer.normalize (normalizer.py:107-110) into the bf16 rows the
+ * bf16-storage GEMMs read (the rollout / evaluation passes of agent.rollout_precision = bf16_storage); same size rules */
+int addhip_normalize_to_bf16(const float* src, const float* mean, const float* std, uint16_t* dst, int64_t rows, int32_t cols, int32_t ld_src,
+                             int32_t ld_dst, void* stream);
 /* the same into plane storage (ADDHIP_STORE_BF16X3): cols and ld_dst multiples of 8, ld_src of 4 */
 int addhip_to_bf16x3(const float* src, uint16_t* dst, int64_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, void* stream);
 /* transposing variant: dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) -- the [in,out] copy of a weight matrix [out,in], which lets the

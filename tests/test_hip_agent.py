@@ -377,6 +377,30 @@ def test_training_runs_and_learns_signal(tmp_path):
     assert ag._sample_count == 2 * 8 * 256
 
 
+def test_bf16_storage_rollout_trains_like_the_default_rollout():
+    """agent.matmul_precision=bf16 with agent.rollout_precision=bf16_storage (rollout / value / discriminator-reward passes on bf16 storage,
+    inside the hipGraph rollout too): two iterations from the same seed stay close to the default bf16x2 rollout in every logged scalar
+    that the 8-bit operands can move only a little, and the first iteration's flags / episode counts are identical."""
+    import torch
+    import add_gym_amd.learning.add_agent as A
+
+    infos = {}
+    for roll in (None, "bf16_storage"):
+        cfg = make_cfg(512, steps_per_iter=16, matmul_precision="bf16", **({"rollout_precision": roll} if roll else {}))
+        cfg["task"]["motion_file"] = "synthetic:2x300"
+        ag = A.ADDAgent(cfg)
+        assert ag._roll_storage == (roll is not None)
+        ag.reset_all_envs()
+        ag._init_train()
+        infos[roll] = [ag._train_iter() for _ in range(2)]
+        torch.cuda.synchronize()
+        assert all(np.isfinite(v) for it in infos[roll] for v in it.values())
+    a, b = infos[None][0], infos["bf16_storage"][0]
+    assert a["num_eps"] == b["num_eps"] and a["mean_ep_len"] == b["mean_ep_len"]
+    for k in ("disc_reward_mean", "critic_loss", "disc_loss", "adv_std"):
+        np.testing.assert_allclose(b[k], a[k], rtol=5e-2, atol=5e-3, err_msg=k)
+
+
 def test_foreign_engine_slow_path_matches_in_place_path():
     """An engine that only offers the reference's BaseEntity getters/setters gives the same rollout as the in-place one."""
     import torch

@@ -124,12 +124,17 @@ def test_update_plan_at_4096_envs_all_gradients_match_oracle(precision):
 # product error at most, the kinematic stand-in feeds it back into the next observation, and the value / logit heads (sums over 512
 # units of O(1) activations) carry up to ~1e-3; the integer outcomes (done flags, clocks, clip ids, reset start times) must not move at all.
 CFG2_TOL = {"bf16x3": dict(obs=5e-5, action=2e-5, logp_r=1e-4, logp_a=1e-3, reward_r=2e-3, reward_a=2e-4, tar_r=2e-3, tar_a=2e-3),
-            "bf16": dict(obs=5e-5, action=5e-5, logp_r=1e-4, logp_a=1e-3, reward_r=5e-3, reward_a=5e-4, tar_r=5e-3, tar_a=3e-3)}
+            "bf16": dict(obs=5e-5, action=5e-5, logp_r=1e-4, logp_a=1e-3, reward_r=5e-3, reward_a=5e-4, tar_r=5e-3, tar_a=3e-3),
+            # agent.rollout_precision = bf16_storage: the rollout / evaluation passes on bf16 storage too (operands rounded to 8 bits)
+            # (every GEMM operand of the actor / critic / discriminator passes rounded to 8 significant bits: the action means move by a few
+            # 1e-4, the kinematic stand-in carries that into the observations, the 512-unit value / logit sums by ~1e-2; flags, clocks, clip
+            # ids and reset start times still must not move at all)
+            "bf16+bf16_storage": dict(obs=5e-4, action=8e-4, logp_r=1e-4, logp_a=1e-3, reward_r=2e-2, reward_a=3e-2, tar_r=2e-2, tar_a=1.2e-1)}
 # measured on MI355X (max abs error over the subset): bf16x3 obs 2.4e-7, action 1.2e-7, reward 1.7e-6, tar_val 1.1e-5;
-# bf16 obs 4.4e-6, action 4.8e-6, reward 9.2e-5, tar_val 5.2e-4
+# bf16 obs 4.4e-6, action 4.8e-6, reward 9.2e-5, tar_val 5.2e-4; bf16 + bf16_storage rollout obs 2.2e-4, action 3.1e-4, reward 1.2e-2, tar_val 5.5e-2
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "bf16+bf16_storage"])
 def test_16384_envs_five_clips_subset_matches_oracle(precision):
     """BASELINE configs[2] composition: 16 384 envs, a multi-clip library (reference-compatible raw-frame offsets), the bf16 MFMA MLP
     path -- agent.matmul_precision=bf16x3 (exact split) and =bf16 (the bf16-STORAGE mode the configs[2] throughput is quoted for) --
@@ -144,11 +149,13 @@ def test_16384_envs_five_clips_subset_matches_oracle(precision):
     from add_gym_amd.anim.synth import synth_clip
 
     N, Tn, C, NF = 16384, 32, 5, 60  # 2 s clips: a good share of the envs runs past a clip end within the rollout
-    cfg = make_cfg(N, steps_per_iter=Tn, matmul_precision=precision)
+    tol_key = precision
+    precision, _, roll = precision.partition("+")
+    cfg = make_cfg(N, steps_per_iter=Tn, matmul_precision=precision, **({"rollout_precision": roll} if roll else {}))
     cfg["task"]["motion_file"] = f"synthetic:{C}x{NF}"
     ag = A.ADDAgent(cfg)
-    assert ag._storage16 == (1 if precision == "bf16" else 0)
-    tol = CFG2_TOL[precision]
+    assert ag._storage16 == (1 if precision == "bf16" else 0) and ag._roll_storage == bool(roll)
+    tol = CFG2_TOL[tol_key]
     seed = 21
     params = OL.synth_params(seed)
     ag._model.load({k: torch.tensor(v) for k, v in params.items()})
@@ -341,8 +348,11 @@ def test_bf16_storage_mode_tracks_fp32_training():
         for k in ("critic_loss", "disc_loss", "disc_grad_penalty", "disc_reward_mean", "adv_std", "mean_return"):
             x, y = float(a[0][it][k]), float(b[0][it][k])
             assert np.isfinite(y) and abs(x - y) <= 0.10 * max(abs(x), abs(y)) + 2e-3, (it, k, x, y)
-    for k, v in a[2].items():  # 240 optimiser steps at lr 1e-4: nobody moved further than 0.024 from the start
-        assert float((v - b[2][k]).abs().max()) <= 3e-2, k
+    # 240 optimiser steps at lr 1e-4: nobody moved further than 0.024 from the start, so two runs are at most 0.048 apart.  (The worst element
+    # -- a discriminator bias whose gradient sign is noise -- was seen between 2.9e-2 and 3.5e-2 over repeated runs of the same build: the
+    # default mode's float atomics make the 240-step trajectory differ from run to run.)
+    for k, v in a[2].items():
+        assert float((v - b[2][k]).abs().max()) <= 4e-2, k
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

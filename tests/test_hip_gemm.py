@@ -460,6 +460,23 @@ def test_to_bf16_rounds_to_nearest_even():
     assert torch.equal(dst[:, :4].cpu(), torch.tensor(x).to(torch.bfloat16)) and bool((dst[:, 4:] == 7.0).all())
 
 
+def test_normalize_to_bf16_is_the_normaliser_then_round_to_nearest_even():
+    """addhip_normalize_to_bf16: (x - mean) / std in fp32 (Normalizer.normalize, normalizer.py:107-110), then bf16 round to nearest even --
+    bit for bit what torch gives for the same two steps; columns past `cols` of the destination rows are left alone."""
+    import torch
+    import add_gym_amd._lib as L
+
+    torch.manual_seed(5)
+    rows, cols, ld_src, ld_dst = 777, 272, 272, 280
+    src = torch.randn(rows, ld_src, device="cuda") * 3
+    mean, std = torch.randn(cols, device="cuda"), torch.rand(cols, device="cuda") + 0.2
+    dst = torch.full((rows, ld_dst), 7.0, device="cuda", dtype=torch.bfloat16)
+    L.call("addhip_normalize_to_bf16", L.ptr(src), L.ptr(mean), L.ptr(std), L.ptr(dst), rows, cols, ld_src, ld_dst, L.current_stream())
+    torch.cuda.synchronize()
+    want = ((src[:, :cols] - mean) / std).to(torch.bfloat16)
+    assert torch.equal(dst[:, :cols], want) and bool((dst[:, cols:] == 7.0).all())
+
+
 def test_shadow_refresh_flat_and_transposed_in_one_launch():
     """addhip_shadow_refresh == addhip_to_bf16 over the flat buffer + addhip_to_bf16_t per listed matrix (ragged 32x32 tiles included)."""
     import ctypes as C

@@ -42,6 +42,6 @@ def iteration_ms(envs, rp, iters=4, warm=2):
 
 if __name__ == "__main__":
     for envs in (4096, 16384):
-        for rp in ("bf16x2", "bf16"):
+        for rp in ("bf16x2", "bf16", "bf16_storage"):
             ms, n = iteration_ms(envs, rp)
             print(f"envs {envs:6d} rollout_precision {rp:7s} iteration {ms:7.1f} ms  {n / ms * 1e3 / 1e6:6.3f} M env-steps/s", flush=True)
