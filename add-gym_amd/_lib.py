@@ -7,7 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaddhip.so")
 
 MAX_TAR = 8
-HIST = 3
+HIST = 3        # default task.num_disc_obs_steps
+HIST_MAX = 4    # ADDHIP_HIST_MAX
 DONE_NULL, DONE_FAIL, DONE_SUCC, DONE_TIME = 0, 1, 2, 3  # base_agent.py:16-20
 POSE_W = 36
 NUM_DOF = 29
@@ -28,7 +29,7 @@ class MotionT(C.Structure):
 
 class TaskT(C.Structure):
     _fields_ = [("dt", C.c_float), ("global_obs", C.c_int32), ("root_height_obs", C.c_int32), ("num_tar_steps", C.c_int32),
-                ("tar_dt", C.c_float * MAX_TAR), ("demo_dt", C.c_float * HIST), ("max_episode_length", C.c_float),
+                ("tar_dt", C.c_float * MAX_TAR), ("demo_dt", C.c_float * HIST_MAX), ("max_episode_length", C.c_float),
                 ("enable_early_termination", C.c_int32), ("pose_termination", C.c_int32), ("pose_termination_dist", C.c_float),
                 ("pose_w", C.c_float), ("vel_w", C.c_float), ("root_pose_w", C.c_float), ("root_vel_w", C.c_float),
                 ("pose_scale", C.c_float), ("vel_scale", C.c_float), ("root_pose_scale", C.c_float), ("root_vel_scale", C.c_float),

@@ -25,17 +25,22 @@ constexpr int WAVES = 4;
 // LDS rows: 16 staged in pass 0, 4 more (velocity history / demo velocity rows) in pass 1 when vel observations are on
 constexpr int R_SIM = 0, R_SIMV = 1, R_REF = 2, R_REFV = 3, R_TAR = 4, R_DEMO0 = 12, R_DEMO1 = 13, R_H0 = 14, R_H1 = 15;
 constexpr int R_D0V = 16, R_D1V = 17, R_H0V = 18, R_H1V = 19;
-constexpr int rows_of(bool vel) { return vel ? 20 : 16; }
+// four discriminator-observation steps (t.num_disc_obs_steps == 4): a third older demo / history row (+ their velocity rows), pass 1 too --
+// such tasks run the two-pass instantiation whether or not they carry velocity observations
+constexpr int R_DEMO2 = 20, R_H2 = 21, R_D2V = 22, R_H2V = 23;
+constexpr int rows_of(bool vel) { return vel ? 24 : 16; }
 
 // wave-private work area: derived values first, then the staged rows
 constexpr int TN_CHAR = 0, TN_TAR = 1, TN_H0 = 9, TN_H1 = 10, TN_SIMG = 11, TN_D0 = 12, TN_D1 = 13, TN_REF = 14, TN_SLOTS = 15;
-constexpr int OFF_TN = 0;                          // [15][6] tangent/normal vectors
-constexpr int OFF_TP = OFF_TN + TN_SLOTS * 6;      // [8][3] target position observations
+constexpr int TN_H2 = 15, TN_D2 = 16, TN_ALL = 17;  // (the two extra slots of a four-step task: derived by a second, small block)
+constexpr int OFF_TN = 0;                          // [17][6] tangent/normal vectors
+constexpr int OFF_TP = OFF_TN + TN_ALL * 6;        // [8][3] target position observations
 // root velocity / angular velocity observations (heading-local when !global_obs) of 6 (rotation, velocity) row pairs
 constexpr int TV_SIM = 0, TV_H0 = 1, TV_H1 = 2, TV_D0 = 3, TV_D1 = 4, TV_REF = 5, TV_SLOTS = 6;
-constexpr int OFF_TV = OFF_TP + ADDHIP_MAX_TAR_STEPS * 3;   // [6][6]
+constexpr int TV_H2 = 6, TV_D2 = 7, TV_ALL = 8;
+constexpr int OFF_TV = OFF_TP + ADDHIP_MAX_TAR_STEPS * 3;   // [8][6]
 constexpr int MAX_PHASE_ENC = 8;
-constexpr int OFF_PH = OFF_TV + TV_SLOTS * 6;               // phase, sin[P], cos[P]
+constexpr int OFF_PH = OFF_TV + TV_ALL * 6;                 // phase, sin[P], cos[P]
 constexpr int OFF_ZERO = OFF_PH + 1 + 2 * MAX_PHASE_ENC;
 constexpr int OFF_ROWS = (OFF_ZERO + 1 + 3) / 4 * 4;        // 16-byte aligned
 // LDS image of a row: 4 chunks of 9 floats padded to 12 so that each lane's chunk is 16-byte aligned
@@ -109,18 +114,18 @@ __device__ __forceinline__ int disc_src(const addhip_task_t& t, int o, bool demo
   constexpr int pw = 3 + 6 + ADDHIP_NUM_DOF;  // 38
   const int sw = pw + (t.enable_vel_obs ? 6 + ADDHIP_NUM_DOF : 0);
   const int c = o - (o / sw) * sw;
-  // step s of S = t.num_disc_obs_steps, oldest first: the last one is the current pose / the reference frame, the ones before it the
-  // history rows / the earlier clip frames (S = 2: one of each)
-  const int s = (o / sw == t.num_disc_obs_steps - 1) ? 2 : o / sw;
-  const int row = demo ? (s == 0 ? R_DEMO0 : (s == 1 ? R_DEMO1 : R_REF)) : (s == 0 ? R_H0 : (s == 1 ? R_H1 : R_SIM));
-  const int slot = demo ? (s == 0 ? TN_D0 : (s == 1 ? TN_D1 : TN_REF)) : (s == 0 ? TN_H0 : (s == 1 ? TN_H1 : TN_SIMG));
+  // step s of S = t.num_disc_obs_steps, oldest first: the last one (coded 3 here) is the current pose / the reference frame, the ones before
+  // it the history rows / the earlier clip frames 0, 1, 2 (S = 2: one of each, S = 4: three)
+  const int s = (o / sw == t.num_disc_obs_steps - 1) ? 3 : o / sw;
+  const int row = demo ? (s == 0 ? R_DEMO0 : s == 1 ? R_DEMO1 : s == 2 ? R_DEMO2 : R_REF) : (s == 0 ? R_H0 : s == 1 ? R_H1 : s == 2 ? R_H2 : R_SIM);
+  const int slot = demo ? (s == 0 ? TN_D0 : s == 1 ? TN_D1 : s == 2 ? TN_D2 : TN_REF) : (s == 0 ? TN_H0 : s == 1 ? TN_H1 : s == 2 ? TN_H2 : TN_SIMG);
   if (c < 3) return (!t.global_obs && c < 2) ? OFF_ZERO : row_off(row, c);
   if (c < 9) return OFF_TN + slot * 6 + (c - 3);
   if (c < pw) return row_off(row, 7 + c - 9);
   // compute_vel_obs (add_observation.py:502-517)
   const int cv = c - pw;
-  const int vrow = demo ? (s == 0 ? R_D0V : (s == 1 ? R_D1V : R_REFV)) : (s == 0 ? R_H0V : (s == 1 ? R_H1V : R_SIMV));
-  const int vslot = demo ? (s == 0 ? TV_D0 : (s == 1 ? TV_D1 : TV_REF)) : (s == 0 ? TV_H0 : (s == 1 ? TV_H1 : TV_SIM));
+  const int vrow = demo ? (s == 0 ? R_D0V : s == 1 ? R_D1V : s == 2 ? R_D2V : R_REFV) : (s == 0 ? R_H0V : s == 1 ? R_H1V : s == 2 ? R_H2V : R_SIMV);
+  const int vslot = demo ? (s == 0 ? TV_D0 : s == 1 ? TV_D1 : s == 2 ? TV_D2 : TV_REF) : (s == 0 ? TV_H0 : s == 1 ? TV_H1 : s == 2 ? TV_H2 : TV_SIM);
   return cv < 6 ? OFF_TV + vslot * 6 + cv : row_off(vrow, 6 + cv - 6);
 }
 __device__ __forceinline__ void build_maps(const addhip_task_t& t, short* maps) {
@@ -162,9 +167,10 @@ enum { ROLE_SKIP = 0, ROLE_TABLE = 1, ROLE_ENV = 2 };
 
 // FRESH (reset): every row comes from the clip tables, the env pointers are never touched
 template <bool VEL, bool FRESH>
-__device__ __forceinline__ Role lane_role(const addhip_task_t& t, const Tables& tb, const EnvPtrs& ep, int lane, int pass, int h0, int h1) {
+__device__ __forceinline__ Role lane_role(const addhip_task_t& t, const Tables& tb, const EnvPtrs& ep, int lane, int pass, int h0, int h1, int h2) {
   constexpr bool fresh = FRESH;
-  const bool three = t.num_disc_obs_steps == ADDHIP_HIST;  // (two steps: the second history / clip row is not staged)
+  const bool three = t.num_disc_obs_steps >= 3, four = t.num_disc_obs_steps == 4;  // (two steps: the second history / clip row is not staged)
+  const bool vel_on = VEL && t.enable_vel_obs;  // (a four-step task without velocity observations runs the two-pass instantiation too)
   const int r = pass * 16 + (lane >> 2), q = lane & 3;
   int kind = K_SKIP, hslot = 0;
   float dt = 0.0f;
@@ -178,12 +184,18 @@ __device__ __forceinline__ Role lane_role(const addhip_task_t& t, const Tables& 
   else if (r == R_DEMO1 || (r == R_H1 && fresh)) { if (three) { kind = K_POSE; dt = t.demo_dt[1]; } }
   else if (r == R_H0) { kind = K_HIST; hslot = h0; }
   else if (r == R_H1) { if (three) { kind = K_HIST; hslot = h1; } }
-  else if (r == R_SIMV) { if (VEL || !FRESH) kind = fresh ? K_VEL : K_SIMV; }  // the step's reward reads it too
+  else if (r == R_SIMV) { if (vel_on || !FRESH) kind = fresh ? K_VEL : K_SIMV; }  // the step's reward reads it too
   else if (VEL) {
-    if (r == R_D0V || (r == R_H0V && fresh)) { kind = K_VEL; dt = t.demo_dt[0]; }
-    else if (r == R_D1V || (r == R_H1V && fresh)) { if (three) { kind = K_VEL; dt = t.demo_dt[1]; } }
-    else if (r == R_H0V) { kind = K_HISTV; hslot = h0; }
-    else if (r == R_H1V) { if (three) { kind = K_HISTV; hslot = h1; } }
+    if (r == R_DEMO2 || (r == R_H2 && fresh)) { if (four) { kind = K_POSE; dt = t.demo_dt[2]; } }
+    else if (r == R_H2) { if (four) { kind = K_HIST; hslot = h2; } }
+    else if (vel_on) {
+      if (r == R_D0V || (r == R_H0V && fresh)) { kind = K_VEL; dt = t.demo_dt[0]; }
+      else if (r == R_D1V || (r == R_H1V && fresh)) { if (three) { kind = K_VEL; dt = t.demo_dt[1]; } }
+      else if (r == R_D2V || (r == R_H2V && fresh)) { if (four) { kind = K_VEL; dt = t.demo_dt[2]; } }
+      else if (r == R_H0V) { kind = K_HISTV; hslot = h0; }
+      else if (r == R_H1V) { if (three) { kind = K_HISTV; hslot = h1; } }
+      else if (r == R_H2V) { if (four) { kind = K_HISTV; hslot = h2; } }
+    }
   }
   Role ro{ROLE_SKIP, dt, nullptr, PW};
   if (kind == K_SKIP) return ro;
@@ -236,6 +248,19 @@ __device__ __forceinline__ Quat lds_quat(const float* w, int r) {
   return Quat{w[row_off(r, 3)], w[row_off(r, 4)], w[row_off(r, 5)], w[row_off(r, 6)]};
 }
 
+// velocity / angular velocity of row rv in the heading frame of row rr (or the global frame) -> slot s of OFF_TV
+template <bool GLOBAL>
+__device__ __forceinline__ void vel_slot(float* w, int s, int rr, int rv) {
+  Vec3 v{w[row_off(rv, 0)], w[row_off(rv, 1)], w[row_off(rv, 2)]}, a{w[row_off(rv, 3)], w[row_off(rv, 4)], w[row_off(rv, 5)]};
+  if (!GLOBAL) {
+    const Quat h = heading_quat_inv(lds_quat(w, rr));
+    v = quat_rotate(h, v);
+    a = quat_rotate(h, a);
+  }
+  float* d = w + OFF_TV + s * 6;
+  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = a.x; d[4] = a.y; d[5] = a.z;
+}
+
 // per-env arithmetic, once: lane s < 15 -> tangent+normal (torch_util.py:231-242) of quaternion slot s;
 // lanes 16.. -> target position observations (add_observation.py:589-618)
 template <bool GLOBAL, bool VEL, bool PHASE>
@@ -265,18 +290,11 @@ __device__ __forceinline__ void derive(const addhip_task_t& t, float* w, int lan
     }
     w[OFF_TP + i] = v;
   } else if (lane >= 40 && lane < 40 + TV_SLOTS) {
-    if (VEL) {  // compute_char_obs / compute_vel_obs velocity terms (add_observation.py:445-452, 502-517)
+    if (VEL && t.enable_vel_obs) {  // compute_char_obs / compute_vel_obs velocity terms (add_observation.py:445-452, 502-517)
       const int s = lane - 40;
       const int rr = s == TV_SIM ? R_SIM : s == TV_H0 ? R_H0 : s == TV_H1 ? R_H1 : s == TV_D0 ? R_DEMO0 : s == TV_D1 ? R_DEMO1 : R_REF;
       const int rv = s == TV_SIM ? R_SIMV : s == TV_H0 ? R_H0V : s == TV_H1 ? R_H1V : s == TV_D0 ? R_D0V : s == TV_D1 ? R_D1V : R_REFV;
-      Vec3 v{w[row_off(rv, 0)], w[row_off(rv, 1)], w[row_off(rv, 2)]}, a{w[row_off(rv, 3)], w[row_off(rv, 4)], w[row_off(rv, 5)]};
-      if (!GLOBAL) {
-        const Quat h = heading_quat_inv(lds_quat(w, rr));
-        v = quat_rotate(h, v);
-        a = quat_rotate(h, a);
-      }
-      float* d = w + OFF_TV + s * 6;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = a.x; d[4] = a.y; d[5] = a.z;
+      vel_slot<GLOBAL>(w, s, rr, rv);
     }
   } else if (lane >= 46 && lane < 47 + 2 * MAX_PHASE_ENC) {
     if (PHASE) {  // compute_phase_obs (add_observation.py:557-575)
@@ -292,6 +310,16 @@ __device__ __forceinline__ void derive(const addhip_task_t& t, float* w, int lan
     }
   } else if (lane == 63) {
     w[OFF_ZERO] = 0.0f;
+  }
+  if (VEL && t.num_disc_obs_steps == 4) {  // the third older history / clip row of a four-step task: two more quaternion slots, two more velocity slots
+    if (lane < 2) {
+      const Quat q = lds_quat(w, lane == 0 ? R_H2 : R_DEMO2);
+      const Vec3 tan = quat_rotate(q, Vec3{1.0f, 0.0f, 0.0f}), nrm = quat_rotate(q, Vec3{0.0f, 0.0f, 1.0f});
+      float* d = w + OFF_TN + (lane == 0 ? TN_H2 : TN_D2) * 6;
+      d[0] = tan.x; d[1] = tan.y; d[2] = tan.z; d[3] = nrm.x; d[4] = nrm.y; d[5] = nrm.z;
+    } else if (lane < 4 && t.enable_vel_obs) {
+      vel_slot<GLOBAL>(w, lane == 2 ? TV_H2 : TV_D2, lane == 2 ? R_H2 : R_DEMO2, lane == 2 ? R_H2V : R_D2V);
+    }
   }
 }
 
@@ -423,12 +451,12 @@ __global__ __launch_bounds__(64 * WAVES) void env_step_kernel(addhip_task_t t, S
   float* w = lds[wv];
   float* slots = slot_mem[wv];
   build_maps(t, maps);
-  const int S = t.num_disc_obs_steps;  // ring depth
-  const int h0 = (a.head + 1) % S, h1 = (a.head + 2) % S;
+  const int S = t.num_disc_obs_steps;  // ring depth: slot a.head receives this step's pose, the others hold the S - 1 poses before it, oldest first from head + 1
+  const int h0 = (a.head + 1) % S, h1 = (a.head + 2) % S, h2 = (a.head + 3) % S;
   const EnvPtrs ep{a.sim_pose, a.sim_vel, a.hist, a.hist_vel};
-  const Role ro = lane_role<VEL, false>(t, a.tb, ep, lane, 0, h0, h1);
+  const Role ro = lane_role<VEL, false>(t, a.tb, ep, lane, 0, h0, h1, h2);
   Role ro1{ROLE_SKIP, 0.0f, nullptr, PW};
-  if (VEL) ro1 = lane_role<VEL, false>(t, a.tb, ep, lane, 1, h0, h1);
+  if (VEL) ro1 = lane_role<VEL, false>(t, a.tb, ep, lane, 1, h0, h1, h2);
   const int n_obs = t.obs_stride, n_disc = t.disc_stride;
   // loop-invariant LDS offsets of this lane's reward inputs: lanes 0-28 dof positions, 32-60 dof velocities; lanes
   // 0-25 also copy one root value each
@@ -493,7 +521,7 @@ __global__ __launch_bounds__(64 * WAVES) void env_step_kernel(addhip_task_t t, S
       if (lane < PW) {
         // history push (circular_buffer.py:17-20) and, optionally, the reference state (add_observation.py:163-174)
         a.hist[((size_t)env * S + a.head) * PW + lane] = w[row_off(R_SIM, lane)];
-        if (VEL) a.hist_vel[((size_t)env * S + a.head) * PW + lane] = w[row_off(R_SIMV, lane)];
+        if (VEL && t.enable_vel_obs) a.hist_vel[((size_t)env * S + a.head) * PW + lane] = w[row_off(R_SIMV, lane)];
         if (a.ref_pose) a.ref_pose[(size_t)env * PW + lane] = w[row_off(R_REF, lane)];
         if (a.ref_vel) a.ref_vel[(size_t)env * PW + lane] = w[row_off(R_REFV, lane)];
       }
@@ -566,9 +594,9 @@ __global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_task_t t, 
   float* w = lds[wv];
   build_maps(t, maps);
   const EnvPtrs ep{nullptr, nullptr, nullptr, nullptr};
-  const Role ro = lane_role<VEL, true>(t, a.tb, ep, lane, 0, 0, 0);
+  const Role ro = lane_role<VEL, true>(t, a.tb, ep, lane, 0, 0, 0, 0);
   Role ro1{ROLE_SKIP, 0.0f, nullptr, PW};
-  if (VEL) ro1 = lane_role<VEL, true>(t, a.tb, ep, lane, 1, 0, 0);
+  if (VEL) ro1 = lane_role<VEL, true>(t, a.tb, ep, lane, 1, 0, 0, 0);
   const int n_obs = t.obs_stride, n_disc = t.disc_stride;
   __syncthreads();  // maps
   for (int env = blockIdx.x * WAVES + wv; env < a.num_envs; env += gridDim.x * WAVES) {
@@ -620,16 +648,18 @@ __global__ __launch_bounds__(64 * WAVES) void env_reset_kernel(addhip_task_t t, 
         if (a.ref_pose) a.ref_pose[(size_t)env * PW + lane] = pose;
         if (a.ref_vel) a.ref_vel[(size_t)env * PW + lane] = vel;
         // CircularBuffer.fill (circular_buffer.py:22-29): get_all() order = demo frames t-2dt, t-dt, t
-        // (S = t.num_disc_obs_steps slots: S = 2 holds t-dt, t)
+        // (S = t.num_disc_obs_steps slots: S = 2 holds t-dt, t; S = 4: t-3dt .. t)
         const int S = t.num_disc_obs_steps;
         float* hb = a.hist + (size_t)env * S * PW;
         hb[((a.head + 0) % S) * PW + lane] = w[row_off(R_DEMO0, lane)];
-        if (S == ADDHIP_HIST) hb[((a.head + 1) % S) * PW + lane] = w[row_off(R_DEMO1, lane)];
+        if (S >= 3) hb[((a.head + 1) % S) * PW + lane] = w[row_off(R_DEMO1, lane)];
+        if (VEL && S == 4) hb[((a.head + 2) % S) * PW + lane] = w[row_off(R_DEMO2, lane)];
         hb[((a.head + S - 1) % S) * PW + lane] = pose;
-        if (VEL) {
+        if (VEL && t.enable_vel_obs) {
           float* hv = a.hist_vel + (size_t)env * S * PW;
           hv[((a.head + 0) % S) * PW + lane] = w[row_off(R_D0V, lane)];
-          if (S == ADDHIP_HIST) hv[((a.head + 1) % S) * PW + lane] = w[row_off(R_D1V, lane)];
+          if (S >= 3) hv[((a.head + 1) % S) * PW + lane] = w[row_off(R_D1V, lane)];
+          if (S == 4) hv[((a.head + 2) % S) * PW + lane] = w[row_off(R_D2V, lane)];
           hv[((a.head + S - 1) % S) * PW + lane] = vel;
         }
       }
@@ -672,9 +702,9 @@ int check_common(const addhip_motion_t* m, const addhip_task_t* t, const addhip_
   ADDHIP_REQUIRE(m->pose && m->vel && m->clip_start && m->clip_len && m->clip_loop && m->clip_steps, "motion tables missing");
   ADDHIP_REQUIRE(m->total_steps > 0 && m->num_clips > 0, "empty motion library");
   ADDHIP_REQUIRE((long long)m->total_steps * PW < (1ll << 31), "motion table too large for 32-bit row offsets");
-  ADDHIP_REQUIRE((long long)e->num_envs * ADDHIP_HIST * PW < (1ll << 31), "env count too large for 32-bit row offsets");
+  ADDHIP_REQUIRE((long long)e->num_envs * ADDHIP_HIST_MAX * PW < (1ll << 31), "env count too large for 32-bit row offsets");
   ADDHIP_REQUIRE(t->num_tar_steps >= 0 && t->num_tar_steps <= ADDHIP_MAX_TAR_STEPS, "num_tar_steps out of range");
-  ADDHIP_REQUIRE(t->num_disc_obs_steps >= 2 && t->num_disc_obs_steps <= ADDHIP_HIST, "num_disc_obs_steps must be 2 or %d", ADDHIP_HIST);
+  ADDHIP_REQUIRE(t->num_disc_obs_steps >= 2 && t->num_disc_obs_steps <= ADDHIP_HIST_MAX, "num_disc_obs_steps must be in 2..%d", ADDHIP_HIST_MAX);
   ADDHIP_REQUIRE(t->demo_dt[t->num_disc_obs_steps - 1] == 0.0f, "demo_dt[last] must be 0 (newest demo frame == reference frame)");
   const int hc = t->root_height_obs ? 1 : 0;
   const int vw = t->enable_vel_obs ? 6 + ADDHIP_NUM_DOF : 0;
@@ -685,7 +715,7 @@ int check_common(const addhip_motion_t* m, const addhip_task_t* t, const addhip_
   ADDHIP_REQUIRE(t->disc_dim == t->num_disc_obs_steps * (9 + ADDHIP_NUM_DOF + vw), "disc_dim must be %d", t->num_disc_obs_steps * (9 + ADDHIP_NUM_DOF + vw));
   ADDHIP_REQUIRE(!t->enable_vel_obs || e->hist_vel, "hist_vel is required when enable_vel_obs is set");
   ADDHIP_REQUIRE(t->obs_stride >= t->obs_dim && t->disc_stride >= t->disc_dim, "strides smaller than dims");
-  const int map_max = map_of(t->enable_vel_obs != 0, t->enable_phase_obs != 0);
+  const int map_max = map_of(t->enable_vel_obs != 0 || t->num_disc_obs_steps == 4, t->enable_phase_obs != 0);
   ADDHIP_REQUIRE(t->obs_stride + 2 * t->disc_stride <= map_max, "obs_stride + 2*disc_stride must be <= %d", map_max);
   ADDHIP_REQUIRE(e->sim_pose && e->sim_vel && e->time && e->time_off && e->motion_id && e->hist && e->done, "env state pointers missing");
   ADDHIP_REQUIRE(!e->ret_acc || e->len_acc, "ret_acc needs len_acc");
@@ -719,7 +749,8 @@ extern "C" int addhip_env_step(const addhip_motion_t* m, const addhip_task_t* t,
   const int groups = (e->num_envs + epw - 1) / epw;
   const int blocks = (groups + WAVES - 1) / WAVES;
   const dim3 grid(blocks), block(64 * WAVES);
-  const int variant = (t->global_obs ? 4 : 0) | (t->enable_vel_obs ? 2 : 0) | (t->enable_phase_obs ? 1 : 0);
+  // (a four-step task stages its third history / clip row in pass 1: the two-pass instantiation with or without velocity observations)
+  const int variant = (t->global_obs ? 4 : 0) | ((t->enable_vel_obs || t->num_disc_obs_steps == 4) ? 2 : 0) | (t->enable_phase_obs ? 1 : 0);
 #define ADDHIP_STEP(G, V, P) hipLaunchKernelGGL((env_step_kernel<G, V, P>), grid, block, 0, st, *t, a)
   switch (variant) {
     case 0: ADDHIP_STEP(false, false, false); break;
@@ -753,7 +784,8 @@ extern "C" int addhip_env_reset(const addhip_motion_t* m, const addhip_task_t* t
   ResetArgs a{tables_of(m), m->clip_len, e->sim_pose, e->sim_vel, e->time, e->time_off, e->motion_id, e->hist, e->hist_vel, e->done, e->ref_pose, e->ref_vel,
               u_seg, u_jit, obs_out, disc_obs_out, disc_demo_out, e->num_envs, head, reset_all};
   const dim3 grid(env_grid(e->num_envs)), block(64 * WAVES);
-  const int variant = (t->global_obs ? 4 : 0) | (t->enable_vel_obs ? 2 : 0) | (t->enable_phase_obs ? 1 : 0);
+  // (a four-step task stages its third history / clip row in pass 1: the two-pass instantiation with or without velocity observations)
+  const int variant = (t->global_obs ? 4 : 0) | ((t->enable_vel_obs || t->num_disc_obs_steps == 4) ? 2 : 0) | (t->enable_phase_obs ? 1 : 0);
 #define ADDHIP_RESET(G, V, P) hipLaunchKernelGGL((env_reset_kernel<G, V, P>), grid, block, 0, st, *t, *s, a)
   switch (variant) {
     case 0: ADDHIP_RESET(false, false, false); break;

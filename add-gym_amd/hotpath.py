@@ -40,8 +40,8 @@ def check_supported(task):
     Anything else fails loudly instead of silently computing something different."""
     if task.get("enable_phase_obs", True) and int(task.get("num_phase_encoding", 0)) > 8:
         raise NotImplementedError("task.num_phase_encoding must be <= 8")
-    if not 2 <= disc_steps(task) <= L.HIST:
-        raise NotImplementedError(f"task.num_disc_obs_steps must be 2 or {L.HIST} (the env-step kernel stages at most {L.HIST - 1} history rows)")
+    if not 2 <= disc_steps(task) <= L.HIST_MAX:
+        raise NotImplementedError(f"task.num_disc_obs_steps must be in 2..{L.HIST_MAX} (the env-step kernel stages at most {L.HIST_MAX - 1} history rows)")
     if task.get("visualize_ref_char", False):
         raise NotImplementedError("task.visualize_ref_char needs a viewer (out of scope)")
     if len(task.get("tar_obs_steps", [1])) > L.MAX_TAR:

@@ -30,7 +30,8 @@ extern "C" {
 #define ADDHIP_POSE_W 36
 #define ADDHIP_NUM_DOF 29
 #define ADDHIP_MAX_TAR_STEPS 8
-#define ADDHIP_HIST 3
+#define ADDHIP_HIST 3          /* default task.num_disc_obs_steps (configs/task/pose.yaml) */
+#define ADDHIP_HIST_MAX 4      /* largest supported */
 
 enum { ADDHIP_DONE_NULL = 0, ADDHIP_DONE_FAIL = 1, ADDHIP_DONE_SUCC = 2, ADDHIP_DONE_TIME = 3 };
 
@@ -63,7 +64,7 @@ typedef struct {
   int32_t global_obs, root_height_obs;
   int32_t num_tar_steps;          /* len(tar_obs_steps) */
   float tar_dt[ADDHIP_MAX_TAR_STEPS]; /* fl32(dt * step_k)   (add_observation.py:215) */
-  float demo_dt[ADDHIP_HIST];     /* fl32(-dt*j) flipped     (add_observation.py:366-369) */
+  float demo_dt[ADDHIP_HIST_MAX]; /* fl32(-dt*j) flipped     (add_observation.py:366-369); [0, num_disc_obs_steps) used */
   float max_episode_length;
   int32_t enable_early_termination, pose_termination;
   float pose_termination_dist;
@@ -73,7 +74,7 @@ typedef struct {
   int32_t enable_vel_obs;         /* root vel / ang vel / dof vel in the policy and discriminator observations */
   int32_t enable_phase_obs;       /* motion phase (+ 2*num_phase_encoding positional terms) in the policy observation */
   int32_t num_phase_encoding;     /* <= 8 */
-  int32_t num_disc_obs_steps;     /* S = 2 or 3 (ADDHIP_HIST): poses per discriminator observation = depth of the history ring [N, S, 36]
+  int32_t num_disc_obs_steps;     /* S = 2 .. ADDHIP_HIST_MAX: poses per discriminator observation = depth of the history ring [N, S, 36]
                                      (add_observation.py:276-294, 362-375); demo_dt[0..S) are used, demo_dt[S-1] = 0 */
 } addhip_task_t;
 

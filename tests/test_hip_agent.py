@@ -207,10 +207,11 @@ def _mid(cdf, k):
 LOOP_VARIANTS = {"loop_1iter": dict(two=False, task={}), "loop_1iter_two": dict(two=True, task={}),
                  "loop_1iter_time": dict(two=False, task=dict(max_episode_length=0.4)),
                  # task.num_disc_obs_steps = 2: two-deep history ring, 76-wide discriminator input
-                 "loop_1iter_s2": dict(two=False, task=dict(num_disc_obs_steps=2))}
+                 "loop_1iter_s2": dict(two=False, task=dict(num_disc_obs_steps=2)),
+                 "loop_1iter_s4": dict(two=False, task=dict(num_disc_obs_steps=4))}
 
 
-@pytest.mark.parametrize("name,precision", [("loop_1iter", p) for p in PRECISIONS] + [("loop_1iter_two", "fp32"), ("loop_1iter_time", "fp32"), ("loop_1iter_s2", "fp32")])
+@pytest.mark.parametrize("name,precision", [("loop_1iter", p) for p in PRECISIONS] + [("loop_1iter_two", "fp32"), ("loop_1iter_time", "fp32"), ("loop_1iter_s2", "fp32"), ("loop_1iter_s4", "fp32")])
 def test_one_full_iteration_matches_reference_and_oracle(name, precision):
     """BASELINE config 1 stand-in: the reference's own iteration (fake kinematic engine, recorded draws) replayed
     through the HIP engine.  Variants: the two-clip library (clip draws, raw-frame table offsets, [2,20] sampler table) and a
@@ -314,7 +315,7 @@ def test_one_full_iteration_matches_reference_and_oracle(name, precision):
     # (the actor's first layer is where 40 Adam steps amplify rounding most -- mean |difference| of the sampled weights over the fixtures, fp32:
     # 1.2e-5, 2.8e-5, 3.0e-5, two-step fixture 5.9e-5, of 4e-3 travelled -- while critic and discriminator stay within 1e-9 .. 3e-7 in all four,
     # the two-step discriminator included; the two-step fixture gets twice the mean bound)
-    _check_param_summary(g, "param", ph, 40, long_run=True, mean_frac=0.02 if name == "loop_1iter_s2" else 0.01)
+    _check_param_summary(g, "param", ph, 40, long_run=True, mean_frac=0.02 if name in ("loop_1iter_s2", "loop_1iter_s4") else 0.01)
 
 
 def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):

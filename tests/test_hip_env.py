@@ -153,7 +153,9 @@ VARIANTS = {"default": {}, "local": dict(global_obs=False), "noheight": dict(roo
             "vel_phase": dict(enable_vel_obs=True, enable_phase_obs=True, num_phase_encoding=4),
             "local_vel": dict(global_obs=False, enable_vel_obs=True),
             # task.num_disc_obs_steps = 2 (add_observation.py:276-294, 362-375; fixture obs_reward_done_s2): the ring depth is a task field
-            "two_steps": dict(num_disc_obs_steps=2), "two_steps_local_vel": dict(num_disc_obs_steps=2, global_obs=False, enable_vel_obs=True)}
+            "two_steps": dict(num_disc_obs_steps=2), "two_steps_local_vel": dict(num_disc_obs_steps=2, global_obs=False, enable_vel_obs=True),
+            # = 4 (fixture obs_reward_done_s4): the third older history / clip row is staged in the kernel's second pass
+            "four_steps": dict(num_disc_obs_steps=4), "four_steps_local_vel": dict(num_disc_obs_steps=4, global_obs=False, enable_vel_obs=True)}
 
 
 @pytest.mark.parametrize("vname", list(VARIANTS) + ["joint_w"])
@@ -221,18 +223,20 @@ def _mid_bin_u(cdf, k):
     return F(0.5 * (lo + float(cdf[k])))
 
 
-@pytest.mark.parametrize("tag", ["one", "two", "one_two_steps"])
+@pytest.mark.parametrize("tag", ["one", "two", "one_two_steps", "one_four_steps"])
 def test_env_reset_matches_reference(tag):
-    """(`one_two_steps`: task.num_disc_obs_steps = 2, fixture reset_s2 -- the reset fills a two-deep ring with the clip frames t-dt, t.)"""
+    """(`one_two_steps` / `one_four_steps`: task.num_disc_obs_steps = 2 / 4, fixtures reset_s2 / reset_s4 -- the reset fills an S-deep ring
+    with the clip frames t-(S-1)dt .. t.)"""
     import torch
     import add_gym_amd._lib as L
     from add_gym_amd.hotpath import make_task
     from oracle.task import SegmentSampler
 
-    s2 = tag == "one_two_steps"
-    v = variant(gload("reset_s2" if s2 else "reset"), "one" if s2 else tag)
+    steps = {"one_two_steps": 2, "one_four_steps": 4}.get(tag, 3)
+    s2 = steps != 3
+    v = variant(gload(f"reset_s{steps}" if s2 else "reset"), "one" if s2 else tag)
     two = tag == "two"
-    task = make_task({**DEFAULT_TASK, **(dict(num_disc_obs_steps=2) if s2 else {})}, 0.01)
+    task = make_task({**DEFAULT_TASK, "num_disc_obs_steps": steps}, 0.01)
     mot = HipMotion(two)
     n = v["time"].shape[0]
     pose = pack_pose(v["sim_root_pos"], v["sim_root_rot"], v["sim_dof_pos"])
@@ -275,7 +279,7 @@ def test_env_reset_matches_reference(tag):
     assert np.array_equal(st["hist"].cpu().numpy(), fixture_hist(v, "post_"))
     np.testing.assert_allclose(obs.cpu().numpy()[env_ids][:, :264], v["obs"][env_ids], rtol=0, atol=ATOL)
     dd = task.disc_dim
-    assert dd == (76 if s2 else 114) and v["disc_obs"].shape[1] == dd
+    assert dd == 38 * steps and v["disc_obs"].shape[1] == dd
     np.testing.assert_allclose(disc.cpu().numpy()[env_ids][:, :dd], v["disc_obs"][env_ids], rtol=0, atol=ATOL)
     np.testing.assert_allclose(demo.cpu().numpy()[env_ids][:, :dd], v["disc_obs_demo"][env_ids], rtol=0, atol=ATOL)
     untouched = np.setdiff1d(np.arange(n), env_ids)

@@ -125,13 +125,17 @@ VARIANTS = {
     # task.num_disc_obs_steps = 2 (fixture obs_reward_done_s2): a two-deep history ring, two clip frames per demo observation
     "two_steps": dict(num_disc_obs_steps=2),
     "two_steps_local_vel": dict(num_disc_obs_steps=2, global_obs=False, enable_vel_obs=True),
+    # = 4 (fixture obs_reward_done_s4)
+    "four_steps": dict(num_disc_obs_steps=4),
+    "four_steps_local_vel": dict(num_disc_obs_steps=4, global_obs=False, enable_vel_obs=True),
 }
 FIELDS = T.TaskState.FIELDS
 
 
 def step_fixture(vname):
     """The fixture that holds a variant of the env-step case."""
-    return "obs_reward_done_jw" if vname == "joint_w" else "obs_reward_done_s2" if vname.startswith("two_steps") else "obs_reward_done"
+    return ("obs_reward_done_jw" if vname == "joint_w" else "obs_reward_done_s2" if vname.startswith("two_steps") else
+            "obs_reward_done_s4" if vname.startswith("four_steps") else "obs_reward_done")
 
 
 def _task_from_fixture(v, cfg, lib, n, prefix="", sim_prefix=None):
@@ -164,6 +168,8 @@ def test_obs_reward_done(vname):
     assert done.dtype == np.int32 and np.array_equal(done, v["done"])
     if vname == "two_steps":
         assert d_obs.shape[1] == 76 and ts.hist["root_pos"].shape[1] == 2
+    if vname == "four_steps":
+        assert d_obs.shape[1] == 152 and ts.hist["root_pos"].shape[1] == 4
     if vname == "default":
         assert obs.shape[1] == 264 and d_obs.shape[1] == 114
         assert set(np.unique(done)) == {0, 1, 2, 3}  # every flag occurs
@@ -190,9 +196,10 @@ def test_reset(tag):
     _reset_case("reset", tag, T.TaskCfg())
 
 
-def test_reset_two_disc_obs_steps():
-    """task.num_disc_obs_steps = 2: CircularBuffer.fill writes the clip frames t-dt, t (circular_buffer.py:22-29)."""
-    _reset_case("reset_s2", "one", T.TaskCfg(num_disc_obs_steps=2))
+@pytest.mark.parametrize("steps", [2, 4])
+def test_reset_other_disc_obs_steps(steps):
+    """task.num_disc_obs_steps = 2 / 4: CircularBuffer.fill writes the clip frames t-(S-1)dt .. t (circular_buffer.py:22-29)."""
+    _reset_case(f"reset_s{steps}", "one", T.TaskCfg(num_disc_obs_steps=steps))
 
 
 def _reset_case(fixture, tag, cfg):
@@ -328,7 +335,8 @@ def test_losses_grads_adamw(name):
 
 LOOP_VARIANTS = {"loop_1iter": dict(two=False, task={}), "loop_1iter_two": dict(two=True, task={}),
                  "loop_1iter_time": dict(two=False, task=dict(max_episode_length=0.4)),
-                 "loop_1iter_s2": dict(two=False, task=dict(num_disc_obs_steps=2))}
+                 "loop_1iter_s2": dict(two=False, task=dict(num_disc_obs_steps=2)),
+                 "loop_1iter_s4": dict(two=False, task=dict(num_disc_obs_steps=4))}
 
 
 @pytest.mark.parametrize("name", list(LOOP_VARIANTS))

@@ -131,10 +131,10 @@ def gen_obs_reward_done_jw():
     gen_obs_reward_done({"joint_w": dict(joint_err_w=JOINT_ERR_W)}, "obs_reward_done_jw")
 
 
-def gen_obs_reward_done_s2():
-    """task.num_disc_obs_steps = 2 (add_observation.py:276-294, 362-375): a two-deep history ring, two clip frames per demo observation."""
-    gen_obs_reward_done({"two_steps": dict(num_disc_obs_steps=2), "two_steps_local_vel": dict(num_disc_obs_steps=2, global_obs=False, enable_vel_obs=True)},
-                        "obs_reward_done_s2")
+def gen_obs_reward_done_s2(S=2, word="two"):
+    """task.num_disc_obs_steps = 2 / 4 (add_observation.py:276-294, 362-375): an S-deep history ring, S clip frames per demo observation."""
+    gen_obs_reward_done({f"{word}_steps": dict(num_disc_obs_steps=S), f"{word}_steps_local_vel": dict(num_disc_obs_steps=S, global_obs=False, enable_vel_obs=True)},
+                        f"obs_reward_done_s{S}")
 
 
 def gen_obs_reward_done(variants=None, name="obs_reward_done"):
@@ -191,8 +191,8 @@ def gen_obs_reward_done(variants=None, name="obs_reward_done"):
     _save(name, **out)
 
 
-def gen_reset_s2():
-    gen_reset("reset_s2", dict(num_disc_obs_steps=2), (("one", False),))
+def gen_reset_s2(S=2):
+    gen_reset(f"reset_s{S}", dict(num_disc_obs_steps=S), (("one", False),))
 
 
 def gen_reset(name="reset", task_over=None, tags=(("one", False), ("two", True))):
@@ -605,5 +605,6 @@ def gen_test_rollout():
           mean_return=float(info["mean_return"]), mean_ep_len=float(info["mean_ep_len"]), num_eps=int(info["num_eps"]))
 
 
-AGENT_GENS = dict(obs_reward_done_s2=gen_obs_reward_done_s2, reset_s2=gen_reset_s2, loop_1iter_s2=lambda: gen_loop_1iter("loop_1iter_s2", task_over=dict(num_disc_obs_steps=2)), loop_1iter_two=gen_loop_1iter_two, loop_1iter_time=gen_loop_1iter_time, logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
+AGENT_GENS = dict(obs_reward_done_s4=lambda: gen_obs_reward_done_s2(4, "four"), reset_s4=lambda: gen_reset_s2(4),
+                  loop_1iter_s4=lambda: gen_loop_1iter("loop_1iter_s4", task_over=dict(num_disc_obs_steps=4)), obs_reward_done_s2=gen_obs_reward_done_s2, reset_s2=gen_reset_s2, loop_1iter_s2=lambda: gen_loop_1iter("loop_1iter_s2", task_over=dict(num_disc_obs_steps=2)), loop_1iter_two=gen_loop_1iter_two, loop_1iter_time=gen_loop_1iter_time, logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
                   td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, losses_small_nets=gen_losses_small_nets, losses_constant_std=gen_losses_constant_std, actor_step_constant_std=lambda: gen_actor_step("actor_step_constant_std", True), normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
