@@ -44,6 +44,8 @@ def parse():
                     "One warm-up + one timed iteration (about 25 s each at 4096 envs on 16 cores)")
     ap.add_argument("--no-configs2", action="store_true", help="skip the BASELINE configs[2] entry (16 384 envs, 5-clip set, bf16-storage MLP path)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement after the headline run")
+    ap.add_argument("--with-alt", action="store_true", help="N > 1: also run the alternative modes / engine / configs[2] entries (default there: headline only, "
+                                                             "so that a scaling run is the headline workload and nothing else)")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="N=1 only: join a 1-rank RCCL group so that the multi-rank exchange path (async gradient buckets) runs; rehearsal, not a headline")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x2", "bf16"],
@@ -298,6 +300,8 @@ def main():
     launch.check_world_fits(world, torch.cuda.device_count())
     launch.bind_device(local_rank)
     distributed = world > 1 or a.exercise_exchange
+    if world > 1 and not a.with_alt:
+        a.no_alt = True
     if distributed and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29655")
