@@ -129,8 +129,8 @@ class PpoMarksT(C.Structure):
 
 class DiscLossT(C.Structure):
     _fields_ = [("disc", C.POINTER(MlpT)), ("rows", C.c_int32), ("disc_dim", C.c_int32), ("norm_diff", f32p), ("norm_diff16", f32p), ("norm_diff_amax", f32p), ("loss_scale", C.c_float),
-                ("logit_reg", C.c_float), ("grad_penalty", C.c_float), ("weight_decay", C.c_float), ("dlogit", f32p), ("a2", f32p), ("a1", f32p), ("g", f32p),
-                ("G", f32p), ("e1", f32p), ("da2", f32p), ("a2_16", f32p), ("a1_16", f32p), ("G16", f32p), ("e1_16", f32p), ("stats", f32p)]
+                ("logit_reg", C.c_float), ("grad_penalty", C.c_float), ("weight_decay", C.c_float), ("dlogit", f32p), ("a", f32p * _H), ("e", f32p * _H),
+                ("g", f32p), ("G", f32p), ("a16", f32p * _H), ("e16", f32p * _H), ("G16", f32p), ("stats", f32p)]
 
 
 class ActorHeadT(C.Structure):
@@ -158,7 +158,7 @@ DIST_FLOATS = 64                           # addhip_dist_refresh's vector (actor
 def actor_head_slab(hidden):
     """ADDHIP_ACTOR_HEAD_SLAB: floats of one workgroup's slab of addhip_actor_head."""
     return 32 * hidden + 64
-AMAX_SLOTS, MLP_AMAX_TENSORS = 64, 12  # tracked operand maxima of PREC_F16X2 (include/addhip.h)
+AMAX_SLOTS, MLP_AMAX_TENSORS = 64, 16  # tracked operand maxima of PREC_F16X2 (include/addhip.h)
 STORE_BF16, STORE_BF16X3 = 1, 3  # 16-bit storage formats of GEMM operands (include/addhip.h, "plane storage")
 GEMM_HINT_BIG_TILE, GEMM_HINT_NO_BIG_TILE, GEMM_HINT_ONE_STAGE, GEMM_HINT_TWO_STAGE, GEMM_HINT_REG_STAGED, GEMM_HINT_WIDE_TILE = 1, 2, 4, 8, 16, 32
 GEMM_MAX_GROUP = 4

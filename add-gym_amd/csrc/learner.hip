@@ -56,8 +56,7 @@ void set_prec(addhip_gemm_t& g, const addhip_mlp_t& n) {
 }
 
 // ADDHIP_PREC_F16X2: the net's tracked-maximum slots of tensor t (include/addhip.h: ADDHIP_MLP_AMAX_*), or NULL in every other mode
-constexpr int AMAX_H = ADDHIP_MLP_AMAX_H, AMAX_DZ = ADDHIP_MLP_AMAX_DZ, AMAX_A2 = ADDHIP_MLP_AMAX_A2, AMAX_A1 = ADDHIP_MLP_AMAX_A1, AMAX_G = ADDHIP_MLP_AMAX_G,
-              AMAX_E1 = ADDHIP_MLP_AMAX_E1;
+constexpr int AMAX_H = ADDHIP_MLP_AMAX_H, AMAX_DZ = ADDHIP_MLP_AMAX_DZ, AMAX_A = ADDHIP_MLP_AMAX_A, AMAX_G = ADDHIP_MLP_AMAX_G, AMAX_E = ADDHIP_MLP_AMAX_E;
 bool f16x2(const addhip_mlp_t& n) { return n.precision == ADDHIP_PREC_F16X2 && n.amax && n.w_amax; }
 uint32_t* amax_of(const addhip_mlp_t& n, int t) { return f16x2(n) ? n.amax + (size_t)t * ADDHIP_AMAX_SLOTS : nullptr; }
 void set_amax(addhip_gemm_t& g, const uint32_t* a, const uint32_t* b, uint32_t* out) {
@@ -392,31 +391,33 @@ static int disc_loss_impl(const addhip_disc_loss_t* d, addhip_disc_marks_t* mark
   const addhip_mlp_t& D = *d->disc;
   const int Mb = d->rows, Md = Mb + 1;
   if (int rc = check_net(&D, Md, "disc_loss_fwd_bwd")) return rc;
-  ADDHIP_REQUIRE(D.num_hidden == 2, "disc_loss_fwd_bwd: the gradient-penalty chain is written for 2-hidden-layer discriminators (fc_2layers_*)");
+  const int n = D.num_hidden, last = n - 1;
   ADDHIP_REQUIRE(D.head_rows == 1 && D.Wh && D.bh && D.gWh && D.gbh && D.slabs && D.slabs_top, "disc_loss_fwd_bwd: head parameters / both split-K scratches missing");
   const bool s16 = storage16(D);
-  ADDHIP_REQUIRE(d->norm_diff && d->dlogit && d->g && d->da2 && d->stats && d->disc_dim > 0 && d->disc_dim <= D.in_ld, "disc_loss_fwd_bwd: buffers missing");
-  ADDHIP_REQUIRE(s16 ? (d->norm_diff16 && d->a2_16 && d->a1_16 && d->G16 && d->e1_16 && D.W16t[0] && D.W16t[1]) : (d->a2 && d->a1 && d->G && d->e1),
-                 "disc_loss_fwd_bwd: the penalty chain's buffers for this storage mode are missing");
-  const int d1 = D.hidden[0], d2 = D.hidden[1], DS = D.in_ld;
+  ADDHIP_REQUIRE(d->norm_diff && d->dlogit && d->g && d->e[last] && d->stats && d->disc_dim > 0 && d->disc_dim <= D.in_ld, "disc_loss_fwd_bwd: buffers missing");
+  ADDHIP_REQUIRE(s16 ? (d->norm_diff16 && d->G16 != nullptr) : (d->G != nullptr), "disc_loss_fwd_bwd: the penalty chain's buffers for this storage mode are missing");
+  for (int i = 0; i < n; ++i)
+    ADDHIP_REQUIRE(s16 ? (d->a16[i] && (i == last || d->e16[i]) && D.W16t[i]) : (d->a[i] && d->e[i]), "disc_loss_fwd_bwd: the penalty chain's buffers of layer %d are missing", i);
+  const int DS = D.in_ld, dl = D.hidden[last];
   const float ls = d->loss_scale, wd = d->weight_decay;
   int launches = 0;
   // L2 terms (add_agent.py:161-164, 181-186): logit regularisation on the head weights, weight decay on every weight.  They go into the
   // freshly zeroed gradient FIRST (the weight gradients are added to them by the split-K combines), where they run beside the other
   // nets' GEMMs instead of alone at the end of the step's longest chain.
-  LAUNCH(addhip_l2_grad(D.W[0], D.gW[0], (int64_t)d1 * DS, 2.0f * ls * wd, d->stats + 24, stream));
-  LAUNCH(addhip_l2_grad(D.W[1], D.gW[1], (int64_t)d2 * d1, 2.0f * ls * wd, d->stats + 24, stream));
-  LAUNCH(addhip_l2_grad(D.Wh, D.gWh, (int64_t)d2, 2.0f * ls * (wd + d->logit_reg), d->stats + 25, stream));
+  for (int i = 0; i < n; ++i)
+    LAUNCH(addhip_l2_grad(D.W[i], D.gW[i], (int64_t)D.hidden[i] * (i == 0 ? DS : D.hidden[i - 1]), 2.0f * ls * wd, d->stats + 24, stream));
+  LAUNCH(addhip_l2_grad(D.Wh, D.gWh, (int64_t)dl, 2.0f * ls * (wd + d->logit_reg), d->stats + 25, stream));
   if (int rc = forward(D, d->norm_diff, d->norm_diff16, Md, nullptr, nullptr, true, launches, stream, d->norm_diff_amax)) return rc;
   if (int rc = refresh_transposed(D, launches, stream)) return rc;
   const int m_head = launches;
   // logit loss on Mb agent rows (negative) and the demo... rows of h[last]: row Mb = the zero-difference sample (positive)
-  LAUNCH(addhip_disc_head(D.h[1], d2, d2, Mb, D.h[1] + (size_t)Mb * d2, D.Wh, D.bh, ls, d->dlogit, d->dlogit + Mb, d->stats + 12, stream));
-  LAUNCH(addhip_head_backward(d->dlogit, D.Wh, D.h[1], d2, d2, Md, s16 ? nullptr : D.dz[1], s16 ? D.dz16[1] : nullptr, store_fmt(D), D.gWh, D.gbh, D.gb[1], amax_of(D, AMAX_DZ + 1), ordered_of(D), stream));
+  LAUNCH(addhip_disc_head(D.h[last], dl, dl, Mb, D.h[last] + (size_t)Mb * dl, D.Wh, D.bh, ls, d->dlogit, d->dlogit + Mb, d->stats + 12, stream));
+  LAUNCH(addhip_head_backward(d->dlogit, D.Wh, D.h[last], dl, dl, Md, s16 ? nullptr : D.dz[last], s16 ? D.dz16[last] : nullptr, store_fmt(D), D.gWh, D.gbh, D.gb[last],
+                              amax_of(D, AMAX_DZ + last), ordered_of(D), stream));
   const int m_chain = launches;
-  // gradient penalty (hand-derived double backward of add_agent.py:166-178):  g = ((w3 * m2) W2 * m1) W1 ;  penalty = mean |g|^2 ;
-  // second-order terms  G = d penalty / d g ;  e1 = (G W1^T) * m1 ;  da2 = (e1 W2^T) * m2
-  LAUNCH(addhip_bcast_mask(D.Wh, D.h[1], d2, d2, Mb, s16 ? nullptr : d->a2, s16 ? d->a2_16 : nullptr, store_fmt(D), amax_of(D, AMAX_A2), stream));
+  // gradient penalty (hand-derived double backward of add_agent.py:166-178; include/addhip.h has the chain):  a[last] = w_head * m[last],
+  // down to g = a[0] W[0];  G = d penalty / d g;  then e[0] = (G W[0]^T) * m[0] up to e[last]
+  LAUNCH(addhip_bcast_mask(D.Wh, D.h[last], dl, dl, Mb, s16 ? nullptr : d->a[last], s16 ? d->a16[last] : nullptr, store_fmt(D), amax_of(D, AMAX_A + last), stream));
   addhip_extra_dw_t extra[ADDHIP_MLP_MAX_HIDDEN];
   memset(extra, 0, sizeof(extra));
   auto chain = [&](addhip_gemm_t g, int mask_layer, int t_in = -1, int t_out = -1) -> int {  // t_in / t_out: tracked-maximum slots of A / the result
@@ -425,35 +426,46 @@ static int disc_loss_impl(const addhip_disc_loss_t* d, addhip_disc_marks_t* mark
     if (f16x2(D)) set_amax(g, t_in >= 0 ? amax_of(D, t_in) : nullptr, D.w_amax, t_out >= 0 ? amax_of(D, t_out) : nullptr);
     return addhip_gemm_f32(&g, stream);
   };
-  if (s16) {  // a2 and G are written as bf16 by their kernels, a1 / e1 leave their GEMMs as bf16, g and da2 as fp32
-    addhip_gemm_t g1 = gemm(Mb, d1, d2, d->a2_16, d2, 1, D.W16t[1], d2, 1, nullptr, d1, ADDHIP_EPI_MASK);
-    g1.C16 = d->a1_16; g1.ldc16 = d1;
-    LAUNCH(chain(g1, 0));
-    LAUNCH(chain(gemm(Mb, DS, d1, d->a1_16, d1, 1, D.W16t[0], d1, 1, d->g, DS), -1));
-    LAUNCH(addhip_grad_penalty(d->g, DS, d->disc_dim, Mb, ls * d->grad_penalty, nullptr, d->G16, store_fmt(D), d->stats + 20, nullptr, stream));
-    addhip_gemm_t g3 = gemm(Mb, d1, DS, d->G16, DS, 1, D.W16[0], DS, 1, nullptr, d1, ADDHIP_EPI_MASK);
-    g3.C16 = d->e1_16; g3.ldc16 = d1;
-    LAUNCH(chain(g3, 0));
-    LAUNCH(chain(gemm(Mb, d2, d1, d->e1_16, d1, 1, D.W16[1], d1, 1, d->da2, d2, ADDHIP_EPI_MASK), 1));
-    extra[0] = {d->a1_16, d1, d->G16, DS, Mb, nullptr, nullptr};
-    extra[1] = {d->a2_16, d2, d->e1_16, d1, Mb, nullptr, nullptr};
-  } else {
-    LAUNCH(chain(gemm(Mb, d1, d2, d->a2, d2, 1, D.W[1], d1, 0, d->a1, d1, ADDHIP_EPI_MASK), 0, AMAX_A2, AMAX_A1));
-    LAUNCH(chain(gemm(Mb, DS, d1, d->a1, d1, 1, D.W[0], DS, 0, d->g, DS), -1, AMAX_A1));
-    LAUNCH(addhip_grad_penalty(d->g, DS, d->disc_dim, Mb, ls * d->grad_penalty, d->G, nullptr, 0, d->stats + 20, amax_of(D, AMAX_G), stream));
-    LAUNCH(chain(gemm(Mb, d1, DS, d->G, DS, 1, D.W[0], DS, 1, d->e1, d1, ADDHIP_EPI_MASK), 0, AMAX_G, AMAX_E1));
-    LAUNCH(chain(gemm(Mb, d2, d1, d->e1, d1, 1, D.W[1], d1, 1, d->da2, d2, ADDHIP_EPI_MASK), 1, AMAX_E1));
-    extra[0] = {d->a1, d1, d->G, DS, Mb, amax_of(D, AMAX_A1), amax_of(D, AMAX_G)};
-    extra[1] = {d->a2, d2, d->e1, d1, Mb, amax_of(D, AMAX_A2), amax_of(D, AMAX_E1)};
+  // (storage modes: a[last] and G are written as 16-bit rows by their kernels, a[i] / e[i < last] leave their GEMMs as such, g and e[last] as fp32)
+  for (int i = last; i >= 1; --i) {  // a[i-1] = (a[i] W[i]) * m[i-1]
+    const int di = D.hidden[i], dp = D.hidden[i - 1];
+    if (s16) {
+      addhip_gemm_t gg = gemm(Mb, dp, di, d->a16[i], di, 1, D.W16t[i], di, 1, nullptr, dp, ADDHIP_EPI_MASK);
+      gg.C16 = d->a16[i - 1]; gg.ldc16 = dp;
+      LAUNCH(chain(gg, i - 1));
+    } else {
+      LAUNCH(chain(gemm(Mb, dp, di, d->a[i], di, 1, D.W[i], dp, 0, d->a[i - 1], dp, ADDHIP_EPI_MASK), i - 1, AMAX_A + i, AMAX_A + i - 1));
+    }
   }
-  LAUNCH(col_sum(D, d->da2, Mb, d2, d2, D.gWh, 1.0f, 1, stream));
+  const int d0 = D.hidden[0];
+  if (s16) {
+    LAUNCH(chain(gemm(Mb, DS, d0, d->a16[0], d0, 1, D.W16t[0], d0, 1, d->g, DS), -1));
+    LAUNCH(addhip_grad_penalty(d->g, DS, d->disc_dim, Mb, ls * d->grad_penalty, nullptr, d->G16, store_fmt(D), d->stats + 20, nullptr, stream));
+  } else {
+    LAUNCH(chain(gemm(Mb, DS, d0, d->a[0], d0, 1, D.W[0], DS, 0, d->g, DS), -1, AMAX_A + 0));
+    LAUNCH(addhip_grad_penalty(d->g, DS, d->disc_dim, Mb, ls * d->grad_penalty, d->G, nullptr, 0, d->stats + 20, amax_of(D, AMAX_G), stream));
+  }
+  for (int i = 0; i < n; ++i) {  // e[0] = (G W[0]^T) * m[0];  e[i] = (e[i-1] W[i]^T) * m[i]
+    const int di = D.hidden[i], kin = i == 0 ? DS : D.hidden[i - 1];
+    if (s16) {
+      addhip_gemm_t gg = gemm(Mb, di, kin, i == 0 ? d->G16 : d->e16[i - 1], kin, 1, D.W16[i], kin, 1, i == last ? d->e[i] : nullptr, di, ADDHIP_EPI_MASK);
+      if (i < last) { gg.C16 = d->e16[i]; gg.ldc16 = di; }
+      LAUNCH(chain(gg, i));
+      extra[i] = {d->a16[i], di, i == 0 ? d->G16 : d->e16[i - 1], kin, Mb, nullptr, nullptr};
+    } else {
+      LAUNCH(chain(gemm(Mb, di, kin, i == 0 ? d->G : d->e[i - 1], kin, 1, D.W[i], kin, 1, d->e[i], di, ADDHIP_EPI_MASK), i, i == 0 ? AMAX_G : AMAX_E + i - 1,
+                   i < last ? AMAX_E + i : -1));
+      extra[i] = {d->a[i], di, i == 0 ? d->G : d->e[i - 1], kin, Mb, amax_of(D, AMAX_A + i), amax_of(D, i == 0 ? AMAX_G : AMAX_E + i - 1)};
+    }
+  }
+  LAUNCH(col_sum(D, d->e[last], Mb, dl, dl, D.gWh, 1.0f, 1, stream));
   const int m_bwd = launches;
   addhip_mlp_marks_t mk;
   if (int rc = backward(D, d->norm_diff, d->norm_diff16, Md, extra,
                         ADDHIP_BWD_GRADS_ZEROED | ADDHIP_BWD_TOP_BIAS_DONE | ADDHIP_BWD_ACCUMULATE_DW | ADDHIP_BWD_TOP_CAST_DONE | ADDHIP_BWD_SIGN_BITS, &mk, launches,
                         stream, d->norm_diff_amax))
     return rc;
-  if (marks) *marks = addhip_disc_marks_t{launches, m_head, m_chain, m_bwd, m_bwd + mk.dw_first[1], m_bwd + mk.dw_last[1]};
+  if (marks) *marks = addhip_disc_marks_t{launches, m_head, m_chain, m_bwd, m_bwd + mk.dw_first[last], m_bwd + mk.dw_last[last]};
   return 0;
 }
 

@@ -280,13 +280,21 @@ class ADDAgent(AgentIO):
         hd = m.disc.hidden
         self._W = dict(mean=z(rows, 32), d_mean=z(rows, 32), noise=z(N, L.NUM_DOF), explore_u=z(N), u=z(3, N), logits=z(rows), nv=z(1),
                        norm_obs=z(Mb, OS), norm_act=z(Mb, 32), mb_logp=z(Mb), mb_adv=z(Mb), mb_tar=z(Mb), mb_mask=z(Mb), norm_diff=z(rows + 1, DS),
-                       dv=z(Mb), dlogit=z(Mb + 1), a2=z(Mb, hd[-1]), a1=z(Mb, hd[0]), g=z(Mb, DS), G=z(Mb, DS), e1=z(Mb, hd[0]), da2=z(Mb, hd[-1]),
+                       dv=z(Mb), dlogit=z(Mb + 1), g=z(Mb, DS), G=z(Mb, DS),
                        stats=z(32), scratch=z(4096, dt=torch.float64), adv_stats=z(2), rstats=z(2), perm_idx=z(Mb, dt=torch.int64),
                        mb_amax=z(2, L.AMAX_SLOTS, dt=torch.int32))  # f16x2: tracked maxima of the gathered norm_obs / norm_diff rows
+        for i, h in enumerate(hd):  # the gradient-penalty chain's rows of discriminator layer i (fp32; storage modes keep only e of the last layer)
+            if not s16:
+                self._W[f"gp_a{i}"] = z(Mb, h)
+            if not s16 or i == len(hd) - 1:
+                self._W[f"gp_e{i}"] = z(Mb, h)
         if s16:  # bf16 copies of the GEMM operands the fp32 kernels produce
             b16 = lambda r, c: torch.zeros(r, s16 * c, dtype=torch.bfloat16, device=dev)  # (plane storage: three bf16 per value)
-            self._W.update(norm_obs16=b16(Mb, OS), norm_diff16=b16(Mb + 1, DS), a2_16=b16(Mb, hd[-1]), a1_16=b16(Mb, hd[0]), G16=b16(Mb, DS),
-                           e1_16=b16(Mb, hd[0]))
+            self._W.update(norm_obs16=b16(Mb, OS), norm_diff16=b16(Mb + 1, DS), G16=b16(Mb, DS))
+            for i, h in enumerate(hd):  # the penalty chain's rows of layer i as 16-bit storage (e of the last layer stays fp32)
+                self._W[f"gp_a{i}_16"] = b16(Mb, h)
+                if i < len(hd) - 1:
+                    self._W[f"gp_e{i}_16"] = b16(Mb, h)
         if self._roll_storage:  # normalised, rounded input rows of the rollout / evaluation passes
             self._W.update(roll_x16=torch.zeros(N, OS, dtype=torch.bfloat16, device=dev), eval_x16=torch.zeros(self._eval_rows, OS, dtype=torch.bfloat16, device=dev),
                            eval_d16=torch.zeros(self._eval_rows, DS, dtype=torch.bfloat16, device=dev))
@@ -398,10 +406,16 @@ class ADDAgent(AgentIO):
                          L.ptr(W["mean"]), L.ptr(W["d_mean"]), L.ptr(W["dv"]), L.ptr(W["nv"]), L.ptr(W["stats"]))
         o = (lambda k: L.ptr(W[k])) if s16 else (lambda k: None)
         f = (lambda k: None) if s16 else (lambda k: L.ptr(W[k]))
-        disc = L.DiscLossT(C.pointer(self._mlp_c["disc"]), Mb, tk.disc_dim, L.ptr(W["norm_diff"]), o("norm_diff16"), L.ptr(W["mb_amax"][1]) if self._f16x2 else None,
-                           self._disc_loss_weight * gs,
-                           self._disc_logit_reg, self._disc_grad_penalty, self._disc_weight_decay, L.ptr(W["dlogit"]), f("a2"), f("a1"), L.ptr(W["g"]), f("G"),
-                           f("e1"), L.ptr(W["da2"]), o("a2_16"), o("a1_16"), o("G16"), o("e1_16"), L.ptr(W["stats"]))
+        disc = L.DiscLossT()
+        disc.disc, disc.rows, disc.disc_dim = C.pointer(self._mlp_c["disc"]), Mb, tk.disc_dim
+        disc.norm_diff, disc.norm_diff16, disc.norm_diff_amax = L.ptr(W["norm_diff"]), o("norm_diff16"), L.ptr(W["mb_amax"][1]) if self._f16x2 else None
+        disc.loss_scale, disc.logit_reg, disc.grad_penalty, disc.weight_decay = self._disc_loss_weight * gs, self._disc_logit_reg, self._disc_grad_penalty, self._disc_weight_decay
+        disc.dlogit, disc.g, disc.G, disc.G16, disc.stats = L.ptr(W["dlogit"]), L.ptr(W["g"]), f("G"), o("G16"), L.ptr(W["stats"])
+        nd = len(m.disc.hidden)
+        for i in range(nd):  # the gradient-penalty chain's workspace, per hidden layer (include/addhip.h: addhip_disc_loss_t)
+            disc.a[i], disc.a16[i] = f(f"gp_a{i}"), o(f"gp_a{i}_16")
+            disc.e[i] = L.ptr(W[f"gp_e{i}"]) if (not s16 or i == nd - 1) else None
+            disc.e16[i] = o(f"gp_e{i}_16") if i < nd - 1 else None
         return ppo, disc
 
     # ------------------------------------------------------------------ public surface

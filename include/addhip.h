@@ -659,8 +659,9 @@ typedef struct {
    * still accumulated by atomics: logged scalars may differ in their last bits, gradients and parameters do not. */
   int32_t deterministic; float* ordered_scratch;
 } addhip_mlp_t;
-enum { ADDHIP_MLP_AMAX_H = 0, ADDHIP_MLP_AMAX_DZ = 4, ADDHIP_MLP_AMAX_A2 = 8, ADDHIP_MLP_AMAX_A1 = 9, ADDHIP_MLP_AMAX_G = 10, ADDHIP_MLP_AMAX_E1 = 11,
-       ADDHIP_MLP_AMAX_TENSORS = 12 };
+enum { ADDHIP_MLP_AMAX_H = 0, ADDHIP_MLP_AMAX_DZ = 4,
+       ADDHIP_MLP_AMAX_A = 8 /* + layer: the penalty chain's a[i] */, ADDHIP_MLP_AMAX_G = 12, ADDHIP_MLP_AMAX_E = 13 /* + layer: e[i], i < last */,
+       ADDHIP_MLP_AMAX_TENSORS = 16 };
 
 /* h[last] = MLP(x) for `rows` rows (<= rows_cap): one GEMM per layer with fused bias + ReLU (+ fused (x - a_mean) / a_std on the first
  * layer's input when a_mean is given: Normalizer.normalize, normalizer.py:107-110; not with bf16 storage, whose input x16 is the
@@ -717,7 +718,10 @@ int addhip_ppo_loss_fwd_bwd(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* mark
 
 /* The discriminator's section: L2 terms (logit regularisation, weight decay) into the zeroed gradient, forward over Mb agent/demo
  * differences + one zero-difference row, logit loss + head backward, the gradient-penalty chain with its second-order terms
- * (hand-derived double backward of add_agent.py:166-178; 2-hidden-layer discriminators), backward. */
+ * (hand-derived double backward of add_agent.py:166-178, any number of hidden layers n <= ADDHIP_MLP_MAX_HIDDEN:
+ *   a[n-1] = w_head * m[n-1];  a[i-1] = (a[i] W[i]) * m[i-1];  g = a[0] W[0] = d logit / d input;  penalty = mean (|g| - 1)^2;
+ *   G = d penalty / d g;  e[0] = (G W[0]^T) * m[0];  e[i] = (e[i-1] W[i]^T) * m[i];  dW[0] += a[0]^T G, dW[i] += a[i]^T e[i-1], d w_head += sum_rows e[n-1]
+ * with m[i] the ReLU masks of the forward pass), backward. */
 typedef struct {
   const addhip_mlp_t* disc;
   int32_t rows;                                   /* Mb; the net runs Mb + 1 rows (rows_cap >= Mb + 1) */
@@ -727,8 +731,10 @@ typedef struct {
   float loss_scale;                               /* disc_loss_weight * grad_scale */
   float logit_reg, grad_penalty, weight_decay;
   float* dlogit;                                  /* workspace [Mb + 1] */
-  float* a2; float* a1; float* g; float* G; float* e1; float* da2;   /* workspace [Mb, hidden[1]] [Mb, hidden[0]] [Mb, in_ld] [Mb, in_ld] [Mb, hidden[0]] [Mb, hidden[1]] */
-  uint16_t* a2_16; uint16_t* a1_16; uint16_t* G16; uint16_t* e1_16;  /* bf16 storage: those four as bf16 instead (a2, a1, G, e1 may then be NULL) */
+  float* a[ADDHIP_MLP_MAX_HIDDEN]; float* e[ADDHIP_MLP_MAX_HIDDEN];  /* workspace, per hidden layer i: a[i], e[i] [Mb, hidden[i]] (e[last] always fp32) */
+  float* g; float* G;                                                   /* workspace [Mb, in_ld] each */
+  uint16_t* a16[ADDHIP_MLP_MAX_HIDDEN]; uint16_t* e16[ADDHIP_MLP_MAX_HIDDEN]; uint16_t* G16;   /* bf16 / plane storage: a[i], e[i < last], G as 16-bit rows
+                                                                           instead (their fp32 pointers may then be NULL) */
   float* stats;
 } addhip_disc_loss_t;
 typedef struct {

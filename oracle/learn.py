@@ -328,7 +328,7 @@ def compute_loss(model, cfg, batch):
     gp = torch.mean(torch.square(gnorm - 1))
     disc_loss = disc_loss + cfg.disc_grad_penalty * gp
     if cfg.disc_weight_decay != 0:
-        ws = [model.p["_model._disc_layers.0.weight"], model.p["_model._disc_layers.2.weight"], w_logit]
+        ws = [v for k, v in model.p.items() if k.startswith("_model._disc_layers.") and k.endswith(".weight")] + [w_logit]  # add_agent.py:181-186
         disc_loss = disc_loss + cfg.disc_weight_decay * sum(torch.sum(torch.square(w)) for w in ws)
     loss = actor_loss + cfg.critic_loss_weight * critic_loss + cfg.disc_loss_weight * disc_loss
     info.update(

@@ -37,7 +37,7 @@ int main(void) {
   addhip_disc_loss_t dl;
   memset(&dl, 0, sizeof(dl));
   dl.disc = &disc; dl.rows = Mb; dl.disc_dim = 114; dl.norm_diff = DEV(12); dl.loss_scale = 5.f; dl.logit_reg = 0.01f; dl.grad_penalty = 2.f; dl.weight_decay = 1e-4f;
-  dl.dlogit = DEV(13); dl.a2 = DEV(14); dl.a1 = DEV(15); dl.g = DEV(16); dl.G = DEV(17); dl.e1 = DEV(18); dl.da2 = DEV(19); dl.stats = DEV(11);
+  dl.dlogit = DEV(13); dl.a[1] = DEV(14); dl.a[0] = DEV(15); dl.g = DEV(16); dl.G = DEV(17); dl.e[0] = DEV(18); dl.e[1] = DEV(19); dl.stats = DEV(11);
 
   addhip_plan_t* plan = NULL;
   addhip_ppo_marks_t pm;

@@ -82,8 +82,8 @@ int main() {
   dl.disc = &D.c; dl.rows = Mb; dl.disc_dim = DISC;
   { float* nd = dev<float>((size_t)(Mb + 1) * DISC_LD, 1.f); (void)hipMemset(nd + (size_t)Mb * DISC_LD, 0, DISC_LD * 4); dl.norm_diff = nd; }  // row Mb: the zero difference
   dl.loss_scale = 5.f; dl.logit_reg = 0.01f; dl.grad_penalty = 2.f; dl.weight_decay = 1e-4f;
-  dl.dlogit = dev<float>(Mb + 1); dl.a2 = dev<float>((size_t)Mb * 128); dl.a1 = dev<float>((size_t)Mb * 256); dl.g = dev<float>((size_t)Mb * DISC_LD);
-  dl.G = dev<float>((size_t)Mb * DISC_LD); dl.e1 = dev<float>((size_t)Mb * 256); dl.da2 = dev<float>((size_t)Mb * 128); dl.stats = ppo.stats;
+  dl.dlogit = dev<float>(Mb + 1); dl.a[1] = dev<float>((size_t)Mb * 128); dl.a[0] = dev<float>((size_t)Mb * 256); dl.g = dev<float>((size_t)Mb * DISC_LD);
+  dl.G = dev<float>((size_t)Mb * DISC_LD); dl.e[0] = dev<float>((size_t)Mb * 256); dl.e[1] = dev<float>((size_t)Mb * 128); dl.stats = ppo.stats;
 
   hipStream_t st[4];
   for (auto& s : st) HIP(hipStreamCreate(&s));

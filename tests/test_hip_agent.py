@@ -90,6 +90,59 @@ def test_trainable_log_std_matches_reference(precision):
     minibatch_loss_gradients_and_adamw(precision, "losses_constant_std")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2", "bf16x3_planes"])
+def test_three_layer_discriminator_matches_reference(precision):
+    """agent.model.disc_net = fc_3layers_1024units: the gradient-penalty chain (the hand-derived double backward of add_agent.py:166-178) runs
+    through three hidden layers -- a[2] -> a[1] -> a[0] -> g, G, e[0] -> e[1] -> e[2], three extra weight-gradient products -- against the
+    reference's gradients and parameters (tools/gen_golden_agent.py: gen_losses_disc3).  bf16x3_planes: the same chain on plane storage."""
+    minibatch_loss_gradients_and_adamw(precision, "losses_disc3")
+
+
+def test_three_layer_discriminator_under_bf16_storage():
+    """The same three-layer chain on bf16 STORAGE (16-bit a[i] / e[i] rows, transposed weight shadows of all three layers): the
+    discriminator's gradients stay within bf16 rounding of the oracle's (relative L2 per tensor; this fixture's actor terms are not
+    looked at -- its 12-sigma actions amplify 8-bit operands to tens of percent), everything finite."""
+    import json
+    import torch
+    import add_gym_amd._lib as L
+
+    g = gload("losses_disc3")
+    nets = json.loads(str(g["nets"]))
+    M = g["in.obs"].shape[0]
+    cfg = make_cfg(M // 4, steps_per_iter=8, matmul_precision="bf16")
+    cfg["agent"]["model"].update(nets)
+    ag = make_agent(cfg, [gload("motion_small")["frames"]], [1.0])
+    params = OL.synth_params(int(g["seed"]), nets=nets)
+    ag._model.load({k: torch.tensor(v) for k, v in params.items()})
+    dn = OL.DiffNormalizer(114)
+    dn.mean_abs = g["disc_mean_abs"]
+    nd = dn.normalize(g["in.disc_obs_demo"] - g["in.disc_obs"])
+    W = ag._W
+    for k in ("norm_obs", "norm_act", "mb_adv", "mb_tar"):
+        W[k].zero_()
+    W["mb_logp"].fill_(ag._model.logp_const)
+    W["mb_mask"].fill_(1.0)
+    W["norm_diff"].zero_()
+    W["norm_diff"][:M, :114] = T(nd)
+    sync_minibatch16(ag)
+    m = ag._model
+    W["stats"].zero_()
+    m.grads.zero_()
+    ag._update_plan.run(L.current_stream())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(m.grads).all())
+    gh = {k: v.numpy() for k, v in m.export(m.grads).items()}
+    model = OL.Model(params)
+    mb = dict(norm_obs=np.zeros((M, 264), F), norm_action=np.zeros((M, 29), F), a_logp=np.full(M, ag._model.logp_const, F), adv=np.zeros(M, F), tar_val=np.zeros(M, F),
+              rand_action_mask=np.ones(M, F), norm_diff=nd)
+    loss, _ = OL.compute_loss(model, OL.LossCfg(), mb)
+    go = OL.AdamW(model, 1e-4).step(loss)
+    for k, v in go.items():
+        if "_disc_" in k:
+            rel = np.linalg.norm(gh[k] - v) / (np.linalg.norm(v) + 1e-12)
+            assert rel <= 8e-2, (k, float(rel))
+
+
 def minibatch_loss_gradients_and_adamw(precision="fp32", fixture="losses"):
     """(At this fixture's 256 rows every GEMM is below the size from which the bf16-MFMA kernels are dispatched, so the three
     modes run the same kernels here; the modes themselves are pinned at full size in tests/test_hip_fullsize.py.)"""

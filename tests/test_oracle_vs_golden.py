@@ -308,7 +308,7 @@ def golden_nets(g):
     return json.loads(str(g["nets"])) if "nets" in g.files else None
 
 
-@pytest.mark.parametrize("name", ["losses", "losses_small_nets", "losses_constant_std"])
+@pytest.mark.parametrize("name", ["losses", "losses_small_nets", "losses_constant_std", "losses_disc3"])
 def test_losses_grads_adamw(name):
     g = gload(name)
     model = L.Model(L.synth_params(int(g["seed"]), nets=golden_nets(g), logstd="logstd" in g.files))

@@ -317,6 +317,12 @@ def gen_losses_small_nets():
     gen_losses("losses_small_nets", SMALL_NETS)
 
 
+def gen_losses_disc3():
+    """A three-hidden-layer discriminator (fc_3layers_1024units: the only deeper module of the registry): the gradient penalty's double
+    backward runs through one more layer."""
+    gen_losses("losses_disc3", dict(disc_net="fc_3layers_1024units"))
+
+
 def gen_losses_constant_std():
     """actor_std_type CONSTANT (distribution_gaussian_diag.py:32-37): the log-std is a trainable vector, different per action dimension here."""
     gen_losses("losses_constant_std", None, logstd=True)
@@ -607,4 +613,4 @@ def gen_test_rollout():
 
 AGENT_GENS = dict(obs_reward_done_s4=lambda: gen_obs_reward_done_s2(4, "four"), reset_s4=lambda: gen_reset_s2(4),
                   loop_1iter_s4=lambda: gen_loop_1iter("loop_1iter_s4", task_over=dict(num_disc_obs_steps=4)), obs_reward_done_s2=gen_obs_reward_done_s2, reset_s2=gen_reset_s2, loop_1iter_s2=lambda: gen_loop_1iter("loop_1iter_s2", task_over=dict(num_disc_obs_steps=2)), loop_1iter_two=gen_loop_1iter_two, loop_1iter_time=gen_loop_1iter_time, logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
-                  td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, losses_small_nets=gen_losses_small_nets, losses_constant_std=gen_losses_constant_std, actor_step_constant_std=lambda: gen_actor_step("actor_step_constant_std", True), normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
+                  td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, losses_small_nets=gen_losses_small_nets, losses_disc3=gen_losses_disc3, losses_constant_std=gen_losses_constant_std, actor_step_constant_std=lambda: gen_actor_step("actor_step_constant_std", True), normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
