@@ -224,8 +224,6 @@ class ADDAgent(AgentIO):
         self._norm_adv_clip = float(c["norm_adv_clip"])
         self._action_bound_weight = float(c["action_bound_weight"])
         self._action_entropy_weight = float(c["action_entropy_weight"])  # ppo_agent.py:262-272
-        if self._action_entropy_weight != 0 and str(c["model"].get("actor_std_type", "FIXED")) != "FIXED":
-            raise NotImplementedError("agent.action_entropy_weight != 0 with a trainable log-std (the entropy's gradient) is not implemented")
         self._action_reg_weight = float(c["action_reg_weight"])
         self._critic_loss_weight = float(c["critic_loss_weight"])
         self._exp_anneal_samples = float(c.get("exp_anneal_samples", float("inf")))  # ppo_agent.py:32-34
@@ -673,6 +671,7 @@ class ADDAgent(AgentIO):
         self._gather(st)
         while steps < n_steps:
             self._run_update_sections(zero_grad=steps == 0)  # later steps find the gradient zeroed by the optimiser launch before them
+            self._post_exchange_grads(st)
             steps += 1
             gathered = None
             if steps < n_steps:
@@ -737,6 +736,13 @@ class ADDAgent(AgentIO):
         elif exchange:
             D.all_reduce_sum_(m.grads)
 
+    def _post_exchange_grads(self, stream):
+        """Loss terms whose gradient is identical on every rank, added once BEHIND the exchange: the entropy bonus of a trainable log-std
+        (ppo_agent.py:262-266 with distribution_gaussian_diag.py:96-99: d(-w * mean entropy) / d logstd_j = -w)."""
+        m = self._model
+        if m.dist is not None and self._action_entropy_weight != 0:
+            L.call("addhip_l2_grad", L.ptr(m.logstd_ones), m.g("actor", "logstd"), L.NUM_DOF, -self._action_entropy_weight, None, stream)
+
     def _need_normalizer_update(self):
         return self._sample_count < self._normalizer_samples
 
@@ -785,7 +791,8 @@ class ADDAgent(AgentIO):
         actor_loss = actor_min + self._action_bound_weight * bound
         extra = {}
         if self._action_entropy_weight != 0:  # fixed-std policy: the entropy is a constant (distribution_gaussian_diag.py:96-99)
-            ent = self._model.entropy
+            # (trainable log-std: the entropy of the policy as it stands after the iteration's last step, not the mean over its steps)
+            ent = self._model.entropy if self._model.dist is None else float(self._model.dist[33])
             actor_loss += -self._action_entropy_weight * ent
             extra["action_entropy"] = ent
         if self._action_reg_weight != 0:

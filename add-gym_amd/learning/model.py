@@ -89,6 +89,8 @@ class Model:
         self.params16 = None  # bf16 shadow of params (agent.matmul_precision = bf16), refreshed after every optimiser step
         self.w_amax = None    # tracked maximum |parameter| (agent.matmul_precision = f16x2: the scale of every weight operand), likewise
         self.dist = torch.zeros(L.DIST_FLOATS, device=device) if self.std_type == "CONSTANT" else None
+        self.logstd_ones = torch.zeros(32, device=device)  # (d entropy / d logstd: ones on the 29 action dimensions)
+        self.logstd_ones[:L.NUM_DOF] = 1.0
         self._init_params(seed)
         self.refresh_dist()
         # distribution_gaussian_diag.py:24-31, 63-94: fp32 logstd vector -> std and the log-prob constant

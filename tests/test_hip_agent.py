@@ -98,6 +98,14 @@ def test_three_layer_discriminator_matches_reference(precision):
     minibatch_loss_gradients_and_adamw(precision, "losses_disc3")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x2"])
+def test_entropy_bonus_reaches_the_trainable_log_std(precision):
+    """action_entropy_weight = 0.05 with actor_std_type CONSTANT (ppo_agent.py:262-266): the bonus's gradient, -w on every log-std, is
+    added behind the exchange (ADDAgent._post_exchange_grads); gradients, three AdamW steps and the logged entropy against the reference
+    (tools/gen_golden_agent.py: gen_losses_constant_std_entropy)."""
+    minibatch_loss_gradients_and_adamw(precision, "losses_constant_std_entropy")
+
+
 def test_three_layer_discriminator_under_bf16_storage():
     """The same three-layer chain on bf16 STORAGE (16-bit a[i] / e[i] rows, transposed weight shadows of all three layers): the
     discriminator's gradients stay within bf16 rounding of the oracle's (relative L2 per tensor; this fixture's actor terms are not
@@ -156,6 +164,8 @@ def minibatch_loss_gradients_and_adamw(precision="fp32", fixture="losses"):
     M = g["in.obs"].shape[0]
     cfg = make_cfg(M // 4, steps_per_iter=8, matmul_precision=precision)
     cfg["agent"]["model"].update(nets or {})
+    agent_over = json.loads(str(g["agent_over"])) if "agent_over" in g.files else {}
+    cfg["agent"].update(agent_over)
     logstd = "logstd" in g.files
     if logstd:
         cfg["agent"]["model"]["actor_std_type"] = "CONSTANT"
@@ -189,9 +199,10 @@ def minibatch_loss_gradients_and_adamw(precision="fp32", fixture="losses"):
         W["stats"].zero_()
         m.grads.zero_()  # zero_grad: _run_update_sections does it before the sections fork
         ag._update_plan.run(st)
+        ag._post_exchange_grads(st)  # (what _update_model adds behind the exchange: the entropy bonus of a trainable log-std)
         torch.cuda.synchronize()
         grads_hip = {k: v.numpy() for k, v in m.export(m.grads).items() if k != OL.LOGSTD_KEY or logstd}
-        loss, info = OL.compute_loss(model, OL.LossCfg(), mb)
+        loss, info = OL.compute_loss(model, OL.LossCfg(**agent_over), mb)
         grads_orc = opt.step(loss)
         if step == 0:
             # (1) against the oracle, tensor by tensor, full gradients
@@ -210,7 +221,7 @@ def minibatch_loss_gradients_and_adamw(precision="fp32", fixture="losses"):
             stats = ag._collect_info(1)
             # (this fixture masks 10 % of the samples out of the actor terms: the means run over the exploring samples)
             for k in ("critic_loss", "actor_loss", "disc_loss", "disc_grad_penalty", "disc_logit_loss", "disc_pos_acc", "disc_neg_acc", "disc_pos_logit",
-                      "disc_neg_logit", "clip_frac", "imp_ratio", "action_bound_loss"):
+                      "disc_neg_logit", "clip_frac", "imp_ratio", "action_bound_loss", "action_entropy"):
                 if "info." + k in g.files:
                     np.testing.assert_allclose(stats[k], float(g["info." + k]), rtol=2e-4, atol=2e-4, err_msg=k)
         m.opt_step += 1

@@ -308,7 +308,14 @@ def golden_nets(g):
     return json.loads(str(g["nets"])) if "nets" in g.files else None
 
 
-@pytest.mark.parametrize("name", ["losses", "losses_small_nets", "losses_constant_std", "losses_disc3"])
+def golden_loss_cfg(g):
+    """LossCfg with the agent options a losses fixture was generated with."""
+    import json
+
+    return L.LossCfg(**(json.loads(str(g["agent_over"])) if "agent_over" in g.files else {}))
+
+
+@pytest.mark.parametrize("name", ["losses", "losses_small_nets", "losses_constant_std", "losses_disc3", "losses_constant_std_entropy"])
 def test_losses_grads_adamw(name):
     g = gload(name)
     model = L.Model(L.synth_params(int(g["seed"]), nets=golden_nets(g), logstd="logstd" in g.files))
@@ -321,9 +328,11 @@ def test_losses_grads_adamw(name):
               norm_diff=dn.normalize(g["in.disc_obs_demo"] - g["in.disc_obs"]))
     opt = L.AdamW(model, 1e-4)
     for step in range(3):
-        loss, info = L.compute_loss(model, L.LossCfg(), mb)
+        loss, info = L.compute_loss(model, golden_loss_cfg(g), mb)
         grads = opt.step(loss)
         if step == 0:
+            if "info.action_entropy" in g.files:
+                np.testing.assert_allclose(info["action_entropy"], float(g["info.action_entropy"]), rtol=1e-6)
             for k in ("loss", "actor_loss", "critic_loss", "disc_loss", "clip_frac", "imp_ratio", "action_bound_loss",
                       "disc_grad_penalty", "disc_logit_loss", "disc_pos_acc", "disc_neg_acc", "disc_pos_logit", "disc_neg_logit"):
                 # |logp| ~ 2e3 in this fixture (12-sigma actions) -> fp32 ratio noise ~1e-4 absolute on the actor terms

@@ -328,10 +328,15 @@ def gen_losses_constant_std():
     gen_losses("losses_constant_std", None, logstd=True)
 
 
-def gen_losses(name="losses", nets=None, logstd=False):
+def gen_losses_constant_std_entropy():
+    """the same with the entropy bonus on (action_entropy_weight = 0.05, ppo_agent.py:262-266): its gradient reaches the log-std only."""
+    gen_losses("losses_constant_std_entropy", None, logstd=True, agent_over=dict(action_entropy_weight=0.05))
+
+
+def gen_losses(name="losses", nets=None, logstd=False, agent_over=None):
     n = 64
     M = 256
-    ag, cfg = build_agent(n, model_over=dict(nets or {}, **({"actor_std_type": "CONSTANT"} if logstd else {})))
+    ag, cfg = build_agent(n, model_over=dict(nets or {}, **({"actor_std_type": "CONSTANT"} if logstd else {})), **(agent_over or {}))
     load_synth(ag, 202, nets, logstd)
     rng = np.random.RandomState(17)
     # non-trivial normalisers
@@ -362,6 +367,8 @@ def gen_losses(name="losses", nets=None, logstd=False):
         out["nets"] = np.array(json.dumps(nets))
     if logstd:
         out["logstd"] = np.array(1)
+    if agent_over:
+        out["agent_over"] = np.array(json.dumps(agent_over))
     sd_params = dict(ag.named_parameters())
     for step in range(3):
         info = ag._compute_loss({k: v.clone() for k, v in inp.items()})
@@ -613,4 +620,4 @@ def gen_test_rollout():
 
 AGENT_GENS = dict(obs_reward_done_s4=lambda: gen_obs_reward_done_s2(4, "four"), reset_s4=lambda: gen_reset_s2(4),
                   loop_1iter_s4=lambda: gen_loop_1iter("loop_1iter_s4", task_over=dict(num_disc_obs_steps=4)), obs_reward_done_s2=gen_obs_reward_done_s2, reset_s2=gen_reset_s2, loop_1iter_s2=lambda: gen_loop_1iter("loop_1iter_s2", task_over=dict(num_disc_obs_steps=2)), loop_1iter_two=gen_loop_1iter_two, loop_1iter_time=gen_loop_1iter_time, logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
-                  td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, losses_small_nets=gen_losses_small_nets, losses_disc3=gen_losses_disc3, losses_constant_std=gen_losses_constant_std, actor_step_constant_std=lambda: gen_actor_step("actor_step_constant_std", True), normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
+                  td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, losses_small_nets=gen_losses_small_nets, losses_disc3=gen_losses_disc3, losses_constant_std_entropy=gen_losses_constant_std_entropy, losses_constant_std=gen_losses_constant_std, actor_step_constant_std=lambda: gen_actor_step("actor_step_constant_std", True), normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
