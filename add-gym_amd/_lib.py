@@ -187,7 +187,7 @@ SIGNATURES = {
     "addhip_col_sum": [vp, i32, i32, i32, vp, f32, i32, vp],
     "addhip_col_sum_ordered": [vp, i32, i32, i32, vp, f32, i32, vp, vp],
     "addhip_dist_refresh": [vp, vp, vp],
-    "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp],
+    "addhip_actor_sample": [vp, i32, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp, f32, vp, vp, vp, vp],
     "addhip_fill_normal": [vp, i64, u64, u64, vp],
     "addhip_fill_uniform": [vp, i64, u64, u64, vp],
     "addhip_fill_normal_at": [vp, i64, u64, u64, vp, vp],
@@ -202,7 +202,7 @@ SIGNATURES = {
     "addhip_norm_merge": [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
     "addhip_diffnorm_merge": [vp, vp, vp, i64, i32, vp],
     "addhip_gather_minibatch": [P(GatherT), vp],
-    "addhip_actor_loss": [vp, vp, vp, vp, vp, i32, f32, f32, vp, f32, f32, f32, f32, vp, vp, vp, vp, vp],
+    "addhip_actor_loss": [vp, vp, vp, vp, vp, i32, f32, f32, vp, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp, vp],
     "addhip_count_mask": [vp, i32, vp, vp],
     "addhip_actor_head_slabs": [i32],     # returns the slab count
     "addhip_actor_head": [P(ActorHeadT), vp],

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void dist_refresh_kernel(const float* logstd, f
 }
 
 __global__ __launch_bounds__(256) void actor_sample_kernel(const float* mean, int ldm, const float* noise, float stdv, float logp_const, const float* dist,
-                                                           const float* a_mean, const float* a_std, int n, int deterministic_all,
+                                                           const float* logstd_rows, const float* a_mean, const float* a_std, int n, int deterministic_all,
                                                            const float* explore_u, float exp_prob, float* action, float* a_logp, float* rand_mask) {
   const int lane = threadIdx.x & 63;
   if (dist) {  // trainable log-std: a standard deviation per action dimension
@@ -115,6 +115,11 @@ __global__ __launch_bounds__(256) void actor_sample_kernel(const float* mean, in
     // rand_action_mask = bernoulli(exp_prob) per env (ppo_agent.py:80-88): a uniform draw below the probability explores
     const bool deterministic = deterministic_all || (explore_u && !(explore_u[env] < exp_prob));
     float sq = 0.f, act = 0.f;
+    if (logstd_rows) {  // actor_std_type VARIABLE: this sample's own log-std row (distribution_gaussian_diag.py:52-53, 63-67, 90-94)
+      const float ls = lane < ADDHIP_NUM_DOF ? logstd_rows[(size_t)env * ldm + lane] : 0.f;
+      stdv = expf(ls);
+      logp_const = __fsub_rn((float)(-0.5 * ADDHIP_NUM_DOF * 1.8378770664093453), wave_sum(ls));
+    }
     if (lane < ADDHIP_NUM_DOF) {
       float mu = mean[(size_t)env * ldm + lane];
       float na = deterministic ? mu : __fadd_rn(mu, __fmul_rn(stdv, noise[(size_t)env * ADDHIP_NUM_DOF + lane]));
@@ -387,7 +392,8 @@ __global__ __launch_bounds__(256) void count_mask_kernel(const float* mask, int 
 
 __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, const float* na, const float* old_logp, const float* adv,
                                                          const float* mask, int M, float stdv, float logp_const, const float* dist, float clip, float bound_w,
-                                                         float reg_w, float loss_scale, const float* n_valid, float* d_mean, float* g_logstd, float* stats) {
+                                                         float reg_w, float loss_scale, const float* n_valid, float* d_mean, float* g_logstd, float* stats, int ldm,
+                                                         const float* logstd_rows) {
   __shared__ float sh[4];
   __shared__ float sh_ls[4][32];
   const int lane = threadIdx.x & 63;
@@ -401,8 +407,13 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, cons
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
     const bool valid = mask[r] == 1.0f;  // ppo_agent.py:229-233
     float mu = 0.f, d = 0.f, viol = 0.f;
+    if (logstd_rows) {  // actor_std_type VARIABLE: per-sample log-std (the columns behind the mean's)
+      const float ls = lane < ADDHIP_NUM_DOF ? logstd_rows[(size_t)r * ldm + lane] : 0.f;
+      stdv = expf(ls);
+      logp_const = (float)(-0.5 * ADDHIP_NUM_DOF * 1.8378770664093453) - wave_sum(ls);
+    }
     if (lane < ADDHIP_NUM_DOF) {
-      mu = mean[(size_t)r * 32 + lane];
+      mu = mean[(size_t)r * ldm + lane];
       d = (na[(size_t)r * 32 + lane] - mu) / stdv;
       viol = fminf(mu + 1.f, 0.f) + fmaxf(mu - 1.f, 0.f);  // base_agent.py:536-541 (one of the two is 0)
     }
@@ -421,8 +432,10 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, cons
     if (lane < 32) {
       float g = 0.f;
       if (valid && lane < ADDHIP_NUM_DOF) g = g_logp * (d / stdv) + (bound_w * 2.f * viol + reg_w * 2.f * mu) / nv;
-      d_mean[(size_t)r * 32 + lane] = loss_scale * g;
-      if (lane < ADDHIP_NUM_DOF) gls += loss_scale * g_logp * (d * d - 1.f);  // d logp / d logstd_j = d_j^2 - 1
+      d_mean[(size_t)r * ldm + lane] = loss_scale * g;
+      const float dls = lane < ADDHIP_NUM_DOF ? loss_scale * g_logp * (d * d - 1.f) : 0.f;  // d logp / d logstd_j = d_j^2 - 1
+      gls += dls;
+      if (logstd_rows) d_mean[(size_t)r * ldm + 32 + lane] = dls;  // (VARIABLE: the second head's output gradient, columns 32..63)
     }
     if (valid && lane == 0) {
       st_min += fminf(l0, l1);
@@ -827,13 +840,13 @@ extern "C" int addhip_dist_refresh(const float* logstd, float* dist, void* strea
   return addhip::check_launch("dist_refresh_kernel");
 }
 
-extern "C" int addhip_actor_sample(const float* mean, int32_t ld_mean, const float* noise, float stdv, float logp_const, const float* dist, const float* a_mean,
+extern "C" int addhip_actor_sample(const float* mean, int32_t ld_mean, const float* noise, float stdv, float logp_const, const float* dist, const float* logstd_rows, const float* a_mean,
                                    const float* a_std, int32_t num_envs, int32_t deterministic, const float* explore_u, float exp_prob, float* action,
                                    float* a_logp, float* rand_mask, void* stream) {
   ADDHIP_REQUIRE(mean && a_mean && a_std && action && a_logp && rand_mask && num_envs > 0, "actor_sample: bad arguments");
   ADDHIP_REQUIRE(deterministic || noise, "actor_sample: noise missing");
-  ADDHIP_RECORDABLE(addhip_actor_sample, mean, ld_mean, noise, stdv, logp_const, dist, a_mean, a_std, num_envs, deterministic, explore_u, exp_prob, action, a_logp, rand_mask);
-  hipLaunchKernelGGL(actor_sample_kernel, dim3(row_grid(num_envs)), dim3(256), 0, ST, mean, ld_mean, noise, stdv, logp_const, dist, a_mean, a_std,
+  ADDHIP_RECORDABLE(addhip_actor_sample, mean, ld_mean, noise, stdv, logp_const, dist, logstd_rows, a_mean, a_std, num_envs, deterministic, explore_u, exp_prob, action, a_logp, rand_mask);
+  hipLaunchKernelGGL(actor_sample_kernel, dim3(row_grid(num_envs)), dim3(256), 0, ST, mean, ld_mean, noise, stdv, logp_const, dist, logstd_rows, a_mean, a_std,
                      num_envs, deterministic, explore_u, exp_prob, action, a_logp, rand_mask);
   return addhip::check_launch("actor_sample_kernel");
 }
@@ -960,12 +973,14 @@ extern "C" int addhip_count_mask(const float* rand_mask, int32_t M, float* out, 
 
 extern "C" int addhip_actor_loss(const float* mean, const float* norm_action, const float* old_logp, const float* adv, const float* rand_mask, int32_t M,
                                  float stdv, float logp_const, const float* dist, float clip_ratio, float bound_weight, float reg_weight, float loss_scale,
-                                 const float* n_valid, float* d_mean, float* g_logstd, float* stats, void* stream) {
+                                 const float* n_valid, float* d_mean, float* g_logstd, float* stats, int32_t ld_mean, const float* logstd_rows, void* stream) {
   ADDHIP_REQUIRE(mean && norm_action && old_logp && adv && rand_mask && n_valid && d_mean && stats && M > 0, "actor_loss: bad arguments");
   ADDHIP_REQUIRE(!dist || g_logstd, "actor_loss: a trainable log-std (dist) needs g_logstd");
-  ADDHIP_RECORDABLE(addhip_actor_loss, mean, norm_action, old_logp, adv, rand_mask, M, stdv, logp_const, dist, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, g_logstd, stats);
+  ADDHIP_REQUIRE(ld_mean == 32 || (ld_mean == 64 && logstd_rows), "actor_loss: ld_mean is 32, or 64 with the per-sample log-std columns (logstd_rows)");
+  ADDHIP_RECORDABLE(addhip_actor_loss, mean, norm_action, old_logp, adv, rand_mask, M, stdv, logp_const, dist, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, g_logstd, stats,
+                    ld_mean, logstd_rows);
   hipLaunchKernelGGL(actor_loss_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, mean, norm_action, old_logp, adv, rand_mask, M,
-                     stdv, logp_const, dist, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, g_logstd, stats);
+                     stdv, logp_const, dist, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, g_logstd, stats, ld_mean, logstd_rows);
   return addhip::check_launch("actor_loss_kernel");
 }
 

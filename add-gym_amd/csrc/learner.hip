@@ -287,14 +287,18 @@ static int ppo_loss_impl(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, 
   const int Mb = d->rows;
   if (int rc = check_net(&A, Mb, "ppo_loss_fwd_bwd (actor)")) return rc;
   if (int rc = check_net(&Cn, Mb, "ppo_loss_fwd_bwd (critic)")) return rc;
-  ADDHIP_REQUIRE(A.head_rows == 32 && Cn.head_rows == 1, "ppo_loss_fwd_bwd: the actor's head is 32 rows (29 + padding), the critic's 1");
+  // HR: rows of the actor's head matrix -- 32 (29 action means + padding), or 64 when the log-std is a second head (actor_std_type VARIABLE:
+  // rows 32..60; the two heads are one 64-wide product in every launch below, the loss kernel reads the log-std columns behind the mean's)
+  const int HR = A.head_rows;
+  ADDHIP_REQUIRE((HR == 32 || HR == 64) && Cn.head_rows == 1, "ppo_loss_fwd_bwd: the actor's head is 32 rows (29 + padding) or 64 (mean | log-std), the critic's 1");
+  ADDHIP_REQUIRE(HR == 32 || !d->dist, "ppo_loss_fwd_bwd: a log-std head (64 head rows) and a log-std vector (dist) exclude each other");
   ADDHIP_REQUIRE(d->norm_obs && d->norm_action && d->old_logp && d->adv && d->tar_val && d->rand_mask, "ppo_loss_fwd_bwd: minibatch rows missing");
   ADDHIP_REQUIRE(d->mean && d->d_mean && d->dv && d->num_valid && d->stats, "ppo_loss_fwd_bwd: workspace missing");
   ADDHIP_REQUIRE(A.Wh && A.bh && A.gWh && A.gbh && Cn.Wh && Cn.bh && Cn.gWh && Cn.gbh && A.slabs && Cn.slabs, "ppo_loss_fwd_bwd: head parameters / scratch missing");
   const bool s16 = storage16(A);
   ADDHIP_REQUIRE(storage16(Cn) == s16 && (!s16 || d->norm_obs16), "ppo_loss_fwd_bwd: both nets in one storage mode (bf16 storage: norm_obs16 too)");
   const int nA = A.num_hidden, nC = Cn.num_hidden, hA = A.hidden[nA - 1], hC = Cn.hidden[nC - 1];
-  ADDHIP_REQUIRE(32LL * 32 * hA <= A.slab_floats, "ppo_loss_fwd_bwd: the actor's split-K scratch is smaller than its head gradient's 32 slabs");
+  ADDHIP_REQUIRE(32LL * HR * hA <= A.slab_floats, "ppo_loss_fwd_bwd: the actor's split-K scratch is smaller than its head gradient's 32 slabs");
   const int bwd = ADDHIP_BWD_GRADS_ZEROED | ADDHIP_BWD_TOP_BIAS_DONE | ADDHIP_BWD_TOP_CAST_DONE | ADDHIP_BWD_SIGN_BITS;
   // the actor's top bias gradient comes as column sums of the head's dz GEMM: replicated like the dX GEMMs' (same-line atomics serialise)
   const bool top_reps = A.bias_replicas && A.bias_replica_rows > 1 && ((int64_t)hA * (nA > 1 ? A.hidden[nA - 2] : A.in_ld)) % 4 == 0;
@@ -306,7 +310,7 @@ static int ppo_loss_impl(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, 
   // The head section: one launch (csrc/actor_head.hip: head forward, loss, gradient, backward step into the last hidden layer) where the
   // last hidden layer is 128 / 256 / 512 wide; the three 32-wide GEMMs + loss + column sums otherwise.
   const int head_slabs = addhip_actor_head_slabs(Mb);
-  const bool fused = (hA == 128 || hA == 256 || hA == 512) && (int64_t)head_slabs * ADDHIP_ACTOR_HEAD_SLAB(hA) <= A.slab_floats;
+  const bool fused = HR == 32 && (hA == 128 || hA == 256 || hA == 512) && (int64_t)head_slabs * ADDHIP_ACTOR_HEAD_SLAB(hA) <= A.slab_floats;
   ADDHIP_REQUIRE(!d->dist || d->g_logstd, "ppo_loss_fwd_bwd: a trainable log-std (dist) needs its gradient g_logstd");
   const bool planes = store_fmt(A) == ADDHIP_STORE_BF16X3;
   LAUNCH(addhip_count_mask(d->rand_mask, Mb, d->num_valid, stream));
@@ -335,23 +339,24 @@ static int ppo_loss_impl(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, 
     if (d->dist && !ls_follows) LAUNCH(addhip_slab_reduce(A.slabs + 32LL * hA + 32, head_slabs, stride, d->g_logstd, 32, 1.0f, 0, stream));
   } else {
     {
-      addhip_gemm_t g = gemm(Mb, 32, hA, A.h[nA - 1], hA, 1, A.Wh, hA, 1, d->mean, 32, ADDHIP_EPI_BIAS, A.bh);
+      addhip_gemm_t g = gemm(Mb, HR, hA, A.h[nA - 1], hA, 1, A.Wh, hA, 1, d->mean, HR, ADDHIP_EPI_BIAS, A.bh);
       g.precision = d->head_precision;
       LAUNCH(addhip_gemm_f32(&g, stream));
     }
     LAUNCH(addhip_actor_loss(d->mean, d->norm_action, d->old_logp, d->adv, d->rand_mask, Mb, d->action_std, d->logp_const, d->dist, d->ppo_clip_ratio,
-                             d->action_bound_weight, d->action_reg_weight, d->grad_scale, d->num_valid, d->d_mean, d->g_logstd, d->stats, stream));
+                             d->action_bound_weight, d->action_reg_weight, d->grad_scale, d->num_valid, d->d_mean, d->g_logstd, d->stats, HR,
+                             HR == 64 ? d->mean + 32 : nullptr, stream));
     {  // head weight gradient: d_mean^T h over Mb rows, 32 K slices
-      addhip_gemm_t g = gemm(32, hA, Mb, d->d_mean, 32, 0, A.h[nA - 1], hA, 0, A.slabs, hA);
+      addhip_gemm_t g = gemm(HR, hA, Mb, d->d_mean, HR, 0, A.h[nA - 1], hA, 0, A.slabs, hA);
       g.split_k = 32;
       g.precision = d->head_precision;
       LAUNCH(addhip_gemm_f32(&g, stream));
     }
-    LAUNCH(addhip_slab_reduce(A.slabs, 32, 32LL * hA, A.gWh, 32LL * hA, 1.0f, 0, stream));
-    LAUNCH(col_sum(A, d->d_mean, Mb, 32, 32, A.gbh, 1.0f, 1, stream));
+    LAUNCH(addhip_slab_reduce(A.slabs, 32, (int64_t)HR * hA, A.gWh, (int64_t)HR * hA, 1.0f, 0, stream));
+    LAUNCH(col_sum(A, d->d_mean, Mb, HR, HR, A.gbh, 1.0f, 1, stream));
     {  // dz[last] = (d_mean Wh) * relu'(h[last]); bf16 storage: written as bf16 directly
       // (plane storage: an fp32-operand GEMM cannot write planes -- it leaves the fp32 dz and the backward pass splits it first)
-      addhip_gemm_t g = gemm(Mb, hA, 32, d->d_mean, 32, 1, A.Wh, hA, 0, s16 && !planes ? nullptr : A.dz[nA - 1], hA, ADDHIP_EPI_MASK);
+      addhip_gemm_t g = gemm(Mb, hA, HR, d->d_mean, HR, 1, A.Wh, hA, 0, s16 && !planes ? nullptr : A.dz[nA - 1], hA, ADDHIP_EPI_MASK);
       g.colsum = A.gb[nA - 1];
       if (top_reps) {  // spread over the replica rows like the dX GEMMs' sums; the top layer's combine folds them into gb[last]
         g.colsum = A.bias_replicas;

@@ -224,6 +224,8 @@ class ADDAgent(AgentIO):
         self._norm_adv_clip = float(c["norm_adv_clip"])
         self._action_bound_weight = float(c["action_bound_weight"])
         self._action_entropy_weight = float(c["action_entropy_weight"])  # ppo_agent.py:262-272
+        if self._action_entropy_weight != 0 and str(c["model"].get("actor_std_type", "FIXED")) == "VARIABLE":
+            raise NotImplementedError("agent.action_entropy_weight != 0 with actor_std_type VARIABLE (the entropy's gradient through the log-std head) is not implemented")
         self._action_reg_weight = float(c["action_reg_weight"])
         self._critic_loss_weight = float(c["critic_loss_weight"])
         self._exp_anneal_samples = float(c.get("exp_anneal_samples", float("inf")))  # ppo_agent.py:32-34
@@ -248,7 +250,7 @@ class ADDAgent(AgentIO):
         from .model import split_k_for
 
         # actor-head weight-gradient slabs: 32 K slices of the 32-wide GEMM, or one per workgroup of addhip_actor_head (<= 256)
-        need = max(32 * 32 * m.actor.hidden[-1], 256 * L.actor_head_slab(m.actor.hidden[-1]))
+        need = max(32 * m.actor.head_rows * m.actor.hidden[-1], 256 * L.actor_head_slab(m.actor.hidden[-1]))
         for net in m.nets:
             for i, h in enumerate(net.hidden):
                 in_ld = net.in_ld if i == 0 else net.hidden[i - 1]
@@ -276,7 +278,8 @@ class ADDAgent(AgentIO):
         self._side_streams = _side_streams(dev)
         OS, DS = self._task.obs_stride, self._task.disc_stride
         hd = m.disc.hidden
-        self._W = dict(mean=z(rows, 32), d_mean=z(rows, 32), noise=z(N, L.NUM_DOF), explore_u=z(N), u=z(3, N), logits=z(rows), nv=z(1),
+        HR = m.actor.head_rows  # 32, or 64 with a log-std head (actor_std_type VARIABLE: mean | log-std columns)
+        self._W = dict(mean=z(rows, HR), d_mean=z(rows, HR), noise=z(N, L.NUM_DOF), explore_u=z(N), u=z(3, N), logits=z(rows), nv=z(1),
                        norm_obs=z(Mb, OS), norm_act=z(Mb, 32), mb_logp=z(Mb), mb_adv=z(Mb), mb_tar=z(Mb), mb_mask=z(Mb), norm_diff=z(rows + 1, DS),
                        dv=z(Mb), dlogit=z(Mb + 1), g=z(Mb, DS), G=z(Mb, DS),
                        stats=z(32), scratch=z(4096, dt=torch.float64), adv_stats=z(2), rstats=z(2), perm_idx=z(Mb, dt=torch.int64),
@@ -320,7 +323,8 @@ class ADDAgent(AgentIO):
                 rr.forward(p, None, N, x16_ptr=L.ptr(W["roll_x16"]))
             else:
                 rr.forward(p, L.ptr(B["obs"][t]), N, a_mean=L.ptr(Nm["obs_mean"]), a_std=L.ptr(Nm["obs_std"]))
-            self._gemm(p, N, 32, hA, L.ptr(rr.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), 32, L.EPI_BIAS, m.p("actor", "bh"))
+            HR = m.actor.head_rows
+            self._gemm(p, N, HR, hA, L.ptr(rr.h[-1]), hA, 1, m.p("actor", "Wh"), hA, 1, L.ptr(W["mean"]), HR, L.EPI_BIAS, m.p("actor", "bh"))
             self._act_plans.append(p)
         for t in range(T):
             self._step_out.append(L.StepOutT(L.ptr(B["obs"][t + 1]), None, L.ptr(B["obs_timeout"]), L.ptr(B["disc_obs"][t]), L.ptr(B["disc_demo"][t]),
@@ -508,7 +512,9 @@ class ADDAgent(AgentIO):
                 else:
                     L.call("addhip_fill_uniform", L.ptr(W["explore_u"]), self.N, self._seed, (3 << 40) + self._iter * self.T + t, st)
                 explore_u = L.ptr(W["explore_u"])
-        L.call("addhip_actor_sample", L.ptr(W["mean"]), 32, L.ptr(W["noise"]), m.std32, m.logp_const, m.dist_ptr(), L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), self.N,
+        HR = m.actor.head_rows
+        L.call("addhip_actor_sample", L.ptr(W["mean"]), HR, L.ptr(W["noise"]), m.std32, m.logp_const, m.dist_ptr(),
+               L.ptr(W["mean"]) + 4 * 32 if HR == 64 else None, L.ptr(Nm["a_mean"]), L.ptr(Nm["a_std"]), self.N,
                int(deterministic), explore_u, exp_prob, L.ptr(B["action"][slot_t]), L.ptr(B["a_logp"][slot_t]), L.ptr(B["rand_mask"][slot_t]), st)
 
     def _get_exp_prob(self):

@@ -31,9 +31,10 @@ def build_net_sizes(name):
 class Mlp:
     """One network: hidden Linear+ReLU stack and a linear head, as views into the flat buffers."""
 
-    def __init__(self, name, in_dim, in_ld, hidden, head_dim):
+    def __init__(self, name, in_dim, in_ld, hidden, head_dim, heads=1):
         self.name, self.in_dim, self.in_ld, self.hidden, self.head_dim = name, in_dim, in_ld, list(hidden), head_dim
-        self.head_rows = 32 if head_dim > 1 else 1  # 29-wide head padded to 32 rows; 1-wide head = vector
+        # 29-wide head padded to 32 rows; 1-wide head = vector; heads = 2 (actor_std_type VARIABLE): the log-std head's 32 rows behind the mean head's
+        self.head_rows = 32 * heads if head_dim > 1 else 1
         self.specs = []  # (key, shape)
         prev = in_ld
         for i, h in enumerate(hidden):
@@ -45,7 +46,8 @@ class Mlp:
 class Model:
     def __init__(self, model_cfg, obs_dim, obs_ld, disc_dim, disc_ld, device, seed=0):
         self.device = device
-        self.actor = Mlp("actor", obs_dim, obs_ld, build_net_sizes(model_cfg["actor_net"]), L.NUM_DOF)
+        self.std_type = str(model_cfg.get("actor_std_type", "FIXED"))
+        self.actor = Mlp("actor", obs_dim, obs_ld, build_net_sizes(model_cfg["actor_net"]), L.NUM_DOF, heads=2 if self.std_type == "VARIABLE" else 1)
         self.critic = Mlp("critic", obs_dim, obs_ld, build_net_sizes(model_cfg["critic_net"]), 1)
         self.disc = Mlp("disc", disc_dim, disc_ld, build_net_sizes(model_cfg["disc_net"]), 1)
         self.nets = [self.actor, self.critic, self.disc]
@@ -53,9 +55,11 @@ class Model:
         # distribution_gaussian_diag.py:19-45.  FIXED: the log-std is a constant (a scalar argument of the kernels).  CONSTANT: one trainable
         # log-std per action dimension -- 32 floats behind the actor head's bias in the flat buffers (gradient, AdamW state, the actor's
         # exchange bucket all follow from that), from which addhip_dist_refresh derives the kernels' `dist` vector after every change.
-        self.std_type = str(model_cfg.get("actor_std_type", "FIXED"))
-        if self.std_type not in ("FIXED", "CONSTANT"):
-            raise NotImplementedError("actor_std_type VARIABLE (a second head on the actor) is not implemented: FIXED or CONSTANT")
+        # VARIABLE: the log-std is a second linear head on the actor's last layer -- rows 32..60 of a 64-row head matrix (bias likewise), so that the
+        # two heads are ONE 64-wide product everywhere (rollout head GEMM, weight gradient, dz); the kernels read the per-sample log-std columns
+        # behind the mean's (addhip_actor_sample / addhip_actor_loss: logstd_rows)
+        if self.std_type not in ("FIXED", "CONSTANT", "VARIABLE"):
+            raise ValueError("actor_std_type must be FIXED, CONSTANT or VARIABLE")
         if self.std_type == "CONSTANT":
             self.actor.specs.append(("logstd", (32,)))
         self.init_output_scale = float(model_cfg["actor_init_output_scale"])
@@ -199,6 +203,9 @@ class Model:
             wh = self.view(net.name, "Wh")
             wh.zero_()
             wh[:net.head_dim] = uniform((net.head_dim, fan_in), bound).to(self.device)
+            if net.head_rows == 64:  # distribution_gaussian_diag.py:38-43: the log-std head, same scale, bias log(action_std)
+                wh[32:32 + net.head_dim] = uniform((net.head_dim, fan_in), bound).to(self.device)
+                self.view(net.name, "bh")[32:32 + net.head_dim] = float(math.log(self.action_std))
         if self.std_type == "CONSTANT":  # distribution_gaussian_diag.py:25, 32-37
             ls = self.view("actor", "logstd")
             ls.zero_()
@@ -217,9 +224,22 @@ class Model:
                 m.append(("_model._action_dist._logstd_net", net, "logstd"))
             m.append((f"{head}.weight", net, "Wh"))
             m.append((f"{head}.bias", net, "bh"))
+            if net is self.actor and self.std_type == "VARIABLE":  # (a sub-module created after the mean head: registered behind it)
+                m.append(("_model._action_dist._logstd_net.weight", net, "Wh@32"))
+                m.append(("_model._action_dist._logstd_net.bias", net, "bh@32"))
         return m
 
+    def _block(self, net, key, buf=None):
+        """The rows of a flat tensor a reference key maps to: `key@r` = rows r.. of `key` (the second head of a two-head matrix), and the first
+        head's block of such a matrix ends where the second begins."""
+        base, _, r0 = key.partition("@")
+        v = self.view(net.name, base, buf)
+        if r0:
+            return v[int(r0):]
+        return v[:32] if (net.head_rows == 64 and base in ("Wh", "bh")) else v
+
     def _ref_shape(self, net, key):
+        key = key.partition("@")[0]
         if key.startswith("W") and key != "Wh":
             i = int(key[1:])
             return (net.hidden[i], net.in_dim if i == 0 else net.hidden[i - 1])
@@ -233,7 +253,7 @@ class Model:
         """{reference key: cpu tensor of the reference shape} from params (or another flat buffer)."""
         out = {}
         for name, net, key in self._key_map():
-            v = self.view(net.name, key, buf)
+            v = self._block(net, key, buf)
             shape = self._ref_shape(net, key)
             if v.dim() == 2:
                 v = v[:shape[0], :shape[1]]
@@ -249,7 +269,7 @@ class Model:
             if name not in state:
                 raise KeyError(f"checkpoint is missing {name}")
             src = state[name].to(torch.float32)
-            v = self.view(net.name, key, buf)
+            v = self._block(net, key, buf)
             v.zero_()
             if v.dim() == 2:
                 v[:src.shape[0], :src.shape[1]] = src.to(self.device)

@@ -374,7 +374,9 @@ int addhip_col_sum_ordered(const float* X, int32_t M, int32_t N, int32_t ld, flo
 #define ADDHIP_DIST_FLOATS 64
 int addhip_dist_refresh(const float* logstd /*[29]*/, float* dist /*[ADDHIP_DIST_FLOATS]*/, void* stream);
 int addhip_actor_sample(const float* mean, int32_t ld_mean, const float* noise /*[N,29] N(0,1)*/, float std,
-                        float logp_const /* fl32(-0.5*29*log(2pi)) - sum(logstd) */, const float* dist /* or NULL */, const float* a_mean, const float* a_std, int32_t num_envs,
+                        float logp_const /* fl32(-0.5*29*log(2pi)) - sum(logstd) */, const float* dist /* or NULL */,
+                        const float* logstd_rows /* or NULL; actor_std_type VARIABLE: [N, ld_mean] per-sample log-std (the second head's columns) */,
+                        const float* a_mean, const float* a_std, int32_t num_envs,
                         int32_t deterministic, const float* explore_u, float exp_prob, float* action /*[N,32]*/, float* a_logp,
                         float* rand_mask, void* stream);
 
@@ -455,7 +457,10 @@ int addhip_gather_minibatch(const addhip_gather_t* g, void* stream);
 int addhip_actor_loss(const float* mean, const float* norm_action, const float* old_logp, const float* adv,
                       const float* rand_mask, int32_t M, float std, float logp_const, const float* dist /* or NULL */, float clip_ratio,
                       float bound_weight, float reg_weight, float loss_scale, const float* n_valid /*device [1]*/, float* d_mean,
-                      float* g_logstd /* [29], with dist */, float* stats, void* stream);
+                      float* g_logstd /* [29], with dist */, float* stats,
+                      int32_t ld_mean /* row stride of mean and d_mean: 32, or 64 with logstd_rows */,
+                      const float* logstd_rows /* or NULL; VARIABLE: per-sample log-std [M, ld_mean] (usually mean + 32); d loss / d logstd then goes
+                                                  to columns 32..63 of d_mean: the two heads are one 64-wide product */, void* stream);
 /* The actor's head section as ONE launch: mean = H Wh^T + bh (DistributionGaussianDiagBuilder.forward, distribution_gaussian_diag.py:47-58),
  * addhip_actor_loss on it (same arguments, same stats slots), and the backward step through the head into the last hidden layer:
  *   dz = (d_mean Wh) * (H > 0)   -> dz [rows, hidden] fp32 and / or dz16 (ADDHIP_STORE_* format planes16),
@@ -705,7 +710,7 @@ typedef struct {
   float action_std, logp_const, ppo_clip_ratio, action_bound_weight, action_reg_weight, critic_loss_weight, grad_scale;
   const float* dist; float* g_logstd;             /* actor_std_type CONSTANT: addhip_dist_refresh's vector and the log-std's gradient [32] (NULL: FIXED) */
   int32_t head_precision;                         /* ADDHIP_PREC_* of the three 32-wide head GEMMs (fp32 operands in every mode) */
-  float* mean; float* d_mean;                     /* workspace [Mb, 32] each */
+  float* mean; float* d_mean;                     /* workspace [Mb, actor->head_rows] each (32; 64 with a log-std head: mean | log-std) */
   float* dv;                                      /* workspace [Mb] */
   float* num_valid;                               /* workspace [1] */
   float* stats;                                   /* [32] loss diagnostics, accumulated over the steps of an iteration (slots: learn.hip) */

@@ -48,7 +48,8 @@ def param_shapes(nets=None, obs_dim=264, disc_dim=114):
     return out
 
 
-LOGSTD_KEY = "_model._action_dist._logstd_net"
+LOGSTD_KEY = "_model._action_dist._logstd_net"                     # actor_std_type CONSTANT: a trainable vector
+LOGSTD_W, LOGSTD_B = LOGSTD_KEY + ".weight", LOGSTD_KEY + ".bias"    # actor_std_type VARIABLE: a second linear head on the actor's last layer
 
 
 def synth_params(seed, obs_dim=264, disc_dim=114, bias_scale=0.02, nets=None, logstd=False):
@@ -69,13 +70,21 @@ def synth_params(seed, obs_dim=264, disc_dim=114, bias_scale=0.02, nets=None, lo
             out[name] = rng.uniform(-bound, bound, size=shape).astype(F)
         else:
             out[name] = (rng.uniform(-1, 1, size=shape) * bias_scale).astype(F)
-    if logstd:  # a trainable log-std (actor_std_type CONSTANT), different per action dimension, at its place in the registration order
-        ls = (np.log(0.05) + np.random.RandomState(seed + 7919).uniform(-0.4, 0.4, size=29)).astype(F)
+    if logstd:  # a trainable log-std, different per action dimension, at its place in the registration order (before the mean head):
+        # True / "constant": a vector (actor_std_type CONSTANT); "variable": a linear head on the last hidden layer (VARIABLE:
+        # distribution_gaussian_diag.py:38-43 -- weights large enough here for the per-sample part to matter)
+        r2 = np.random.RandomState(seed + 7919)
+        ls = (np.log(0.05) + r2.uniform(-0.4, 0.4, size=29)).astype(F)
         ordered = {}
         for k, v in out.items():
-            if k == "_model._action_dist._mean_net.weight":
+            # (registration order: a Parameter of the distribution module precedes its sub-modules' -- CONSTANT's vector comes before the
+            # mean head, VARIABLE's linear head, a sub-module created after the mean head, behind it)
+            if k == "_model._action_dist._mean_net.weight" and logstd != "variable":
                 ordered[LOGSTD_KEY] = ls
             ordered[k] = v
+            if k == "_model._action_dist._mean_net.bias" and logstd == "variable":
+                ordered[LOGSTD_W] = r2.uniform(-0.02, 0.02, size=out["_model._action_dist._mean_net.weight"].shape).astype(F)
+                ordered[LOGSTD_B] = ls
         out = ordered
     return out
 
@@ -201,6 +210,16 @@ class Model:
     def std(self):
         return torch.exp(self.p[LOGSTD_KEY]) if LOGSTD_KEY in self.p else self._std_fixed
 
+    def dist(self, x):
+        """(mean, logstd, std) of the action distribution for normalised observations x (DistributionGaussianDiagBuilder.forward,
+        distribution_gaussian_diag.py:47-58): logstd / std are per row for the VARIABLE type, vectors otherwise."""
+        h = self._mlp(x, "_model._actor_layers")
+        mean = torch.nn.functional.linear(h, self.p["_model._action_dist._mean_net.weight"], self.p["_model._action_dist._mean_net.bias"])
+        if LOGSTD_W in self.p:
+            ls = torch.nn.functional.linear(h, self.p[LOGSTD_W], self.p[LOGSTD_B])
+            return mean, ls, torch.exp(ls)
+        return mean, self.logstd, self.std
+
     def names(self):
         return list(self.p)  # (registration order: the order of PARAM_SHAPES / param_shapes())
 
@@ -222,11 +241,12 @@ class Model:
         h = self._mlp(x, "_model._disc_layers", (0, 2))
         return torch.nn.functional.linear(h, self.p["_model._disc_logits.weight"], self.p["_model._disc_logits.bias"]).squeeze(-1)
 
-    def log_prob(self, mean, a):
+    def log_prob(self, mean, a, logstd=None, std=None):
         # distribution_gaussian_diag.py:90-94
         d = mean.shape[-1]
-        logp = -0.5 * torch.sum(torch.square((a - mean) / self.std), dim=-1)
-        logp = logp + (-0.5 * d * np.log(2.0 * np.pi) - torch.sum(torch.broadcast_to(self.logstd, mean.shape), dim=-1))
+        logstd, std = (self.logstd, self.std) if logstd is None else (logstd, std)
+        logp = -0.5 * torch.sum(torch.square((a - mean) / std), dim=-1)
+        logp = logp + (-0.5 * d * np.log(2.0 * np.pi) - torch.sum(torch.broadcast_to(logstd, mean.shape), dim=-1))
         return logp
 
 
@@ -253,11 +273,11 @@ def t32(x):
 def actor_step(model, obs_norm, a_norm, obs, noise, rand_mask=None):
     """ppo_agent.py:72-104 (TRAIN mode) given the N(0,1) draw: returns action, logp, norm_a."""
     with torch.no_grad():
-        mean = model.actor_mean(t32(obs_norm.normalize(obs)))
-        norm_a = mean + model.std * t32(noise)
+        mean, ls, std = model.dist(t32(obs_norm.normalize(obs)))
+        norm_a = mean + std * t32(noise)
         if rand_mask is not None:
             norm_a = torch.where(t32(rand_mask)[:, None] == 1.0, norm_a, mean)
-        logp = model.log_prob(mean, norm_a)
+        logp = model.log_prob(mean, norm_a, ls, std)
     a = a_norm.unnormalize(norm_a.numpy())
     return a, logp.numpy(), norm_a.numpy()
 
@@ -289,8 +309,8 @@ def compute_loss(model, cfg, batch):
     critic_loss = torch.mean(torch.square(t32(batch["tar_val"]) - pred))
     # actor (ppo_agent.py:221-275); only samples with random actions
     m = t32(batch["rand_action_mask"]) == 1.0
-    mean = model.actor_mean(norm_obs[m])
-    logp = model.log_prob(mean, t32(batch["norm_action"])[m])
+    mean, ls, std = model.dist(norm_obs[m])
+    logp = model.log_prob(mean, t32(batch["norm_action"])[m], ls, std)
     ratio = torch.exp(logp - t32(batch["a_logp"])[m])
     adv = t32(batch["adv"])[m]
     l0 = adv * ratio
@@ -305,7 +325,7 @@ def compute_loss(model, cfg, batch):
     actor_loss = actor_loss + cfg.action_bound_weight * bound
     info["action_bound_loss"] = bound.item()
     if cfg.action_entropy_weight != 0:  # ppo_agent.py:262-266, distribution_gaussian_diag.py:96-99
-        ent = torch.sum(torch.broadcast_to(model.logstd, mean.shape), dim=-1) + 0.5 * mean.shape[-1] * np.log(2.0 * np.pi * np.e)
+        ent = torch.sum(torch.broadcast_to(ls, mean.shape), dim=-1) + 0.5 * mean.shape[-1] * np.log(2.0 * np.pi * np.e)
         actor_loss = actor_loss - cfg.action_entropy_weight * torch.mean(ent)
         info["action_entropy"] = torch.mean(ent).item()
     if cfg.action_reg_weight != 0:      # ppo_agent.py:268-272, distribution_gaussian_diag.py:113-116

@@ -106,6 +106,14 @@ def test_entropy_bonus_reaches_the_trainable_log_std(precision):
     minibatch_loss_gradients_and_adamw(precision, "losses_constant_std_entropy")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])
+def test_log_std_head_matches_reference(precision):
+    """agent.model.actor_std_type VARIABLE (distribution_gaussian_diag.py:38-43, 52-53): the log-std is a second linear head on the actor's
+    last layer -- rows 32..60 of a 64-row head matrix here, so that the two heads are one 64-wide product in the head GEMM, its weight
+    gradient and dz -- gradients of both heads, three AdamW steps, against the reference (tools/gen_golden_agent.py: gen_losses_variable_std)."""
+    minibatch_loss_gradients_and_adamw(precision, "losses_variable_std")
+
+
 def test_three_layer_discriminator_under_bf16_storage():
     """The same three-layer chain on bf16 STORAGE (16-bit a[i] / e[i] rows, transposed weight shadows of all three layers): the
     discriminator's gradients stay within bf16 rounding of the oracle's (relative L2 per tensor; this fixture's actor terms are not
@@ -166,9 +174,11 @@ def minibatch_loss_gradients_and_adamw(precision="fp32", fixture="losses"):
     cfg["agent"]["model"].update(nets or {})
     agent_over = json.loads(str(g["agent_over"])) if "agent_over" in g.files else {}
     cfg["agent"].update(agent_over)
-    logstd = "logstd" in g.files
+    from tests.test_oracle_vs_golden import golden_logstd
+
+    logstd = golden_logstd(g)
     if logstd:
-        cfg["agent"]["model"]["actor_std_type"] = "CONSTANT"
+        cfg["agent"]["model"]["actor_std_type"] = "VARIABLE" if logstd == "variable" else "CONSTANT"
     ag = make_agent(cfg, [gload("motion_small")["frames"]], [1.0])
     assert ag.Mb == M
     params = OL.synth_params(int(g["seed"]), nets=nets, logstd=logstd)
@@ -238,7 +248,8 @@ def minibatch_loss_gradients_and_adamw(precision="fp32", fixture="losses"):
                 assert d.max() <= 2.1e-4 * (step + 1), (k, float(d.max()))
                 assert (d > 5e-6).mean() < 0.01, (k, float((d > 5e-6).mean()))
     # padded rows / columns of the device layout never receive gradient
-    assert float(m.view("actor", "Wh", m.grads)[29:].abs().max()) == 0
+    wh = m.view("actor", "Wh", m.grads)  # (a log-std head occupies rows 32..60)
+    assert float(wh[29:32].abs().max()) == 0 and float(wh[61:].abs().max() if wh.shape[0] == 64 else 0.0) == 0
     assert float(m.view("disc", "W0", m.grads)[:, 114:].abs().max()) == 0
 
 
@@ -423,6 +434,49 @@ def test_checkpoint_roundtrip_uses_reference_keys(tmp_path):
     ag._model.params.zero_()
     ag.load(path)
     assert torch.equal(ag._model.params, before)
+
+
+@pytest.mark.parametrize("std_type,precision", [("CONSTANT", "fp32"), ("VARIABLE", "fp32"), ("VARIABLE", "bf16"), ("CONSTANT", "bf16")])
+def test_trainable_std_types_train_and_checkpoint(tmp_path, std_type, precision):
+    """actor_std_type CONSTANT / VARIABLE through the whole loop: two iterations (graph rollout on) stay finite and move the log-std
+    parameters; the checkpoint carries the reference's keys for that type in the reference's registration order (a Parameter of the
+    distribution module before its sub-modules: distribution_gaussian_diag.py:19-43), the optimiser state one entry more / two more than
+    FIXED, and loads back bit for bit."""
+    import torch
+    import add_gym_amd.learning.add_agent as A
+
+    cfg = make_cfg(256, steps_per_iter=8, matmul_precision=precision, rollout_graph=True)
+    cfg["agent"]["model"]["actor_std_type"] = std_type
+    cfg["task"]["motion_file"] = "synthetic:2x300"
+    ag = A.ADDAgent(cfg)
+    ag.reset_all_envs()
+    ag._init_train()
+    key = "_model._action_dist._logstd_net" + (".bias" if std_type == "VARIABLE" else "")
+    before = ag._model.export()[key].clone()
+    assert torch.allclose(before, torch.full_like(before, float(np.log(0.05))))
+    for _ in range(2):
+        info = ag._train_iter()
+        ag._iter += 1
+    torch.cuda.synchronize()
+    assert all(np.isfinite(v) for v in info.values())
+    after = ag._model.export()
+    assert float((after[key] - before).abs().max()) > 1e-4  # 80 optimiser steps moved it
+    path = str(tmp_path / "model.pt")
+    ag.save(path)
+    ck = torch.load(path, weights_only=True)
+    names = list(ck["model"])
+    i_mean = names.index("_model._action_dist._mean_net.weight")
+    if std_type == "CONSTANT":
+        assert names[i_mean - 1] == "_model._action_dist._logstd_net" and tuple(ck["model"][names[i_mean - 1]].shape) == (29,)
+        assert len(ck["optimizer"]["state"]) == 23
+    else:
+        assert names[i_mean + 2:i_mean + 4] == ["_model._action_dist._logstd_net.weight", "_model._action_dist._logstd_net.bias"]
+        assert tuple(ck["model"][names[i_mean + 2]].shape) == (29, 512) and tuple(ck["model"][names[i_mean]].shape) == (29, 512)
+        assert len(ck["optimizer"]["state"]) == 24
+    params = ag._model.params.clone()
+    ag._model.params.zero_()
+    ag.load(path)
+    assert torch.equal(ag._model.params, params)
 
 
 def test_training_runs_and_learns_signal(tmp_path):

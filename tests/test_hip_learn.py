@@ -39,21 +39,28 @@ def logp_const():
     return float((-0.5 * 29 * np.log(2.0 * np.pi) - torch.sum(logstd)).item()), float(torch.exp(logstd)[0].item())
 
 
-@pytest.mark.parametrize("name", ["actor_step", "actor_step_constant_std"])
+@pytest.mark.parametrize("name", ["actor_step", "actor_step_constant_std", "actor_step_variable_std"])
 def test_actor_sample_matches_reference_golden(name):
-    """(`_constant_std`: actor_std_type CONSTANT -- a trainable log-std per action dimension through addhip_dist_refresh's vector.)"""
+    """(`_constant_std`: actor_std_type CONSTANT -- a trainable log-std per action dimension through addhip_dist_refresh's vector;
+    `_variable_std`: VARIABLE -- the per-sample log-std in columns 32..60 of a 64-wide head output.)"""
     import torch
     import add_gym_amd._lib as L
+    from tests.test_oracle_vs_golden import golden_logstd
 
     g = gload(name)
-    params = OL.synth_params(int(g["seed"]), logstd=name.endswith("constant_std"))
+    variable = golden_logstd(name) == "variable"
+    params = OL.synth_params(int(g["seed"]), logstd=golden_logstd(name))
     model = OL.Model(params)
     on = OL.Normalizer(264, g["obs_mean"], g["obs_std"])
     with torch.no_grad():
-        mean = model.actor_mean(OL.t32(on.normalize(g["obs"]))).numpy()
+        mean, ls_rows, _ = model.dist(OL.t32(on.normalize(g["obs"])))
+        mean = mean.numpy()
     n = mean.shape[0]
-    mean32 = np.zeros((n, 32), F)
+    ldm = 64 if variable else 32
+    mean32 = np.zeros((n, ldm), F)
     mean32[:, :29] = mean
+    if variable:
+        mean32[:, 32:61] = ls_rows.numpy()
     c, std = logp_const()
     dist = None
     if OL.LOGSTD_KEY in params:  # the scalars are ignored then
@@ -69,7 +76,11 @@ def test_actor_sample_matches_reference_golden(name):
     act = torch.zeros(n, 32, device="cuda")
     logp = torch.zeros(n, device="cuda")
     mask = torch.zeros(n, device="cuda")
-    L.call("addhip_actor_sample", P(T(mean32)), 32, P(T(g["noise"])), std, c if dist is None else float("nan"), dist, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0, None, 1.0,
+    dmean = T(mean32)
+    rows = L.ptr(dmean) + 4 * 32 if variable else None  # (the scalars / dist are ignored then)
+    if variable:
+        std, c = float("nan"), float("nan")
+    L.call("addhip_actor_sample", L.ptr(dmean), ldm, P(T(g["noise"])), std, c if dist is None else float("nan"), dist, rows, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0, None, 1.0,
            L.ptr(act), L.ptr(logp), L.ptr(mask), L.current_stream())
     torch.cuda.synchronize()
     np.testing.assert_allclose(act.cpu().numpy()[:, :29], g["action"], rtol=0, atol=1e-5)
@@ -78,7 +89,7 @@ def test_actor_sample_matches_reference_golden(name):
     # exploration probability < 1 (ppo_agent.py:80-88): env i explores iff u[i] < p, else it takes the mode with mask 0
     u = np.random.default_rng(3).random(n).astype(F)
     act2, logp2, mask2 = torch.zeros(n, 32, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-    L.call("addhip_actor_sample", P(T(mean32)), 32, P(T(g["noise"])), std, c, dist, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0, P(T(u)), 0.5,
+    L.call("addhip_actor_sample", L.ptr(dmean), ldm, P(T(g["noise"])), std, c, dist, rows, P(T(g["a_mean"])), P(T(g["a_std"])), n, 0, P(T(u)), 0.5,
            L.ptr(act2), L.ptr(logp2), L.ptr(mask2), L.current_stream())
     torch.cuda.synchronize()
     ex = u < 0.5
@@ -86,7 +97,9 @@ def test_actor_sample_matches_reference_golden(name):
     assert torch.equal(act2[T(ex)], act[T(ex)]) and torch.equal(logp2[T(ex)], logp[T(ex)])
     mode = (mean * g["a_std"] + g["a_mean"]).astype(F)
     np.testing.assert_allclose(act2.cpu().numpy()[~ex][:, :29], mode[~ex], rtol=0, atol=1e-6)
-    np.testing.assert_allclose(logp2.cpu().numpy()[~ex], c, rtol=1e-6)  # log-density at the mode
+    if variable:  # log-density at the mode: the row's own constant
+        c = (-0.5 * 29 * np.log(2 * np.pi) - ls_rows.numpy().astype(np.float64).sum(1))[~ex]
+    np.testing.assert_allclose(logp2.cpu().numpy()[~ex], c, rtol=2e-6)  # log-density at the mode
 
 
 def test_td_lambda_adv_matches_reference_golden():
@@ -297,7 +310,7 @@ def test_actor_loss_head_gradient(trainable_std):
     dmask = T(mask)
     L.call("addhip_count_mask", L.ptr(dmask), M, L.ptr(nv), L.current_stream())
     L.call("addhip_actor_loss", P(T(pad(mean))), P(T(pad(na))), P(T(old)), P(T(adv)), L.ptr(dmask), M, std, c, dist, 0.2, 10.0, 0.3, 1.0, L.ptr(nv),
-           L.ptr(dm), L.ptr(gls) if trainable_std else None, L.ptr(stats), L.current_stream())
+           L.ptr(dm), L.ptr(gls) if trainable_std else None, L.ptr(stats), 32, None, L.current_stream())
     torch.cuda.synchronize()
     assert float(nv.item()) == mask.sum()
     if trainable_std:
@@ -313,6 +326,48 @@ def test_actor_loss_head_gradient(trainable_std):
     np.testing.assert_allclose(s[5], reg.item(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(s[2], ratio.mean().item(), rtol=1e-4)
     np.testing.assert_allclose(s[1], (torch.abs(ratio - 1) > 0.2).float().mean().item(), atol=2.0 / nvf)
+
+
+def test_actor_loss_with_a_log_std_head():
+    """actor_std_type VARIABLE: mean and per-sample log-std as the two halves of a 64-wide head output; d loss / d mean in columns 0..28 and
+    d loss / d logstd in columns 32..60 of d_mean against autograd (distribution_gaussian_diag.py:52-53, 90-94; ppo_agent.py:221-275)."""
+    import torch
+    import add_gym_amd._lib as L
+
+    rng = np.random.RandomState(9)
+    M = 777
+    mean = (rng.standard_normal((M, 29)) * 0.7).astype(F)
+    ls = (np.log(0.05) + rng.uniform(-0.5, 0.5, (M, 29))).astype(F)
+    na = (mean + rng.standard_normal((M, 29)) * 1.5 * np.exp(ls)).astype(F)
+    adv = np.clip(rng.standard_normal(M), -4, 4).astype(F)
+    mask = (rng.rand(M) < 0.9).astype(F)
+    mt, lt = torch.tensor(mean, requires_grad=True), torch.tensor(ls, requires_grad=True)
+    d = (torch.tensor(na) - mt) / torch.exp(lt)
+    logp = -0.5 * torch.sum(d * d, -1) + (-0.5 * 29 * np.log(2.0 * np.pi) - torch.sum(lt, -1))
+    old = (logp.detach() + torch.tensor(rng.standard_normal(M).astype(F) * 0.3)).numpy()
+    sel = torch.tensor(mask) == 1.0
+    ratio = torch.exp(logp - torch.tensor(old))[sel]
+    a = torch.tensor(adv)[sel]
+    loss = -torch.mean(torch.minimum(a * ratio, a * torch.clamp(ratio, 0.8, 1.2)))
+    vmin, vmax = torch.clamp_max(mt[sel] + 1, 0), torch.clamp_min(mt[sel] - 1, 0)
+    bound = torch.mean(torch.sum(vmin ** 2, -1) + torch.sum(vmax ** 2, -1))
+    (loss + 10.0 * bound).backward()
+    out64 = np.zeros((M, 64), F)
+    out64[:, :29], out64[:, 32:61] = mean, ls
+    na32 = np.zeros((M, 32), F)
+    na32[:, :29] = na
+    head = T(out64)
+    nv, dm, stats, dmask = torch.zeros(1, device="cuda"), torch.full((M, 64), 7.0, device="cuda"), torch.zeros(8, device="cuda"), T(mask)
+    L.call("addhip_count_mask", L.ptr(dmask), M, L.ptr(nv), L.current_stream())
+    L.call("addhip_actor_loss", L.ptr(head), P(T(na32)), P(T(old)), P(T(adv)), L.ptr(dmask), M, float("nan"), float("nan"), None, 0.2, 10.0, 0.0, 1.0, L.ptr(nv),
+           L.ptr(dm), None, L.ptr(stats), 64, L.ptr(head) + 4 * 32, L.current_stream())
+    torch.cuda.synchronize()
+    got = dm.cpu().numpy()
+    gm, gl = mt.grad.numpy(), lt.grad.numpy()
+    np.testing.assert_allclose(got[:, :29], gm, rtol=2e-4, atol=2e-4 * np.abs(gm).max())
+    np.testing.assert_allclose(got[:, 32:61], gl, rtol=2e-4, atol=2e-4 * np.abs(gl).max())
+    assert np.all(got[:, 29:32] == 0) and np.all(got[:, 61:] == 0)
+    np.testing.assert_allclose(-stats.cpu().numpy()[0], loss.item(), rtol=1e-4, atol=1e-6)
 
 
 def test_critic_and_disc_heads_and_grad_penalty():
@@ -704,7 +759,7 @@ def test_fused_actor_head_equals_the_unfused_sequence(hidden, rows, trainable_st
     mean, d_mean, stats_a = z(M, 32), z(M, 32), z(8)
     L.call("addhip_gemm_f32", gemm(M, 32, K, L.ptr(H), K, 1, L.ptr(dWh), K, 1, L.ptr(mean), 32, L.EPI_BIAS, L.ptr(dbh)), st)
     L.call("addhip_actor_loss", L.ptr(mean), L.ptr(dna), L.ptr(dol), L.ptr(dadv), L.ptr(dmask), M, std, logp_const, dist, clip, bw, rw, ls, L.ptr(nv), L.ptr(d_mean),
-           L.ptr(want_gls) if trainable_std else None, L.ptr(stats_a), st)
+           L.ptr(want_gls) if trainable_std else None, L.ptr(stats_a), 32, None, st)
     torch.cuda.synchronize()
     dm64, H64 = d_mean.cpu().numpy().astype(np.float64), H.cpu().numpy().astype(np.float64)
     want_gW, want_gb = dm64.T @ H64, dm64.sum(0)

@@ -260,11 +260,19 @@ def test_normalizers():
     close(dn.normalize(g["yq"]), g["yq_norm"])
 
 
-@pytest.mark.parametrize("name", ["actor_step", "actor_step_constant_std"])
+def golden_logstd(g_or_name):
+    """synth_params' logstd argument for a fixture: False (FIXED), True (CONSTANT: a vector), "variable" (VARIABLE: a second head)."""
+    if isinstance(g_or_name, str):
+        return "variable" if g_or_name.endswith("variable_std") else g_or_name.endswith("constant_std")
+    return False if "logstd" not in g_or_name.files else ("variable" if int(g_or_name["logstd"]) == 2 else True)
+
+
+@pytest.mark.parametrize("name", ["actor_step", "actor_step_constant_std", "actor_step_variable_std"])
 def test_actor_step(name):
-    """(`_constant_std`: actor_std_type CONSTANT -- a standard deviation per action dimension, distribution_gaussian_diag.py:32-37, 47-58.)"""
+    """(`_constant_std`: actor_std_type CONSTANT -- a standard deviation per action dimension, distribution_gaussian_diag.py:32-37, 47-58;
+    `_variable_std`: VARIABLE -- per sample and dimension, from a second head, :38-43, 52-53.)"""
     g = gload(name)
-    model = L.Model(L.synth_params(int(g["seed"]), logstd=name.endswith("constant_std")))
+    model = L.Model(L.synth_params(int(g["seed"]), logstd=golden_logstd(name)))
     on = L.Normalizer(264, g["obs_mean"], g["obs_std"])
     an = L.Normalizer(29, g["a_mean"], g["a_std"])
     a, logp, _ = L.actor_step(model, on, an, g["obs"], g["noise"], g["rand_action_mask"])
@@ -315,10 +323,10 @@ def golden_loss_cfg(g):
     return L.LossCfg(**(json.loads(str(g["agent_over"])) if "agent_over" in g.files else {}))
 
 
-@pytest.mark.parametrize("name", ["losses", "losses_small_nets", "losses_constant_std", "losses_disc3", "losses_constant_std_entropy"])
+@pytest.mark.parametrize("name", ["losses", "losses_small_nets", "losses_constant_std", "losses_disc3", "losses_constant_std_entropy", "losses_variable_std"])
 def test_losses_grads_adamw(name):
     g = gload(name)
-    model = L.Model(L.synth_params(int(g["seed"]), nets=golden_nets(g), logstd="logstd" in g.files))
+    model = L.Model(L.synth_params(int(g["seed"]), nets=golden_nets(g), logstd=golden_logstd(g)))
     on = L.Normalizer(264, g["obs_mean"], g["obs_std"])
     an = L.Normalizer(29, g["a_mean"], g["a_std"])
     dn = L.DiffNormalizer(114)

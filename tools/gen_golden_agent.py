@@ -254,7 +254,7 @@ def gen_sampler():
 
 def gen_actor_step(name="actor_step", logstd=False):
     n = 96
-    ag, cfg = build_agent(n, model_over={"actor_std_type": "CONSTANT"} if logstd else None)
+    ag, cfg = build_agent(n, model_over={"actor_std_type": "VARIABLE" if logstd == "variable" else "CONSTANT"} if logstd else None)
     load_synth(ag, 101, logstd=logstd)
     rng = np.random.RandomState(2)
     ag._reset_envs()
@@ -328,6 +328,11 @@ def gen_losses_constant_std():
     gen_losses("losses_constant_std", None, logstd=True)
 
 
+def gen_losses_variable_std():
+    """actor_std_type VARIABLE (distribution_gaussian_diag.py:38-43, 52-53): the log-std is a second linear head on the actor's last layer."""
+    gen_losses("losses_variable_std", None, logstd="variable")
+
+
 def gen_losses_constant_std_entropy():
     """the same with the entropy bonus on (action_entropy_weight = 0.05, ppo_agent.py:262-266): its gradient reaches the log-std only."""
     gen_losses("losses_constant_std_entropy", None, logstd=True, agent_over=dict(action_entropy_weight=0.05))
@@ -336,7 +341,7 @@ def gen_losses_constant_std_entropy():
 def gen_losses(name="losses", nets=None, logstd=False, agent_over=None):
     n = 64
     M = 256
-    ag, cfg = build_agent(n, model_over=dict(nets or {}, **({"actor_std_type": "CONSTANT"} if logstd else {})), **(agent_over or {}))
+    ag, cfg = build_agent(n, model_over=dict(nets or {}, **({"actor_std_type": "VARIABLE" if logstd == "variable" else "CONSTANT"} if logstd else {})), **(agent_over or {}))
     load_synth(ag, 202, nets, logstd)
     rng = np.random.RandomState(17)
     # non-trivial normalisers
@@ -356,6 +361,10 @@ def gen_losses(name="losses", nets=None, logstd=False, agent_over=None):
     # make old log-probs consistent with the current policy so that ratios are O(1)
     with torch.no_grad():
         dist = ag.model.eval_actor(ag._obs_norm.normalize(batch["obs"]))
+        if logstd == "variable":
+            # actions drawn from the policy itself (a few sigma at most): with the 12-sigma actions above d logp / d logstd ~ 140 per dimension,
+            # and ONE Adam step through the log-std head moves logp by ~1e2 -- the reference's own third step is NaN
+            batch["action"] = ag._a_norm.unnormalize(dist.mean + dist.stddev * T(rng.standard_normal((M, 29)).astype(np.float32) * 1.5))
         batch["a_logp"] = dist.log_prob(ag._a_norm.normalize(batch["action"])) + T(rng.standard_normal(M).astype(np.float32) * 0.3)
     inp = {k: v.clone() for k, v in batch.items()}
     out = {"in." + k: v for k, v in inp.items()}
@@ -366,7 +375,7 @@ def gen_losses(name="losses", nets=None, logstd=False, agent_over=None):
     if nets is not None:
         out["nets"] = np.array(json.dumps(nets))
     if logstd:
-        out["logstd"] = np.array(1)
+        out["logstd"] = np.array(2 if logstd == "variable" else 1)
     if agent_over:
         out["agent_over"] = np.array(json.dumps(agent_over))
     sd_params = dict(ag.named_parameters())
@@ -620,4 +629,4 @@ def gen_test_rollout():
 
 AGENT_GENS = dict(obs_reward_done_s4=lambda: gen_obs_reward_done_s2(4, "four"), reset_s4=lambda: gen_reset_s2(4),
                   loop_1iter_s4=lambda: gen_loop_1iter("loop_1iter_s4", task_over=dict(num_disc_obs_steps=4)), obs_reward_done_s2=gen_obs_reward_done_s2, reset_s2=gen_reset_s2, loop_1iter_s2=lambda: gen_loop_1iter("loop_1iter_s2", task_over=dict(num_disc_obs_steps=2)), loop_1iter_two=gen_loop_1iter_two, loop_1iter_time=gen_loop_1iter_time, logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
-                  td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, losses_small_nets=gen_losses_small_nets, losses_disc3=gen_losses_disc3, losses_constant_std_entropy=gen_losses_constant_std_entropy, losses_constant_std=gen_losses_constant_std, actor_step_constant_std=lambda: gen_actor_step("actor_step_constant_std", True), normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
+                  td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, losses_small_nets=gen_losses_small_nets, losses_disc3=gen_losses_disc3, losses_variable_std=gen_losses_variable_std, actor_step_variable_std=lambda: gen_actor_step("actor_step_variable_std", "variable"), losses_constant_std_entropy=gen_losses_constant_std_entropy, losses_constant_std=gen_losses_constant_std, actor_step_constant_std=lambda: gen_actor_step("actor_step_constant_std", True), normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
