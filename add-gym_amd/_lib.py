@@ -120,7 +120,7 @@ class PpoLossT(C.Structure):
                 ("norm_action", f32p),
                 ("old_logp", f32p), ("adv", f32p), ("tar_val", f32p), ("rand_mask", f32p), ("action_std", C.c_float), ("logp_const", C.c_float),
                 ("ppo_clip_ratio", C.c_float), ("action_bound_weight", C.c_float), ("action_reg_weight", C.c_float), ("critic_loss_weight", C.c_float),
-                ("grad_scale", C.c_float), ("dist", f32p), ("g_logstd", f32p), ("head_precision", C.c_int32), ("mean", f32p), ("d_mean", f32p), ("dv", f32p), ("num_valid", f32p), ("stats", f32p)]
+                ("grad_scale", C.c_float), ("dist", f32p), ("g_logstd", f32p), ("action_entropy_weight", C.c_float), ("head_precision", C.c_int32), ("mean", f32p), ("d_mean", f32p), ("dv", f32p), ("num_valid", f32p), ("stats", f32p)]
 
 
 class PpoMarksT(C.Structure):
@@ -202,7 +202,7 @@ SIGNATURES = {
     "addhip_norm_merge": [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
     "addhip_diffnorm_merge": [vp, vp, vp, i64, i32, vp],
     "addhip_gather_minibatch": [P(GatherT), vp],
-    "addhip_actor_loss": [vp, vp, vp, vp, vp, i32, f32, f32, vp, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp, vp],
+    "addhip_actor_loss": [vp, vp, vp, vp, vp, i32, f32, f32, vp, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp, f32, vp],
     "addhip_count_mask": [vp, i32, vp, vp],
     "addhip_actor_head_slabs": [i32],     # returns the slab count
     "addhip_actor_head": [P(ActorHeadT), vp],

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void count_mask_kernel(const float* mask, int 
 __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, const float* na, const float* old_logp, const float* adv,
                                                          const float* mask, int M, float stdv, float logp_const, const float* dist, float clip, float bound_w,
                                                          float reg_w, float loss_scale, const float* n_valid, float* d_mean, float* g_logstd, float* stats, int ldm,
-                                                         const float* logstd_rows) {
+                                                         const float* logstd_rows, float ent_w) {
   __shared__ float sh[4];
   __shared__ float sh_ls[4][32];
   const int lane = threadIdx.x & 63;
@@ -403,14 +403,16 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, cons
     logp_const = dist[32];
   }
   float gls = 0.f;  // d loss / d logstd[lane], this wave's rows
-  float st_min = 0.f, st_clip = 0.f, st_ratio = 0.f, st_bound = 0.f, st_reg = 0.f;
+  float st_min = 0.f, st_clip = 0.f, st_ratio = 0.f, st_bound = 0.f, st_reg = 0.f, st_ent = 0.f;
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
     const bool valid = mask[r] == 1.0f;  // ppo_agent.py:229-233
     float mu = 0.f, d = 0.f, viol = 0.f;
     if (logstd_rows) {  // actor_std_type VARIABLE: per-sample log-std (the columns behind the mean's)
       const float ls = lane < ADDHIP_NUM_DOF ? logstd_rows[(size_t)r * ldm + lane] : 0.f;
       stdv = expf(ls);
-      logp_const = (float)(-0.5 * ADDHIP_NUM_DOF * 1.8378770664093453) - wave_sum(ls);
+      const float ls_sum = wave_sum(ls);
+      logp_const = (float)(-0.5 * ADDHIP_NUM_DOF * 1.8378770664093453) - ls_sum;
+      if (valid && lane == 0) st_ent += ls_sum + (float)(0.5 * ADDHIP_NUM_DOF * 2.8378770664093453);  // entropy of this sample's distribution (:96-99)
     }
     if (lane < ADDHIP_NUM_DOF) {
       mu = mean[(size_t)r * ldm + lane];
@@ -433,7 +435,8 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, cons
       float g = 0.f;
       if (valid && lane < ADDHIP_NUM_DOF) g = g_logp * (d / stdv) + (bound_w * 2.f * viol + reg_w * 2.f * mu) / nv;
       d_mean[(size_t)r * ldm + lane] = loss_scale * g;
-      const float dls = lane < ADDHIP_NUM_DOF ? loss_scale * g_logp * (d * d - 1.f) : 0.f;  // d logp / d logstd_j = d_j^2 - 1
+      // d logp / d logstd_j = d_j^2 - 1;  per-sample log-std: + the entropy bonus -ent_w * mean(entropy), whose gradient is -ent_w / nv on every log-std of an exploring sample
+      const float dls = lane < ADDHIP_NUM_DOF ? loss_scale * (g_logp * (d * d - 1.f) - ((logstd_rows && valid) ? ent_w / nv : 0.f)) : 0.f;
       gls += dls;
       if (logstd_rows) d_mean[(size_t)r * ldm + 32 + lane] = dls;  // (VARIABLE: the second head's output gradient, columns 32..63)
     }
@@ -447,6 +450,10 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* mean, cons
   }
   float t0 = block_sum(st_min, sh), t1 = block_sum(st_clip, sh), t2 = block_sum(st_ratio, sh), t3 = block_sum(st_bound, sh);
   float t5 = block_sum(st_reg, sh);
+  if (logstd_rows && ent_w != 0.f) {
+    const float t6 = block_sum(st_ent, sh);
+    if (threadIdx.x == 0) atomicAdd(&stats[6], t6 / nv);
+  }
   if (dist && g_logstd) {
     if (lane < 32) sh_ls[threadIdx.x >> 6][lane] = gls;
     __syncthreads();
@@ -973,14 +980,15 @@ extern "C" int addhip_count_mask(const float* rand_mask, int32_t M, float* out, 
 
 extern "C" int addhip_actor_loss(const float* mean, const float* norm_action, const float* old_logp, const float* adv, const float* rand_mask, int32_t M,
                                  float stdv, float logp_const, const float* dist, float clip_ratio, float bound_weight, float reg_weight, float loss_scale,
-                                 const float* n_valid, float* d_mean, float* g_logstd, float* stats, int32_t ld_mean, const float* logstd_rows, void* stream) {
+                                 const float* n_valid, float* d_mean, float* g_logstd, float* stats, int32_t ld_mean, const float* logstd_rows, float entropy_weight,
+                                 void* stream) {
   ADDHIP_REQUIRE(mean && norm_action && old_logp && adv && rand_mask && n_valid && d_mean && stats && M > 0, "actor_loss: bad arguments");
   ADDHIP_REQUIRE(!dist || g_logstd, "actor_loss: a trainable log-std (dist) needs g_logstd");
   ADDHIP_REQUIRE(ld_mean == 32 || (ld_mean == 64 && logstd_rows), "actor_loss: ld_mean is 32, or 64 with the per-sample log-std columns (logstd_rows)");
   ADDHIP_RECORDABLE(addhip_actor_loss, mean, norm_action, old_logp, adv, rand_mask, M, stdv, logp_const, dist, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, g_logstd, stats,
-                    ld_mean, logstd_rows);
+                    ld_mean, logstd_rows, entropy_weight);
   hipLaunchKernelGGL(actor_loss_kernel, dim3(row_grid(M) < 256 ? row_grid(M) : 256), dim3(256), 0, ST, mean, norm_action, old_logp, adv, rand_mask, M,
-                     stdv, logp_const, dist, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, g_logstd, stats, ld_mean, logstd_rows);
+                     stdv, logp_const, dist, clip_ratio, bound_weight, reg_weight, loss_scale, n_valid, d_mean, g_logstd, stats, ld_mean, logstd_rows, entropy_weight);
   return addhip::check_launch("actor_loss_kernel");
 }
 

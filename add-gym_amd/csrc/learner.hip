@@ -345,7 +345,7 @@ static int ppo_loss_impl(const addhip_ppo_loss_t* d, addhip_ppo_marks_t* marks, 
     }
     LAUNCH(addhip_actor_loss(d->mean, d->norm_action, d->old_logp, d->adv, d->rand_mask, Mb, d->action_std, d->logp_const, d->dist, d->ppo_clip_ratio,
                              d->action_bound_weight, d->action_reg_weight, d->grad_scale, d->num_valid, d->d_mean, d->g_logstd, d->stats, HR,
-                             HR == 64 ? d->mean + 32 : nullptr, stream));
+                             HR == 64 ? d->mean + 32 : nullptr, HR == 64 ? d->action_entropy_weight : 0.f, stream));
     {  // head weight gradient: d_mean^T h over Mb rows, 32 K slices
       addhip_gemm_t g = gemm(HR, hA, Mb, d->d_mean, HR, 0, A.h[nA - 1], hA, 0, A.slabs, hA);
       g.split_k = 32;

@@ -224,8 +224,6 @@ class ADDAgent(AgentIO):
         self._norm_adv_clip = float(c["norm_adv_clip"])
         self._action_bound_weight = float(c["action_bound_weight"])
         self._action_entropy_weight = float(c["action_entropy_weight"])  # ppo_agent.py:262-272
-        if self._action_entropy_weight != 0 and str(c["model"].get("actor_std_type", "FIXED")) == "VARIABLE":
-            raise NotImplementedError("agent.action_entropy_weight != 0 with actor_std_type VARIABLE (the entropy's gradient through the log-std head) is not implemented")
         self._action_reg_weight = float(c["action_reg_weight"])
         self._critic_loss_weight = float(c["critic_loss_weight"])
         self._exp_anneal_samples = float(c.get("exp_anneal_samples", float("inf")))  # ppo_agent.py:32-34
@@ -404,7 +402,7 @@ class ADDAgent(AgentIO):
         ppo = L.PpoLossT(C.pointer(self._mlp_c["actor"]), C.pointer(self._mlp_c["critic"]), Mb, L.ptr(W["norm_obs"]), L.ptr(W["norm_obs16"]) if s16 else None,
                          L.ptr(W["mb_amax"][0]) if self._f16x2 else None, L.ptr(W["norm_act"]), L.ptr(W["mb_logp"]), L.ptr(W["mb_adv"]), L.ptr(W["mb_tar"]), L.ptr(W["mb_mask"]), m.std32, m.logp_const,
                          self._ppo_clip_ratio, self._action_bound_weight, self._action_reg_weight, self._critic_loss_weight, gs,
-                         m.dist_ptr(), m.g("actor", "logstd") if m.dist is not None else None, self._prec_small,
+                         m.dist_ptr(), m.g("actor", "logstd") if m.dist is not None else None, self._action_entropy_weight, self._prec_small,
                          L.ptr(W["mean"]), L.ptr(W["d_mean"]), L.ptr(W["dv"]), L.ptr(W["nv"]), L.ptr(W["stats"]))
         o = (lambda k: L.ptr(W[k])) if s16 else (lambda k: None)
         f = (lambda k: None) if s16 else (lambda k: L.ptr(W[k]))
@@ -799,6 +797,8 @@ class ADDAgent(AgentIO):
         if self._action_entropy_weight != 0:  # fixed-std policy: the entropy is a constant (distribution_gaussian_diag.py:96-99)
             # (trainable log-std: the entropy of the policy as it stands after the iteration's last step, not the mean over its steps)
             ent = self._model.entropy if self._model.dist is None else float(self._model.dist[33])
+            if self._model.std_type == "VARIABLE":  # (per-sample entropies: their mean over the exploring samples, averaged over the steps)
+                ent = s[6]
             actor_loss += -self._action_entropy_weight * ent
             extra["action_entropy"] = ent
         if self._action_reg_weight != 0:

@@ -460,7 +460,9 @@ int addhip_actor_loss(const float* mean, const float* norm_action, const float* 
                       float* g_logstd /* [29], with dist */, float* stats,
                       int32_t ld_mean /* row stride of mean and d_mean: 32, or 64 with logstd_rows */,
                       const float* logstd_rows /* or NULL; VARIABLE: per-sample log-std [M, ld_mean] (usually mean + 32); d loss / d logstd then goes
-                                                  to columns 32..63 of d_mean: the two heads are one 64-wide product */, void* stream);
+                                                  to columns 32..63 of d_mean: the two heads are one 64-wide product */,
+                      float entropy_weight /* with logstd_rows: the entropy bonus -w * mean(entropy) (ppo_agent.py:262-266) -- its gradient on every
+                                              log-std, stats[6] += mean entropy over the exploring samples */, void* stream);
 /* The actor's head section as ONE launch: mean = H Wh^T + bh (DistributionGaussianDiagBuilder.forward, distribution_gaussian_diag.py:47-58),
  * addhip_actor_loss on it (same arguments, same stats slots), and the backward step through the head into the last hidden layer:
  *   dz = (d_mean Wh) * (H > 0)   -> dz [rows, hidden] fp32 and / or dz16 (ADDHIP_STORE_* format planes16),
@@ -709,6 +711,8 @@ typedef struct {
   const float* old_logp; const float* adv; const float* tar_val; const float* rand_mask;   /* [Mb] */
   float action_std, logp_const, ppo_clip_ratio, action_bound_weight, action_reg_weight, critic_loss_weight, grad_scale;
   const float* dist; float* g_logstd;             /* actor_std_type CONSTANT: addhip_dist_refresh's vector and the log-std's gradient [32] (NULL: FIXED) */
+  float action_entropy_weight;                    /* actor_std_type VARIABLE (actor->head_rows == 64): the entropy bonus's weight (other types: its
+                                                     gradient is zero / added by the host behind the exchange) */
   int32_t head_precision;                         /* ADDHIP_PREC_* of the three 32-wide head GEMMs (fp32 operands in every mode) */
   float* mean; float* d_mean;                     /* workspace [Mb, actor->head_rows] each (32; 64 with a log-std head: mean | log-std) */
   float* dv;                                      /* workspace [Mb] */

@@ -98,12 +98,12 @@ def test_three_layer_discriminator_matches_reference(precision):
     minibatch_loss_gradients_and_adamw(precision, "losses_disc3")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x2"])
-def test_entropy_bonus_reaches_the_trainable_log_std(precision):
-    """action_entropy_weight = 0.05 with actor_std_type CONSTANT (ppo_agent.py:262-266): the bonus's gradient, -w on every log-std, is
-    added behind the exchange (ADDAgent._post_exchange_grads); gradients, three AdamW steps and the logged entropy against the reference
-    (tools/gen_golden_agent.py: gen_losses_constant_std_entropy)."""
-    minibatch_loss_gradients_and_adamw(precision, "losses_constant_std_entropy")
+@pytest.mark.parametrize("precision,fixture", [("fp32", "losses_constant_std_entropy"), ("f16x2", "losses_constant_std_entropy"), ("fp32", "losses_variable_std_entropy")])
+def test_entropy_bonus_reaches_the_trainable_log_std(precision, fixture):
+    """action_entropy_weight = 0.05 (ppo_agent.py:262-266).  actor_std_type CONSTANT: the bonus's gradient, -w on every log-std, is added
+    behind the exchange (ADDAgent._post_exchange_grads); VARIABLE: per-sample entropies, -w / n on every log-std of an exploring sample inside
+    the loss kernel.  Gradients, three AdamW steps and the logged entropy against the reference (tools/gen_golden_agent.py)."""
+    minibatch_loss_gradients_and_adamw(precision, fixture)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])

@@ -310,7 +310,7 @@ def test_actor_loss_head_gradient(trainable_std):
     dmask = T(mask)
     L.call("addhip_count_mask", L.ptr(dmask), M, L.ptr(nv), L.current_stream())
     L.call("addhip_actor_loss", P(T(pad(mean))), P(T(pad(na))), P(T(old)), P(T(adv)), L.ptr(dmask), M, std, c, dist, 0.2, 10.0, 0.3, 1.0, L.ptr(nv),
-           L.ptr(dm), L.ptr(gls) if trainable_std else None, L.ptr(stats), 32, None, L.current_stream())
+           L.ptr(dm), L.ptr(gls) if trainable_std else None, L.ptr(stats), 32, None, 0.0, L.current_stream())
     torch.cuda.synchronize()
     assert float(nv.item()) == mask.sum()
     if trainable_std:
@@ -328,8 +328,9 @@ def test_actor_loss_head_gradient(trainable_std):
     np.testing.assert_allclose(s[1], (torch.abs(ratio - 1) > 0.2).float().mean().item(), atol=2.0 / nvf)
 
 
-def test_actor_loss_with_a_log_std_head():
-    """actor_std_type VARIABLE: mean and per-sample log-std as the two halves of a 64-wide head output; d loss / d mean in columns 0..28 and
+@pytest.mark.parametrize("ENT_W", [0.0, 0.05])
+def test_actor_loss_with_a_log_std_head(ENT_W):
+    """(ENT_W: the entropy bonus -w * mean(entropy) of ppo_agent.py:262-266 with per-sample entropies.)  actor_std_type VARIABLE: mean and per-sample log-std as the two halves of a 64-wide head output; d loss / d mean in columns 0..28 and
     d loss / d logstd in columns 32..60 of d_mean against autograd (distribution_gaussian_diag.py:52-53, 90-94; ppo_agent.py:221-275)."""
     import torch
     import add_gym_amd._lib as L
@@ -351,7 +352,8 @@ def test_actor_loss_with_a_log_std_head():
     loss = -torch.mean(torch.minimum(a * ratio, a * torch.clamp(ratio, 0.8, 1.2)))
     vmin, vmax = torch.clamp_max(mt[sel] + 1, 0), torch.clamp_min(mt[sel] - 1, 0)
     bound = torch.mean(torch.sum(vmin ** 2, -1) + torch.sum(vmax ** 2, -1))
-    (loss + 10.0 * bound).backward()
+    ent = torch.mean((torch.sum(lt, -1) + 0.5 * 29 * np.log(2.0 * np.pi * np.e))[sel])  # distribution_gaussian_diag.py:96-99
+    (loss + 10.0 * bound - ENT_W * ent).backward()
     out64 = np.zeros((M, 64), F)
     out64[:, :29], out64[:, 32:61] = mean, ls
     na32 = np.zeros((M, 32), F)
@@ -360,7 +362,7 @@ def test_actor_loss_with_a_log_std_head():
     nv, dm, stats, dmask = torch.zeros(1, device="cuda"), torch.full((M, 64), 7.0, device="cuda"), torch.zeros(8, device="cuda"), T(mask)
     L.call("addhip_count_mask", L.ptr(dmask), M, L.ptr(nv), L.current_stream())
     L.call("addhip_actor_loss", L.ptr(head), P(T(na32)), P(T(old)), P(T(adv)), L.ptr(dmask), M, float("nan"), float("nan"), None, 0.2, 10.0, 0.0, 1.0, L.ptr(nv),
-           L.ptr(dm), None, L.ptr(stats), 64, L.ptr(head) + 4 * 32, L.current_stream())
+           L.ptr(dm), None, L.ptr(stats), 64, L.ptr(head) + 4 * 32, ENT_W, L.current_stream())
     torch.cuda.synchronize()
     got = dm.cpu().numpy()
     gm, gl = mt.grad.numpy(), lt.grad.numpy()
@@ -368,6 +370,7 @@ def test_actor_loss_with_a_log_std_head():
     np.testing.assert_allclose(got[:, 32:61], gl, rtol=2e-4, atol=2e-4 * np.abs(gl).max())
     assert np.all(got[:, 29:32] == 0) and np.all(got[:, 61:] == 0)
     np.testing.assert_allclose(-stats.cpu().numpy()[0], loss.item(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(stats.cpu().numpy()[6], ent.item() if ENT_W else 0.0, rtol=1e-5)
 
 
 def test_critic_and_disc_heads_and_grad_penalty():
@@ -759,7 +762,7 @@ def test_fused_actor_head_equals_the_unfused_sequence(hidden, rows, trainable_st
     mean, d_mean, stats_a = z(M, 32), z(M, 32), z(8)
     L.call("addhip_gemm_f32", gemm(M, 32, K, L.ptr(H), K, 1, L.ptr(dWh), K, 1, L.ptr(mean), 32, L.EPI_BIAS, L.ptr(dbh)), st)
     L.call("addhip_actor_loss", L.ptr(mean), L.ptr(dna), L.ptr(dol), L.ptr(dadv), L.ptr(dmask), M, std, logp_const, dist, clip, bw, rw, ls, L.ptr(nv), L.ptr(d_mean),
-           L.ptr(want_gls) if trainable_std else None, L.ptr(stats_a), 32, None, st)
+           L.ptr(want_gls) if trainable_std else None, L.ptr(stats_a), 32, None, 0.0, st)
     torch.cuda.synchronize()
     dm64, H64 = d_mean.cpu().numpy().astype(np.float64), H.cpu().numpy().astype(np.float64)
     want_gW, want_gb = dm64.T @ H64, dm64.sum(0)

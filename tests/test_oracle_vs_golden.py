@@ -323,7 +323,7 @@ def golden_loss_cfg(g):
     return L.LossCfg(**(json.loads(str(g["agent_over"])) if "agent_over" in g.files else {}))
 
 
-@pytest.mark.parametrize("name", ["losses", "losses_small_nets", "losses_constant_std", "losses_disc3", "losses_constant_std_entropy", "losses_variable_std"])
+@pytest.mark.parametrize("name", ["losses", "losses_small_nets", "losses_constant_std", "losses_disc3", "losses_constant_std_entropy", "losses_variable_std", "losses_variable_std_entropy"])
 def test_losses_grads_adamw(name):
     g = gload(name)
     model = L.Model(L.synth_params(int(g["seed"]), nets=golden_nets(g), logstd=golden_logstd(g)))

@@ -333,6 +333,10 @@ def gen_losses_variable_std():
     gen_losses("losses_variable_std", None, logstd="variable")
 
 
+def gen_losses_variable_std_entropy():
+    gen_losses("losses_variable_std_entropy", None, logstd="variable", agent_over=dict(action_entropy_weight=0.05))
+
+
 def gen_losses_constant_std_entropy():
     """the same with the entropy bonus on (action_entropy_weight = 0.05, ppo_agent.py:262-266): its gradient reaches the log-std only."""
     gen_losses("losses_constant_std_entropy", None, logstd=True, agent_over=dict(action_entropy_weight=0.05))
@@ -629,4 +633,4 @@ def gen_test_rollout():
 
 AGENT_GENS = dict(obs_reward_done_s4=lambda: gen_obs_reward_done_s2(4, "four"), reset_s4=lambda: gen_reset_s2(4),
                   loop_1iter_s4=lambda: gen_loop_1iter("loop_1iter_s4", task_over=dict(num_disc_obs_steps=4)), obs_reward_done_s2=gen_obs_reward_done_s2, reset_s2=gen_reset_s2, loop_1iter_s2=lambda: gen_loop_1iter("loop_1iter_s2", task_over=dict(num_disc_obs_steps=2)), loop_1iter_two=gen_loop_1iter_two, loop_1iter_time=gen_loop_1iter_time, logger=gen_logger, state_dict=gen_state_dict, test_rollout=gen_test_rollout, obs_reward_done=gen_obs_reward_done, obs_reward_done_jw=gen_obs_reward_done_jw, reset=gen_reset, sampler=gen_sampler, actor_step=gen_actor_step,
-                  td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, losses_small_nets=gen_losses_small_nets, losses_disc3=gen_losses_disc3, losses_variable_std=gen_losses_variable_std, actor_step_variable_std=lambda: gen_actor_step("actor_step_variable_std", "variable"), losses_constant_std_entropy=gen_losses_constant_std_entropy, losses_constant_std=gen_losses_constant_std, actor_step_constant_std=lambda: gen_actor_step("actor_step_constant_std", True), normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
+                  td_lambda_adv=gen_td_lambda_adv, losses=gen_losses, losses_small_nets=gen_losses_small_nets, losses_disc3=gen_losses_disc3, losses_variable_std=gen_losses_variable_std, losses_variable_std_entropy=gen_losses_variable_std_entropy, actor_step_variable_std=lambda: gen_actor_step("actor_step_variable_std", "variable"), losses_constant_std_entropy=gen_losses_constant_std_entropy, losses_constant_std=gen_losses_constant_std, actor_step_constant_std=lambda: gen_actor_step("actor_step_constant_std", True), normalizers=gen_normalizers, loop_1iter=gen_loop_1iter)
